@@ -1,0 +1,223 @@
+"""CPU oracle: NumPy restatement of the callback providers on the path.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/cpu_ref.py``).
+
+Restated from the reference (file:line relative to /root/reference):
+
+* ``Problem.g``            zfista/problems.py:101-117   (shifted l1 values, box -> inf)
+* ``Problem.prox_wsum_g``  zfista/problems.py:119-138   (composed soft-thresholds, box clip)
+* ``JOS1.f / jac_f``       zfista/problems.py:193-205
+* ``FDS.f / jac_f``        zfista/problems.py:309-328
+* test-LASSO closures      tests/test_proximal_gradient.py:49-61,81-97
+
+Third-party arithmetic not under /root/reference: jaxopt (unpinned,
+pyproject.toml:16).  ``jaxopt.prox.prox_lasso(x, t) = sign(x) * relu(|x| - t)``
+and ``jaxopt.projection.projection_box(x, (lo, hi)) = clip(x, lo, hi)`` are
+restated from their published definitions; the reference's own known answers at
+that boundary (tests/test_problems.py:37-42,69-74,121-126 and the toy-LASSO
+optima, tests/test_proximal_gradient.py:103-114) pin them and are checked in
+``tests/test_oracle_golden.py``.
+
+The single-objective operator families used by the benchmark configurations
+(diagonal quadratic + l1, dense least squares + l1) have no class in the
+reference; their NumPy expressions are *defined* here and the HIP engine
+follows them term by term.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def soft_threshold(u, tau):
+    """prox of tau*|.|: sign(u) * max(|u| - tau, 0)  (jaxopt.prox.prox_lasso)."""
+    return np.sign(u) * np.maximum(np.abs(u) - tau, 0)
+
+
+def clip_box(u, lo, hi):
+    """jaxopt.projection.projection_box."""
+    return np.clip(u, lo, hi)
+
+
+# --------------------------------------------------------------------------
+# Problem family of zfista/problems.py (multi-objective, shifted l1 + box)
+# --------------------------------------------------------------------------
+class ProblemRef:
+    """g and prox_wsum_g shared by every reference problem (problems.py:63-138)."""
+
+    def __init__(self, n_features, n_objectives, l1_ratios=None, l1_shifts=None, bounds=None):
+        self.n_features = n_features
+        self.n_objectives = n_objectives
+        self.l1_ratios = None if l1_ratios is None else np.array(l1_ratios)
+        self.l1_shifts = np.zeros(n_objectives) if l1_shifts is None else np.array(l1_shifts)
+        self.bounds = bounds
+
+    def g(self, x):
+        if self.n_features != len(x):
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        if self.bounds is not None:
+            lo, hi = self.bounds
+            if (x < lo).any() or (x > hi).any():
+                return np.full(self.n_objectives, np.inf)
+        if self.l1_ratios is None:
+            return np.zeros(self.n_objectives)
+        if self.n_objectives != len(self.l1_ratios):
+            raise ValueError("len(l1_ratios) should be equal to n_objectives.")
+        if self.n_objectives != len(self.l1_shifts):
+            raise ValueError("len(l1_shifts) should be equal to n_objectives.")
+        dist = np.linalg.norm(x - self.l1_shifts.reshape(-1, 1), ord=1, axis=1)
+        return self.l1_ratios * dist
+
+    def prox_wsum_g(self, weight, x):
+        if self.n_features != len(x):
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        if self.n_objectives != len(weight):
+            raise ValueError("len(weight) should be equal to n_objectives.")
+        if self.l1_ratios is not None:
+            coef = weight * self.l1_ratios
+            s = self.l1_shifts
+            # stage 0 adds and subtracts s[0]: shift 0 is (net) ignored (:129)
+            x = soft_threshold(x + np.sum(coef[1:]) - s[0] + s[0], coef[0])
+            for i in range(1, self.n_objectives):
+                x = soft_threshold(x - coef[i] - s[i], coef[i]) + s[i]
+        if self.bounds is not None:
+            x = clip_box(x, self.bounds[0], self.bounds[1])
+        return x
+
+    def callbacks(self):
+        return self.f, self.g, self.jac_f, self.prox_wsum_g
+
+
+class JOS1Ref(ProblemRef):
+    def __init__(self, n_features=5, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(n_features, 2, l1_ratios, l1_shifts, bounds)
+
+    def f(self, x):
+        if self.n_features != len(x):
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        n = self.n_features
+        return np.array([np.linalg.norm(x) ** 2 / n, np.linalg.norm(x - 2) ** 2 / n])
+
+    def jac_f(self, x):
+        if self.n_features != len(x):
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        n = self.n_features
+        return np.vstack((2 * x / n, 2 * (x - 2) / n))
+
+
+class FDSRef(ProblemRef):
+    def __init__(self, n_features=10, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(n_features, 3, l1_ratios, l1_shifts, bounds)
+        self.idx = np.arange(n_features) + 1          # one_to_n (:309)
+        self.conv = self.idx * self.idx[::-1]          # i (n - i + 1) (:310)
+
+    def f(self, x):
+        if self.n_features != len(x):
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        n = self.n_features
+        f1 = np.inner(self.idx, (x - self.idx) ** 4) / n**2
+        f2 = np.exp(x.sum() / n) + np.linalg.norm(x) ** 2
+        f3 = np.inner(self.conv, np.exp(-x)) / (n * (n + 1))
+        return np.array([f1, f2, f3])
+
+    def jac_f(self, x):
+        if self.n_features != len(x):
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        n = self.n_features
+        r1 = 4 / n**2 * self.idx * (x - self.idx) ** 3
+        r2 = np.exp(x.sum() / n) / n + 2 * x
+        r3 = -self.conv * np.exp(-x) / (n * (n + 1))
+        return np.vstack((r1, r2, r3))
+
+
+# --------------------------------------------------------------------------
+# Single-objective operator families (benchmark configurations)
+# --------------------------------------------------------------------------
+class DiagQuadL1Ref:
+    """f(x) = 1/2 sum d_i (x_i - c_i)^2,  g(x) = lam ||x||_1   (P-diag)."""
+
+    def __init__(self, d, c, lam):
+        self.d, self.c, self.lam = np.asarray(d, float), np.asarray(c, float), float(lam)
+
+    def f(self, x):
+        r = x - self.c
+        return 0.5 * np.sum(self.d * (r * r))
+
+    def g(self, x):
+        return self.lam * np.sum(np.abs(x))
+
+    def jac_f(self, x):
+        return self.d * (x - self.c)
+
+    def prox_wsum_g(self, weight, x):
+        return soft_threshold(x, self.lam * weight)
+
+    def callbacks(self):
+        return self.f, self.g, self.jac_f, self.prox_wsum_g
+
+
+class LeastSquaresL1Ref:
+    """f(x) = scale ||Ax - b||^2,  g(x) = lam ||x||_1   (P-lasso; scale 1/2).
+
+    The test closures of the reference are the scale = 1/6 member
+    (tests/test_proximal_gradient.py:81-97).
+    """
+
+    def __init__(self, A, b, lam, scale=0.5):
+        self.A = np.asarray(A, float)
+        self.b = np.asarray(b, float)
+        self.lam, self.scale = float(lam), float(scale)
+
+    def f(self, x):
+        return self.scale * np.linalg.norm(self.A @ x - self.b) ** 2
+
+    def g(self, x):
+        return self.lam * np.linalg.norm(x, ord=1)
+
+    def jac_f(self, x):
+        return (2 * self.scale) * (self.A.T @ (self.A @ x - self.b))
+
+    def prox_wsum_g(self, weight, x):
+        return soft_threshold(x, self.lam * weight)
+
+    def callbacks(self):
+        return self.f, self.g, self.jac_f, self.prox_wsum_g
+
+
+def stacked(problem, m):
+    """The reference's m-fold duplicated test objectives
+    (tests/test_proximal_gradient.py:128-149,181-202): every objective equal,
+    prox uses weight.sum()."""
+
+    def f(x):
+        return np.full(m, problem.f(x))
+
+    def g(x):
+        return np.full(m, problem.g(x))
+
+    def jac_f(x):
+        return np.vstack([problem.jac_f(x)] * m)
+
+    def prox_wsum_g(weight, x):
+        return problem.prox_wsum_g(weight.sum(), x)
+
+    return f, g, jac_f, prox_wsum_g
+
+
+# --------------------------------------------------------------------------
+# Synthetic inputs of SURVEY.md 8(d) (seeded; shared by tests and bench)
+# --------------------------------------------------------------------------
+def make_pdiag(n, seed=1, lam=0.1):
+    rng = np.random.default_rng(seed)
+    d = rng.uniform(0.5, 2.0, n)
+    c = rng.standard_normal(n)
+    return d, c, lam
+
+
+def make_plasso(m_rows, n, seed=0, n_informative=20, noise=0.01, lam_frac=0.1):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m_rows, n))
+    x_true = np.zeros(n)
+    x_true[:n_informative] = rng.standard_normal(n_informative)
+    b = A @ x_true + noise * rng.standard_normal(m_rows)
+    lam = lam_frac * np.max(np.abs(A.T @ b))
+    return A, b, lam
