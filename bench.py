@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py - FISTA iterations/sec of the fused grad+prox+momentum step (P-diag).
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1
+the driver launches one rank per GPU with torch.distributed.run.  A "step" is one
+FISTA iteration (one accepted line-search trial) over this rank's 10^8-element
+shard of the decision vector; lr = 0.45 < 1/max(d) so every trial is accepted
+(checked).  Inputs are generated on the device and are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line.
+
+value = (N * K) / t : iterations per second in units of one 10^8-element shard.
+At N = 1 that is exactly BASELINE.json's metric (FISTA it/s at n = 10^8); for
+N > 1 (weak scaling: n = N x 10^8) the full-problem rate K / t is reported beside
+it as ``config.iters_per_sec_full_problem``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PER_GPU = 10**8
+ALG_BYTES_PER_ELEM = 40          # read x_k, x_{k-1}, d, c ; write x+   
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LR, LAM = 0.45, 0.1
+
+
+def make_inputs(n, seed, device):
+    import torch
+
+    gen = torch.Generator(device=device).manual_seed(seed)
+    d = torch.rand(n, dtype=torch.float64, device=device, generator=gen) * 1.5 + 0.5   # U[0.5, 2]
+    c = torch.randn(n, dtype=torch.float64, device=device, generator=gen)
+    return d, c
+
+
+def cpu_baseline(d, c, sample_n=10**7, iters=5):
+    """The oracle (NumPy restatement of the reference path) on the host cores,
+    on a bounded sample of the same workload.  Reported, never a target."""
+    from oracle import cpu_ref, problems_ref as P
+
+    ds = d[:sample_n].cpu().numpy()
+    cs = c[:sample_n].cpu().numpy()
+    ref = P.DiagQuadL1Ref(ds, cs, LAM)
+    x0 = np.zeros(sample_n)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t0 = time.perf_counter()
+        res = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, lr=LR, nesterov=True, tol=0.0,
+                                                 max_iter=iters)
+        dt = time.perf_counter() - t0
+    assert res.nit == iters
+    its = iters / dt
+    return {
+        "value": its * sample_n / N_PER_GPU,
+        "unit": "iterations/s (n=1e8)",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {sample_n:.0e} of 1e8 elements, {iters} FISTA iterations in {dt:.1f} s "
+                  f"({its:.3f} it/s at n={sample_n:.0e}), scaled by n to 1e8; elementwise NumPy is "
+                  f"single-threaded (host has {os.cpu_count()} cores)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=N_PER_GPU, help="elements per GPU (default 1e8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        group = dist.group.WORLD
+
+    from zfista_amd import _lib
+    from zfista_amd.problems import DiagQuadL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    n = args.n
+    K, W = args.steps, args.warmup
+    d, c = make_inputs(n, seed=1 + rank, device="cuda")
+    prob = DiagQuadL1(d, c, LAM, group=group)
+    opts = dict(lr=LR, tol=0.0, tol_internal=1e-12, max_iter=K + W, max_backtrack_iter=100, decay_rate=0.5,
+                nesterov=True, nesterov_ratio=(0, 0.25), deprecated=False)
+    run = NativeRun(prob, torch.zeros(n, dtype=torch.float64, device="cuda"), opts, timing=True)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    done = 0
+    while done < W:
+        done += len(run.advance(min(W - done, _lib.ZF_RING)))
+    run.solver.trial_kernel_ms()          # reset the event window after warm-up
+    nit0 = run.nit_seen
+    sync_all()
+    t0 = time.perf_counter()
+    accepted = 0
+    while accepted < K:          # a rejected trial (lr halves, :305) costs an extra launch
+        run.enqueue_only(min(K - accepted, _lib.ZF_RING))
+        accepted += len(run.collect())
+    sync_all()
+    dt = time.perf_counter() - t0
+    assert run.nit_seen - nit0 == K, f"expected {K} accepted iterations, got {run.nit_seen - nit0}"
+    ker_ms, ker_n = run.solver.trial_kernel_ms()
+    assert ker_n >= K
+    trials_per_iter = ker_n / K
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        achieved = ALG_BYTES_PER_ELEM * n / (ker_ms * 1e-3) / 1e9
+        line = {
+            "metric": "fista_iterations_per_sec_n1e8_per_gpu_shard",
+            "value": world * K / dt * (n / N_PER_GPU),
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "P-diag l1-regularised diagonal quadratic, fused grad+soft-threshold+momentum, "
+                            f"n={n:.0e} per GPU, FISTA (a,b)=(0,0.25), lr=0.45, lam=0.1",
+                "n_per_gpu": n,
+                "n_total": n * world,
+                "iters_per_sec_full_problem": K / dt,
+                "trials_per_iteration": trials_per_iter,
+                "parallelism": f"x sharded over {world} GPU(s); per-trial scalar pack all-gather"
+                               if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "zf_trial_kernel<grad inline, nesterov>",
+                "kernel_avg_ms": ker_ms,
+                "algorithmic_bytes_per_launch": ALG_BYTES_PER_ELEM * n,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(d, c)
+        print(json.dumps(line), flush=True)
+    run.solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

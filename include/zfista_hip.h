@@ -1,0 +1,208 @@
+/* zfista_hip.h - C ABI of libzfista_hip.so, the MI355X (gfx950) engine behind
+ * zfista_amd.minimize_proximal_gradient().
+ *
+ * The reference (zalgo3/zfista) has no FFI: the path it replaces is the Python
+ * keyword API zfista/proximal_gradient.py:311-331.  This header is therefore the
+ * interface the drop-in's own Python host binds through ctypes (INTEGRATION.md
+ * shows the binding a zfista maintainer would add).  Every entry point names the
+ * reference lines whose arithmetic it carries.
+ *
+ * Conventions: plain C, no exceptions across the boundary; every function
+ * returns ZF_OK (0) or a negative ZF_ERR_* and leaves a message retrievable with
+ * zf_last_error() (thread-local); sizes are int64_t, reals are double (the
+ * reference is float64 throughout: zfista/problems.py:22); "dev" pointers are
+ * device (HBM) addresses owned by the caller unless stated; `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  One solver object
+ * per host thread/process and GPU; stream-ordered; thread-compatible, not
+ * thread-safe.
+ */
+#ifndef ZFISTA_HIP_H
+#define ZFISTA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZF_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------ */
+#define ZF_OK 0
+#define ZF_ERR_HIP (-1)      /* a HIP runtime call failed (message has details) */
+#define ZF_ERR_ARG (-2)      /* invalid argument */
+#define ZF_ERR_STATE (-3)    /* call sequence violated */
+#define ZF_ERR_NODEVICE (-4) /* no usable GPU */
+
+/* ---- zf_control.status: where the device-resident loop stands ---------- */
+#define ZF_RUNNING 0
+#define ZF_CONVERGED 1          /* err < tol            proximal_gradient.py:525-529 */
+#define ZF_MAXITER 2            /* loop exhausted       proximal_gradient.py:539-543 */
+#define ZF_BACKTRACK_FAILED 3   /* RuntimeError         proximal_gradient.py:306-307 */
+
+/* ---- problem kinds (single objective, recognised descriptors) ---------- */
+#define ZF_PROBLEM_DIAG_QUAD_L1 1     /* f = 1/2 sum d_i (x_i-c_i)^2, g = lam |x|_1 (+box) */
+#define ZF_PROBLEM_LEAST_SQUARES_L1 2 /* f = scale |Ax-b|^2,          g = lam |x|_1 (+box) */
+
+#define ZF_PACK_LEN 8    /* doubles in one per-trial scalar pack */
+#define ZF_TRACE_COLS 8  /* doubles per accepted iteration in the trace ring */
+#define ZF_RING 1024     /* capacity (iterations) of the trace and momentum rings */
+
+/* Device-resident control block of the line-search / termination logic
+ * (proximal_gradient.py:279-307,510,525-538).  Lives in HBM; the decide kernel
+ * is its only writer while a chunk of trials is in flight; zf_solver_poll()
+ * copies it to the host.  Field order is ABI: the Python host mirrors it as a
+ * numpy structured dtype and checks zf_sizeof_control(). */
+typedef struct zf_control {
+    double lr;            /* current learning rate; only ever shrinks (:305)          */
+    double F_old;         /* F(x_k) = f + g at the latest accepted iterate (:279)    */
+    double f_x, g_x;      /* its two parts                                            */
+    double err;           /* max|x_k - y_k| of the latest accepted iteration (:510)  */
+    double fun;           /* model value of the latest accepted trial (:149-155)     */
+    double tol;           /* outer tolerance (:525)                                   */
+    double tol_internal;  /* slack of the sufficient-decrease test (:303, tol=...)   */
+    double decay_rate;    /* (:305); == 1 accepts unconditionally (:298)             */
+    double f_y;           /* f(y_k) of the current line search                        */
+    int64_t nit;          /* accepted outer iterations so far                         */
+    int64_t max_iter;
+    int64_t trial;        /* trials spent in the current line search                  */
+    int64_t max_backtrack;
+    int64_t total_trials; /* over the whole run                                       */
+    int32_t status;       /* ZF_RUNNING ...                                           */
+    int32_t cur;          /* which of the three x buffers holds x_k                   */
+    int32_t nesterov;
+    int32_t deprecated;   /* deprecated acceptance test (:300-302)                    */
+    int32_t need_grad;    /* least squares: gradient at y_k must be (re)computed      */
+    int32_t world;        /* ranks whose packs are summed by the decide step          */
+    int32_t reserved[2];
+} zf_control;
+
+typedef struct zf_problem_desc {
+    int32_t kind;      /* ZF_PROBLEM_*                                                */
+    int32_t world;     /* ranks sharing the decision vector (1 = unsharded)           */
+    int32_t rank;
+    int32_t reserved;
+    int64_t n;         /* local length of x (this rank's shard)                       */
+    int64_t m_rows;    /* least squares: rows of A (0 otherwise)                      */
+    const double* d;   /* dev, n   - DIAG_QUAD_L1                                     */
+    const double* c;   /* dev, n   - DIAG_QUAD_L1                                     */
+    const double* A;   /* dev, m_rows x n row-major - LEAST_SQUARES_L1                */
+    const double* b;   /* dev, m_rows                                                 */
+    double scale;      /* LEAST_SQUARES_L1: f = scale |Ax-b|^2                        */
+    double lam;        /* l1 weight                                                   */
+    double box_lo;     /* -inf / +inf when there is no box                            */
+    double box_hi;
+} zf_problem_desc;
+
+typedef struct zf_options {  /* keyword arguments of proximal_gradient.py:317-330 */
+    double lr;
+    double tol;
+    double tol_internal;
+    double decay_rate;
+    int64_t max_iter;
+    int64_t max_backtrack_iter;
+    int32_t nesterov;
+    int32_t deprecated;
+} zf_options;
+
+typedef struct zf_solver zf_solver; /* opaque; owns x ring, partials, control, rings */
+
+/* ---- library, device, memory ------------------------------------------- */
+int zf_abi_version(void);
+const char* zf_last_error(void);
+int64_t zf_sizeof_control(void);
+int zf_device_count(int* count);
+int zf_set_device(int device);
+int zf_malloc(void** dev_ptr, int64_t bytes);
+int zf_free(void* dev_ptr);
+int zf_memcpy_h2d(void* dst_dev, const void* src_host, int64_t bytes, void* stream);
+int zf_memcpy_d2h(void* dst_host, const void* src_dev, int64_t bytes, void* stream);
+int zf_memcpy_d2d(void* dst_dev, const void* src_dev, int64_t bytes, void* stream);
+int zf_stream_synchronize(void* stream);
+
+/* ---- the decision step on the host (no GPU needed) ----------------------
+ * Same inline function the decide kernel runs (csrc/zf_decide.h); exported so
+ * the control logic of proximal_gradient.py:279-307,510,525-543 can be tested
+ * on a machine without a GPU.  `packs` holds `world` packs of ZF_PACK_LEN
+ * doubles; `trace` is a ZF_RING x ZF_TRACE_COLS ring. */
+int zf_decide_host(zf_control* ctl, const double* packs, double* trace);
+
+/* ---- device-resident single-objective solver -----------------------------
+ * Replaces the body of the outer loop, proximal_gradient.py:474-538, for the
+ * recognised problem kinds.  One "step" = one line-search trial:
+ *   trial kernel  : y = x_k + beta (x_k - x_{k-1})            (:534)
+ *                   x+ = prox_{lr g}(y - lr grad f(y))         (:148)
+ *                   per-block partials of f(y), <grad f,x+-y>, |x+-y|^2,
+ *                   g(x+), f(x+), max|x+-y|                    (:140,:150-152,:295,:510)
+ *   finalize      : fixed-order reduction of the partials -> pack
+ *   decide        : model value, acceptance, lr decay, termination, buffer
+ *                   rotation, trace row                        (:149-155,:298-305,:525)
+ */
+int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, const zf_options* opt,
+                     void* stream);
+int zf_solver_destroy(zf_solver* s);
+/* copy x0 (dev, n) into the ring and evaluate f(x0), g(x0) -> local init pack (:463-466) */
+int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev);
+/* consume the (gathered) init packs: F_old = sum over ranks; world == 1 may skip the gather */
+int zf_solver_enqueue_init_commit(zf_solver* s);
+/* momentum factors beta_j for accepted-iteration indices first..first+count-1 (:531-533) */
+int zf_solver_set_beta(zf_solver* s, int64_t first, const double* beta_host, int64_t count);
+/* world == 1: enqueue `steps` complete steps (trial+finalize+decide), no host sync */
+int zf_solver_enqueue_steps(zf_solver* s, int64_t steps);
+/* world > 1: the two halves of a step; the caller gathers pack_local -> pack_all between them */
+int zf_solver_enqueue_trial(zf_solver* s);
+int zf_solver_enqueue_decide(zf_solver* s);
+/* device addresses of this rank's pack (ZF_PACK_LEN doubles) and of the gathered
+ * packs (world x ZF_PACK_LEN doubles, rank-major) */
+int zf_solver_pack_ptrs(zf_solver* s, double** pack_local_dev, double** pack_all_dev);
+/* make the solver write / read caller-owned pack buffers instead (e.g. torch
+ * tensors the collective runs on); sizes as above; must outlive the solver */
+int zf_solver_set_pack_buffers(zf_solver* s, double* pack_local_dev, double* pack_all_dev);
+/* synchronise the stream, copy out the control block and the trace ring */
+int zf_solver_poll(zf_solver* s, zf_control* ctl_host, double* trace_host /* ZF_RING*ZF_TRACE_COLS */);
+/* device address / host copy of the latest accepted iterate x_k (local shard) */
+int zf_solver_x_dev(zf_solver* s, const double** x_dev);
+int zf_solver_get_x(zf_solver* s, double* x_host);
+/* average duration (ms) of the trial kernel over the launches since the last
+ * call, measured with HIP events on the solver's stream; resets the window */
+int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches);
+int zf_solver_set_timing(zf_solver* s, int32_t enabled);
+
+/* ---- vector kernels for opaque (Python) callbacks ------------------------
+ * The solver's own O(n) arithmetic when f/g/jac_f/prox are arbitrary host
+ * callables: v = y - lr*jac (:148), {<jac,x-y>, |x-y|^2, max|x-y|} (:150-152,
+ * :510) and y = x + beta (x - x_old) (:534).  Host pointers in, host pointers
+ * out; the library stages through its own device workspace. */
+int zf_host_grad_step(double* v_host, const double* y_host, const double* jac_host, double lr,
+                      int64_t n);
+int zf_host_model_terms(const double* jac_host, const double* x_host, const double* y_host,
+                        int64_t n, double out3[3]);
+int zf_host_momentum(double* y_out_host, const double* x_host, const double* x_old_host,
+                     double beta, int64_t n);
+
+/* ---- operator evaluations at a host point ---------------------------------
+ * The callback contract of proximal_gradient.py rows f / g / jac_f /
+ * prox_wsum_g (:140-148) for the recognised operators, evaluated on the GPU at
+ * a point given in host memory (problem data stays in HBM).  These back the
+ * NumPy-callable methods of zfista_amd.problems.* . */
+/* out = sign(x) max(|x| - tau, 0), then clip to [lo, hi]   (problems.py:128-137) */
+int zf_host_prox_l1_box(double* out_host, const double* x_host, double tau, double lo, double hi,
+                        int64_t n);
+/* out = sum |x_i|   (the l1 value of g, tests/test_proximal_gradient.py:53) */
+int zf_host_asum(const double* x_host, int64_t n, double* out);
+/* out = d * (x - c) */
+int zf_host_diag_grad(double* out_host, const double* x_host, const double* d_dev,
+                      const double* c_dev, int64_t n);
+/* f = scale |A x - b|^2 and (grad_out_host != NULL) grad = 2 scale A^T (A x - b)
+ * (tests/test_proximal_gradient.py:49-57) */
+int zf_ls_eval(const double* A_dev, const double* b_dev, int64_t m_rows, int64_t n, double scale,
+               const double* x_host, double* f_out, double* grad_out_host);
+
+/* ---- device vector kernels (device pointers) ----------------------------- */
+int zf_eval_diag_l1(const double* x_dev, const double* d_dev, const double* c_dev, double lam,
+                    int64_t n, double out2_host[2], void* stream); /* f(x), g(x) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZFISTA_HIP_H */

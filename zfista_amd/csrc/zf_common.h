@@ -1,0 +1,96 @@
+// zf_common.h - error plumbing and wave64/LDS reduction helpers (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/zfista_hip.h"
+
+// ---- error plumbing ------------------------------------------------------
+extern thread_local char zf_errbuf[512];
+static inline int zf_fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+    snprintf(zf_errbuf, sizeof(zf_errbuf), fmt, a, b);
+    return code;
+}
+#define ZF_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) return zf_fail(ZF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define ZF_REQUIRE(cond, msg)                                  \
+    do {                                                       \
+        if (!(cond)) return zf_fail(ZF_ERR_ARG, "%s%s", msg);  \
+    } while (0)
+
+// ---- launch geometry -----------------------------------------------------
+// Streaming kernels: 256-thread blocks (4 waves, one per SIMD), at most 2048
+// blocks (256 CUs x 8) and grid-stride beyond that (guide: Guideline 11).
+constexpr int ZF_BLOCK = 256;
+constexpr int ZF_MAX_GRID = 2048;
+constexpr int ZF_WAVES = ZF_BLOCK / 64;
+
+static inline int zf_grid_for(int64_t items_per_thread_units) {
+    int64_t blocks = (items_per_thread_units + ZF_BLOCK - 1) / ZF_BLOCK;
+    if (blocks < 1) blocks = 1;
+    if (blocks > ZF_MAX_GRID) blocks = ZF_MAX_GRID;
+    return (int)blocks;
+}
+
+// ---- wave64 + LDS block reductions ----------------------------------------
+// Fixed shuffle tree (offsets 32..1) inside the wave, lane 0 of each wave
+// stages its value in LDS, thread k adds the four wave values in wave order:
+// the result depends only on the launch geometry, never on timing.
+__device__ __forceinline__ double zf_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double zf_wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// Reduce NS sums and NM maxima held per thread; thread k < NS+NM of the block
+// returns the block total of quantity k in `out` (valid only for those threads).
+template <int NS, int NM, int WAVES>
+__device__ __forceinline__ void zf_block_reduce(const double (&sums)[NS], const double (&maxs)[NM > 0 ? NM : 1],
+                                                double* lds /* WAVES*(NS+NM) */, double& out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        double v = zf_wave_sum(sums[k]);
+        if (lane == 0) lds[wave * (NS + NM) + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        double v = zf_wave_max(maxs[k]);
+        if (lane == 0) lds[wave * (NS + NM) + NS + k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS + NM) {
+        const int k = threadIdx.x;
+        double v = lds[k];
+        if (k < NS) {
+            for (int w = 1; w < WAVES; ++w) v += lds[w * (NS + NM) + k];
+        } else {
+            for (int w = 1; w < WAVES; ++w) v = fmax(v, lds[w * (NS + NM) + k]);
+        }
+        out = v;
+    }
+}
+
+// soft-threshold, prox of tau*|.|:  sign(u) * max(|u| - tau, 0)
+// (jaxopt.prox.prox_lasso as used at zfista/problems.py:128-135 and
+// tests/test_proximal_gradient.py:61).  NaN propagates as in NumPy.
+__device__ __forceinline__ double zf_soft_threshold(double u, double tau) {
+    double a = fabs(u) - tau;
+    a = (a < 0.0) ? 0.0 : a;
+    return copysign(a, u);
+}
+// np.clip(u, lo, hi) = minimum(maximum(u, lo), hi)  (jaxopt projection_box, problems.py:137)
+__device__ __forceinline__ double zf_clip(double u, double lo, double hi) {
+    double t = (u < lo) ? lo : u;
+    return (t > hi) ? hi : t;
+}

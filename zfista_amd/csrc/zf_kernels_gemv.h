@@ -1,0 +1,199 @@
+// zf_kernels_gemv.h - dense fp64 least-squares kernels (K14):
+//   f(x) = scale |Ax - b|^2,  grad f(y) = 2 scale A^T (A y - b)
+// (tests/test_proximal_gradient.py:49-57 with scale = 1/6; BASELINE cfg1/cfg3
+// with scale = 1/2).  A is row-major m_rows x n in HBM and is streamed exactly
+// twice per accepted trial: once by rows for A x+ and once by columns for
+// A^T r.  A y is obtained by linearity from the cached A x_k, A x_{k-1}.
+// Both sweeps are HBM-bound (0.25 flop/B); they use 16-B loads (V = 2; V = 1
+// is the scalar form for odd n, where rows are not 16-B aligned), one row
+// panel or column panel per workgroup and fixed-order reductions.
+#pragma once
+#include "zf_common.h"
+
+struct zf_ring3 {
+    double* p[3];
+};
+
+template <int V> struct zf_vec;
+template <> struct zf_vec<1> { using type = double; };
+template <> struct zf_vec<2> { using type = double2; };
+template <int V> __device__ __forceinline__ void zf_fma_acc(double (&acc)[V], typename zf_vec<V>::type a, double s);
+template <> __device__ __forceinline__ void zf_fma_acc<1>(double (&acc)[1], double a, double s) { acc[0] += a * s; }
+template <> __device__ __forceinline__ void zf_fma_acc<2>(double (&acc)[2], double2 a, double s) {
+    acc[0] += a.x * s;
+    acc[1] += a.y * s;
+}
+template <int V> __device__ __forceinline__ double zf_dot_v(typename zf_vec<V>::type a, typename zf_vec<V>::type b);
+template <> __device__ __forceinline__ double zf_dot_v<1>(double a, double b) { return a * b; }
+template <> __device__ __forceinline__ double zf_dot_v<2>(double2 a, double2 b) { return a.x * b.x + a.y * b.y; }
+
+// ---- s_out = A x_in  (row dot products) ------------------------------------
+// One workgroup owns GEMV_ROWS consecutive rows; threads sweep the columns in
+// V-wide units so every wave load is contiguous per row; x (n doubles) is
+// re-read by every workgroup from L2 / Infinity Cache.
+// slot: -1 -> x_in = xr.p[0], s_out = sr.p[0] (plain call)
+//       >=0 -> relative ring slot: index (ctl->cur + slot) % 3 on both rings.
+constexpr int GEMV_ROWS = 4;
+template <int V>
+__global__ __launch_bounds__(ZF_BLOCK) void zf_gemv_rows_kernel(const zf_control* ctl,
+                                                                const double* __restrict__ A,
+                                                                zf_ring3 xr, zf_ring3 sr, int slot,
+                                                                int64_t m_rows, int64_t n) {
+    using VT = typename zf_vec<V>::type;
+    __shared__ double lds[ZF_WAVES * GEMV_ROWS];
+    int idx = 0;
+    if (slot >= 0) {
+        if (ctl->status != ZF_RUNNING) return;
+        idx = (ctl->cur + slot) % 3;
+    }
+    const double* __restrict__ x = xr.p[idx];
+    double* __restrict__ s = sr.p[idx];
+    const int64_t nv = n / V;
+    const VT* __restrict__ xv = reinterpret_cast<const VT*>(x);
+    for (int64_t row0 = (int64_t)blockIdx.x * GEMV_ROWS; row0 < m_rows;
+         row0 += (int64_t)gridDim.x * GEMV_ROWS) {
+        double acc[GEMV_ROWS];
+#pragma unroll
+        for (int r = 0; r < GEMV_ROWS; ++r) acc[r] = 0.0;
+        for (int64_t j = threadIdx.x; j < nv; j += ZF_BLOCK) {
+            const VT xj = xv[j];
+#pragma unroll
+            for (int r = 0; r < GEMV_ROWS; ++r) {
+                if (row0 + r < m_rows) {
+                    const VT a = reinterpret_cast<const VT*>(A + (row0 + r) * n)[j];
+                    acc[r] += zf_dot_v<V>(a, xj);
+                }
+            }
+        }
+        const double maxs[1] = {0.0};
+        double out = 0.0;
+        zf_block_reduce<GEMV_ROWS, 0, ZF_WAVES>(acc, maxs, lds, out);
+        if (threadIdx.x < GEMV_ROWS && row0 + threadIdx.x < m_rows) s[row0 + threadIdx.x] = out;
+        __syncthreads();
+    }
+}
+
+// ---- residual at y by linearity + f(y) -------------------------------------
+// r = (s_k + beta (s_k - s_{k-1})) - b ;  f(y) = scale * (sqrt(sum r^2))^2
+// One workgroup (m_rows is at most a few 10^4).  Skipped unless ctl->need_grad.
+constexpr int RESID_BLOCK = 1024;
+__device__ __forceinline__ double zf_block_sum_1024(double acc, double* lds) {
+    acc = zf_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double t = lds[0];
+    for (int w = 1; w < RESID_BLOCK / 64; ++w) t += lds[w];
+    return t;
+}
+
+__global__ __launch_bounds__(RESID_BLOCK) void zf_resid_y_kernel(const zf_control* ctl,
+                                                                 const double* beta_ring, zf_ring3 sr,
+                                                                 const double* __restrict__ b,
+                                                                 double* __restrict__ r, double scale,
+                                                                 int64_t m_rows, double* f_out,
+                                                                 int nesterov) {
+    __shared__ double lds[RESID_BLOCK / 64];
+    if (ctl->status != ZF_RUNNING || !ctl->need_grad) return;
+    const int cur = ctl->cur;
+    const double beta = nesterov ? beta_ring[ctl->nit % ZF_RING] : 0.0;
+    const double* __restrict__ sk = sr.p[cur];
+    const double* __restrict__ so = sr.p[(cur + 2) % 3];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < m_rows; i += RESID_BLOCK) {
+        double ay = sk[i];
+        if (nesterov) ay = ay + beta * (ay - so[i]);
+        const double rv = ay - b[i];
+        r[i] = rv;
+        acc += rv * rv;
+    }
+    const double t = zf_block_sum_1024(acc, lds);
+    if (threadIdx.x == 0) {
+        const double nrm = sqrt(t);
+        *f_out = scale * (nrm * nrm);
+    }
+}
+
+// f(x) = scale * (sqrt(sum (s - b)^2))^2 for a computed s = A x
+// slot as in zf_gemv_rows_kernel.
+__global__ __launch_bounds__(RESID_BLOCK) void zf_resid_x_kernel(const zf_control* ctl, zf_ring3 sr,
+                                                                 int slot, const double* __restrict__ b,
+                                                                 double scale, int64_t m_rows,
+                                                                 double* f_out) {
+    __shared__ double lds[RESID_BLOCK / 64];
+    int idx = 0;
+    if (slot >= 0) {
+        if (ctl->status != ZF_RUNNING) return;
+        idx = (ctl->cur + slot) % 3;
+    }
+    const double* __restrict__ s = sr.p[idx];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < m_rows; i += RESID_BLOCK) {
+        const double rv = s[i] - b[i];
+        acc += rv * rv;
+    }
+    const double t = zf_block_sum_1024(acc, lds);
+    if (threadIdx.x == 0) {
+        const double nrm = sqrt(t);
+        *f_out = scale * (nrm * nrm);
+    }
+}
+
+// s <- s - b (residual in place; operator evaluation outside the solver loop)
+__global__ __launch_bounds__(ZF_BLOCK) void zf_axmb_kernel(double* __restrict__ s,
+                                                           const double* __restrict__ b, int64_t m_rows) {
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; i < m_rows; i += stride) s[i] = s[i] - b[i];
+}
+
+// ---- grad = 2 scale A^T r  (column sums) ------------------------------------
+// Grid (column panels of 256*V, row slices).  Each thread owns V adjacent
+// columns (one V*8-byte load per row) and walks its row slice; slice partials
+// go to a slab [slices][n] that a second kernel adds in slice order (no
+// atomics: bit-reproducible).
+constexpr int GEMVT_UNROLL = 8;
+template <int V>
+__global__ __launch_bounds__(ZF_BLOCK) void zf_gemvT_partial_kernel(const zf_control* ctl,
+                                                                    const double* __restrict__ A,
+                                                                    const double* __restrict__ r,
+                                                                    double* __restrict__ slab,
+                                                                    int64_t m_rows, int64_t n,
+                                                                    int64_t rows_per_slice) {
+    using VT = typename zf_vec<V>::type;
+    if (ctl && (ctl->status != ZF_RUNNING || !ctl->need_grad)) return;   // ctl == NULL: plain call
+    const int64_t colv = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x;  // V-wide unit
+    const int64_t nv = n / V;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
+    int64_t r1 = r0 + rows_per_slice;
+    if (r1 > m_rows) r1 = m_rows;
+    if (colv >= nv) return;
+    double acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.0;
+    const VT* __restrict__ Ac = reinterpret_cast<const VT*>(A) + colv;
+    int64_t i = r0;
+    for (; i + GEMVT_UNROLL <= r1; i += GEMVT_UNROLL) {
+        VT a[GEMVT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GEMVT_UNROLL; ++u) a[u] = Ac[(i + u) * nv];
+#pragma unroll
+        for (int u = 0; u < GEMVT_UNROLL; ++u) zf_fma_acc<V>(acc, a[u], r[i + u]);
+    }
+    for (; i < r1; ++i) zf_fma_acc<V>(acc, Ac[i * nv], r[i]);
+    double* out = slab + (int64_t)blockIdx.y * n + colv * V;
+#pragma unroll
+    for (int v = 0; v < V; ++v) out[v] = acc[v];
+}
+
+__global__ __launch_bounds__(ZF_BLOCK) void zf_gemvT_combine_kernel(const zf_control* ctl,
+                                                                    const double* __restrict__ slab,
+                                                                    double* __restrict__ grad,
+                                                                    double two_scale, int64_t n,
+                                                                    int slices) {
+    if (ctl && (ctl->status != ZF_RUNNING || !ctl->need_grad)) return;
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        double t = slab[j];
+        for (int s = 1; s < slices; ++s) t += slab[(int64_t)s * n + j];
+        grad[j] = two_scale * t;
+    }
+}

@@ -1,0 +1,673 @@
+// zf_solver.hip - device-resident single-objective proximal-gradient solver
+// and the C ABI of include/zfista_hip.h (gfx950 only).
+//
+// Replaces the outer loop body of zfista/proximal_gradient.py:474-538 for the
+// recognised problem kinds.  The host enqueues "steps" (one line-search trial
+// each) back to back on one HIP stream; acceptance, lr decay, termination and
+// buffer rotation happen in a one-workgroup decide kernel, so there is no host
+// round trip inside a chunk of steps.
+#include <new>
+#include <vector>
+
+#include "zf_common.h"
+#include "zf_decide.h"
+#include "zf_kernels_gemv.h"
+#include "zf_kernels_step.h"
+
+thread_local char zf_errbuf[512] = "";
+
+// ---------------------------------------------------------------------------
+// finalize / decide kernels
+// ---------------------------------------------------------------------------
+struct zf_fin_args {
+    const double* partials;
+    int nblocks;
+    double scale[ZF_NPART];   // pack[k] = scale[k] * total[k]
+    const double* f_y_ext;    // least squares: f(y), f(x+) computed by the GEMV side
+    const double* f_x_ext;
+    double* pack;             // local pack out (ZF_PACK_LEN)
+};
+
+__device__ __forceinline__ void zf_make_pack(const zf_fin_args& F, const double* totals, double* pack) {
+    // thread 0 only
+    pack[ZF_PK_FY] = F.f_y_ext ? *F.f_y_ext : F.scale[0] * totals[0];
+    pack[ZF_PK_DOT] = totals[1];
+    pack[ZF_PK_SS] = totals[2];
+    pack[ZF_PK_GX] = F.scale[3] * totals[3];
+    pack[ZF_PK_FX] = F.f_x_ext ? *F.f_x_ext : F.scale[4] * totals[4];
+    pack[ZF_PK_ERR] = totals[5];
+    pack[6] = 0.0;
+    pack[7] = 0.0;
+}
+
+// world == 1: finalize + decide in one launch
+__global__ __launch_bounds__(ZF_FIN_BLOCK) void zf_finalize_decide_kernel(zf_fin_args F, zf_control* ctl,
+                                                                          double* trace) {
+    __shared__ double lds[(ZF_FIN_BLOCK / 64) * 8];
+    __shared__ double totals[8];
+    if (ctl->status != ZF_RUNNING) return;
+    zf_finalize_partials(F.partials, F.nblocks, ZF_NPART, 5, lds, totals);
+    if (threadIdx.x == 0) {
+        zf_make_pack(F, totals, F.pack);
+        zf_decide_step(ctl, F.pack, trace);
+    }
+}
+
+// world > 1: finalize only (-> local pack), the decide kernel runs after the gather
+__global__ __launch_bounds__(ZF_FIN_BLOCK) void zf_finalize_kernel(zf_fin_args F, const zf_control* ctl) {
+    __shared__ double lds[(ZF_FIN_BLOCK / 64) * 8];
+    __shared__ double totals[8];
+    if (ctl->status != ZF_RUNNING) {
+        if (threadIdx.x < ZF_PACK_LEN) F.pack[threadIdx.x] = 0.0;
+        return;
+    }
+    zf_finalize_partials(F.partials, F.nblocks, ZF_NPART, 5, lds, totals);
+    if (threadIdx.x == 0) zf_make_pack(F, totals, F.pack);
+}
+
+__global__ void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) zf_decide_step(ctl, packs, trace);
+}
+
+// initial F(x0): partials [f raw, |x|_1, violations] -> init pack [f, g, 0...]
+struct zf_init_args {
+    const double* partials;
+    int nblocks;
+    double f_scale, lam;
+    const double* f_ext;
+    double* pack;
+};
+__global__ __launch_bounds__(ZF_FIN_BLOCK) void zf_init_finalize_kernel(zf_init_args I) {
+    __shared__ double lds[(ZF_FIN_BLOCK / 64) * 8];
+    __shared__ double totals[8];
+    zf_finalize_partials(I.partials, I.nblocks, 3, -1, lds, totals);
+    if (threadIdx.x == 0) {
+        const double f = I.f_ext ? *I.f_ext : I.f_scale * totals[0];
+        double g = I.lam * totals[1];
+        if (totals[2] > 0.0) g = INFINITY;   // zfista/problems.py:104-106
+        I.pack[0] = f;
+        I.pack[1] = g;
+        for (int k = 2; k < ZF_PACK_LEN; ++k) I.pack[k] = 0.0;
+        I.pack[2] = totals[2];
+    }
+}
+__global__ void zf_init_commit_kernel(zf_control* ctl, const double* packs, int f_replicated) {
+    if (threadIdx.x || blockIdx.x) return;
+    double f = packs[0], g = packs[1], viol = packs[2];
+    for (int r = 1; r < ctl->world; ++r) {
+        if (!f_replicated) f = f + packs[r * ZF_PACK_LEN + 0];
+        g = g + packs[r * ZF_PACK_LEN + 1];
+        viol = viol + packs[r * ZF_PACK_LEN + 2];
+    }
+    if (viol > 0.0) g = INFINITY;
+    ctl->f_x = f;
+    ctl->g_x = g;
+    ctl->F_old = f + g;   // proximal_gradient.py:279 at the first line search
+}
+
+// ---------------------------------------------------------------------------
+// solver object
+// ---------------------------------------------------------------------------
+struct zf_solver {
+    zf_problem_desc desc;
+    zf_options opt;
+    hipStream_t stream;
+    int grid;                 // trial kernel grid
+    bool box;
+    // device memory owned by the solver
+    double* xbuf = nullptr;   // 3 * n_pad
+    double* xb[3] = {nullptr, nullptr, nullptr};
+    double* partials = nullptr;
+    zf_control* ctl = nullptr;
+    double* trace = nullptr;      // ZF_RING * ZF_TRACE_COLS
+    double* beta_ring = nullptr;  // ZF_RING
+    double* pack_local = nullptr; // ZF_PACK_LEN
+    double* pack_all = nullptr;   // world * ZF_PACK_LEN
+    // least squares
+    double* grad = nullptr;       // n
+    double* sbuf = nullptr;       // 3 * m_pad
+    zf_ring3 sring = {{nullptr, nullptr, nullptr}};
+    double* resid = nullptr;      // m_rows
+    double* slab = nullptr;       // slices * n
+    double* ls_scal = nullptr;    // [0] f(y) [1] f(x+)
+    int slices = 1;
+    int64_t rows_per_slice = 0;
+    bool initialised = false;
+    bool own_packs = true;
+    // trial-kernel timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double ms_total = 0.0;
+    int64_t ms_count = 0;
+};
+
+static int zf_solver_free_all(zf_solver* s) {
+    void* ptrs[] = {s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
+                    s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
+                    s->grad, s->sbuf, s->resid, s->slab, s->ls_scal};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& e : s->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    return ZF_OK;
+}
+
+static bool zf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, const zf_options* opt,
+                                void* stream) {
+    ZF_REQUIRE(out && desc && opt, "zf_solver_create: null argument");
+    ZF_REQUIRE(desc->n >= 1, "zf_solver_create: n must be >= 1");
+    ZF_REQUIRE(desc->world >= 1 && desc->rank >= 0 && desc->rank < desc->world,
+               "zf_solver_create: bad world/rank");
+    ZF_REQUIRE(opt->max_iter >= 1, "zf_solver_create: max_iter must be >= 1");
+    ZF_REQUIRE(opt->max_backtrack_iter >= 0, "zf_solver_create: max_backtrack_iter must be >= 0");
+    if (desc->kind == ZF_PROBLEM_DIAG_QUAD_L1) {
+        ZF_REQUIRE(desc->d && desc->c, "zf_solver_create: d and c are required");
+        ZF_REQUIRE(zf_aligned16(desc->d) && zf_aligned16(desc->c),
+                   "zf_solver_create: d and c must be 16-byte aligned");
+    } else if (desc->kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
+        ZF_REQUIRE(desc->A && desc->b && desc->m_rows >= 1, "zf_solver_create: A, b, m_rows required");
+        ZF_REQUIRE(zf_aligned16(desc->A), "zf_solver_create: A must be 16-byte aligned");
+        ZF_REQUIRE(desc->world == 1, "zf_solver_create: sharded least squares is not built yet");
+    } else {
+        return zf_fail(ZF_ERR_ARG, "zf_solver_create: unknown problem kind");
+    }
+    zf_solver* s = new (std::nothrow) zf_solver();
+    if (!s) return zf_fail(ZF_ERR_ARG, "zf_solver_create: out of host memory");
+    s->desc = *desc;
+    s->opt = *opt;
+    s->stream = reinterpret_cast<hipStream_t>(stream);
+    s->box = !(desc->box_lo == -INFINITY && desc->box_hi == INFINITY);
+    const int64_t n = desc->n;
+    const int64_t n_pad = (n + 63) & ~int64_t(63);   // keep every ring buffer 512-B aligned
+    s->grid = zf_grid_for((n / 2 + 1) / 2 + 1);      // two 16-B units per thread per trip
+#define ZF_TRY(expr)                                                                    \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            zf_solver_free_all(s);                                                      \
+            delete s;                                                                   \
+            return zf_fail(ZF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));         \
+        }                                                                               \
+    } while (0)
+    ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * 3 * n_pad));
+    for (int k = 0; k < 3; ++k) s->xb[k] = s->xbuf + k * n_pad;
+    ZF_TRY(hipMalloc(&s->partials, sizeof(double) * ZF_NPART * ZF_MAX_GRID));
+    ZF_TRY(hipMalloc(&s->ctl, sizeof(zf_control)));
+    ZF_TRY(hipMalloc(&s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS));
+    ZF_TRY(hipMalloc(&s->beta_ring, sizeof(double) * ZF_RING));
+    ZF_TRY(hipMalloc(&s->pack_local, sizeof(double) * ZF_PACK_LEN));
+    ZF_TRY(hipMalloc(&s->pack_all, sizeof(double) * ZF_PACK_LEN * desc->world));
+    ZF_TRY(hipMemsetAsync(s->trace, 0, sizeof(double) * ZF_RING * ZF_TRACE_COLS, s->stream));
+    ZF_TRY(hipMemsetAsync(s->beta_ring, 0, sizeof(double) * ZF_RING, s->stream));
+    ZF_TRY(hipMemsetAsync(s->pack_all, 0, sizeof(double) * ZF_PACK_LEN * desc->world, s->stream));
+    if (desc->kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
+        const int64_t m = desc->m_rows;
+        const int64_t m_pad = (m + 63) & ~int64_t(63);
+        // enough row slices that panels x slices fills the chip (>= ~2048 workgroups)
+        const int V = (n % 2 == 0) ? 2 : 1;
+        const int64_t panels = (n / V + ZF_BLOCK - 1) / ZF_BLOCK;
+        int64_t slices = (ZF_MAX_GRID + panels - 1) / panels;
+        if (slices > (m + 7) / 8) slices = (m + 7) / 8;
+        if (slices < 1) slices = 1;
+        if (slices > 64) slices = 64;
+        s->rows_per_slice = (m + slices - 1) / slices;
+        s->slices = (int)((m + s->rows_per_slice - 1) / s->rows_per_slice);
+        ZF_TRY(hipMalloc(&s->grad, sizeof(double) * n_pad));
+        ZF_TRY(hipMalloc(&s->sbuf, sizeof(double) * 3 * m_pad));
+        for (int k = 0; k < 3; ++k) s->sring.p[k] = s->sbuf + k * m_pad;
+        ZF_TRY(hipMalloc(&s->resid, sizeof(double) * m_pad));
+        ZF_TRY(hipMalloc(&s->slab, sizeof(double) * s->slices * n));
+        ZF_TRY(hipMalloc(&s->ls_scal, sizeof(double) * 8));
+    }
+#undef ZF_TRY
+    *out = s;
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_destroy(zf_solver* s) {
+    if (!s) return ZF_OK;
+    (void)hipStreamSynchronize(s->stream);
+    zf_solver_free_all(s);
+    delete s;
+    return ZF_OK;
+}
+
+// ---- launches ---------------------------------------------------------------
+template <bool GI>
+static void zf_launch_trial_t(zf_solver* s, const zf_step_args& a) {
+    const bool nest = s->opt.nesterov != 0;
+    dim3 g(s->grid), b(ZF_BLOCK);
+    if (nest && s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, true, true>), g, b, 0, s->stream, a);
+    else if (nest) hipLaunchKernelGGL((zf_trial_kernel<GI, true, false>), g, b, 0, s->stream, a);
+    else if (s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, false, true>), g, b, 0, s->stream, a);
+    else hipLaunchKernelGGL((zf_trial_kernel<GI, false, false>), g, b, 0, s->stream, a);
+}
+
+static int zf_launch_trial(zf_solver* s) {
+    const zf_problem_desc& d = s->desc;
+    zf_step_args a;
+    a.ctl = s->ctl;
+    a.beta_ring = s->beta_ring;
+    for (int k = 0; k < 3; ++k) a.xb[k] = s->xb[k];
+    a.lam = d.lam;
+    a.lo = d.box_lo;
+    a.hi = d.box_hi;
+    a.n = d.n;
+    a.partials = s->partials;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s->timing) {
+        if (s->ev_used == s->ev_pool.size()) {
+            hipEvent_t x, y;
+            ZF_HIP(hipEventCreate(&x));
+            ZF_HIP(hipEventCreate(&y));
+            s->ev_pool.emplace_back(x, y);
+        }
+        e0 = s->ev_pool[s->ev_used].first;
+        e1 = s->ev_pool[s->ev_used].second;
+        s->ev_used++;
+    }
+    if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
+        a.p0 = d.d;
+        a.p1 = d.c;
+        if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
+        zf_launch_trial_t<true>(s, a);
+        if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+    } else {
+        const int64_t n = d.n, m = d.m_rows;
+        const int V = (n % 2 == 0) ? 2 : 1;
+        // (1) r = A y - b by linearity, f(y); grad = 2 scale A^T r   [only when y changed]
+        hipLaunchKernelGGL(zf_resid_y_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl,
+                           s->beta_ring, s->sring, d.b, s->resid, d.scale, m, s->ls_scal + 0,
+                           (int)s->opt.nesterov);
+        const int64_t nv = n / V;
+        dim3 gT((unsigned)((nv + ZF_BLOCK - 1) / ZF_BLOCK), (unsigned)s->slices);
+        if (nv > 0) {
+            if (V == 2)
+                hipLaunchKernelGGL(zf_gemvT_partial_kernel<2>, gT, dim3(ZF_BLOCK), 0, s->stream, s->ctl,
+                                   d.A, s->resid, s->slab, m, n, s->rows_per_slice);
+            else
+                hipLaunchKernelGGL(zf_gemvT_partial_kernel<1>, gT, dim3(ZF_BLOCK), 0, s->stream, s->ctl,
+                                   d.A, s->resid, s->slab, m, n, s->rows_per_slice);
+        }
+        hipLaunchKernelGGL(zf_gemvT_combine_kernel, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, s->stream,
+                           s->ctl, s->slab, s->grad, 2 * d.scale, n, s->slices);
+        // (2) fused prox step with the gradient vector in HBM
+        a.p0 = s->grad;
+        a.p1 = nullptr;
+        if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
+        zf_launch_trial_t<false>(s, a);
+        if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+        // (3) s+ = A x+ ; f(x+)
+        zf_ring3 xr = {{s->xb[0], s->xb[1], s->xb[2]}};
+        int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
+        if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
+        if (V == 2)
+            hipLaunchKernelGGL(zf_gemv_rows_kernel<2>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, s->ctl, d.A,
+                               xr, s->sring, 1, m, n);
+        else
+            hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, s->ctl, d.A,
+                               xr, s->sring, 1, m, n);
+        hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1,
+                           d.b, d.scale, m, s->ls_scal + 1);
+    }
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+static zf_fin_args zf_make_fin(zf_solver* s) {
+    zf_fin_args F;
+    F.partials = s->partials;
+    F.nblocks = s->grid;
+    for (int k = 0; k < ZF_NPART; ++k) F.scale[k] = 1.0;
+    F.scale[3] = s->desc.lam;   // g = lam * sum|x|
+    F.f_y_ext = nullptr;
+    F.f_x_ext = nullptr;
+    if (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
+        F.scale[0] = 0.5;       // f = 0.5 * sum(d (x-c)^2)
+        F.scale[4] = 0.5;
+    } else {
+        F.f_y_ext = s->ls_scal + 0;
+        F.f_x_ext = s->ls_scal + 1;
+    }
+    F.pack = s->pack_local;
+    return F;
+}
+
+extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
+    ZF_REQUIRE(s && x0_dev, "zf_solver_enqueue_init: null argument");
+    const zf_problem_desc& d = s->desc;
+    const int64_t n = d.n;
+    // x_k = x_{k-1} = y = x0  (proximal_gradient.py:463-465)
+    ZF_HIP(hipMemcpyAsync(s->xb[0], x0_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream));
+    ZF_HIP(hipMemcpyAsync(s->xb[2], x0_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream));
+    zf_control c;
+    memset(&c, 0, sizeof(c));
+    c.lr = s->opt.lr;
+    c.tol = s->opt.tol;
+    c.tol_internal = s->opt.tol_internal;
+    c.decay_rate = s->opt.decay_rate;
+    c.max_iter = s->opt.max_iter;
+    c.max_backtrack = s->opt.max_backtrack_iter;
+    c.status = (s->opt.max_backtrack_iter == 0) ? ZF_BACKTRACK_FAILED : ZF_RUNNING;  // :280,:306
+    c.cur = 0;
+    c.nesterov = s->opt.nesterov;
+    c.deprecated = s->opt.deprecated;
+    c.need_grad = 1;
+    c.world = d.world;
+    ZF_HIP(hipMemcpyAsync(s->ctl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));   // `c` is a stack object
+    zf_init_args I;
+    I.partials = s->partials;
+    I.lam = d.lam;
+    I.pack = s->pack_local;
+    I.f_ext = nullptr;
+    const int g = zf_grid_for(n);
+    I.nblocks = g;
+    if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
+        I.f_scale = 0.5;
+        if (s->box)
+            hipLaunchKernelGGL((zf_eval_kernel<true, true>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0],
+                               d.d, d.c, d.box_lo, d.box_hi, n, s->partials);
+        else
+            hipLaunchKernelGGL((zf_eval_kernel<true, false>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0],
+                               d.d, d.c, d.box_lo, d.box_hi, n, s->partials);
+    } else {
+        I.f_scale = 0.0;
+        I.f_ext = s->ls_scal + 1;
+        const int64_t m = d.m_rows;
+        const int V = (n % 2 == 0) ? 2 : 1;
+        zf_ring3 xr = {{s->xb[0], s->xb[0], s->xb[0]}};
+        zf_ring3 s0 = {{s->sring.p[0], s->sring.p[0], s->sring.p[0]}};
+        int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
+        if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
+        if (V == 2)
+            hipLaunchKernelGGL(zf_gemv_rows_kernel<2>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
+                               s0, -1, m, n);
+        else
+            hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
+                               s0, -1, m, n);
+        // A x_{-1} = A x0 as well
+        const int64_t m_pad = (m + 63) & ~int64_t(63);
+        (void)m_pad;
+        ZF_HIP(hipMemcpyAsync(s->sring.p[2], s->sring.p[0], sizeof(double) * m, hipMemcpyDeviceToDevice,
+                              s->stream));
+        hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, nullptr, s0, -1, d.b,
+                           d.scale, m, s->ls_scal + 1);
+        if (s->box)
+            hipLaunchKernelGGL((zf_eval_kernel<false, true>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0],
+                               nullptr, nullptr, d.box_lo, d.box_hi, n, s->partials);
+        else
+            hipLaunchKernelGGL((zf_eval_kernel<false, false>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0],
+                               nullptr, nullptr, d.box_lo, d.box_hi, n, s->partials);
+    }
+    hipLaunchKernelGGL(zf_init_finalize_kernel, dim3(1), dim3(ZF_FIN_BLOCK), 0, s->stream, I);
+    ZF_HIP(hipGetLastError());
+    if (d.world == 1)
+        ZF_HIP(hipMemcpyAsync(s->pack_all, s->pack_local, sizeof(double) * ZF_PACK_LEN,
+                              hipMemcpyDeviceToDevice, s->stream));
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_enqueue_init_commit(zf_solver* s) {
+    ZF_REQUIRE(s, "zf_solver_enqueue_init_commit: null solver");
+    const int f_repl = (s->desc.kind == ZF_PROBLEM_LEAST_SQUARES_L1) ? 1 : 0;
+    hipLaunchKernelGGL(zf_init_commit_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, f_repl);
+    ZF_HIP(hipGetLastError());
+    s->initialised = true;
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_set_beta(zf_solver* s, int64_t first, const double* beta_host, int64_t count) {
+    ZF_REQUIRE(s && beta_host, "zf_solver_set_beta: null argument");
+    ZF_REQUIRE(first >= 0 && count >= 0 && count <= ZF_RING, "zf_solver_set_beta: bad range");
+    // ring index = accepted-iteration count % ZF_RING; at most two contiguous pieces
+    int64_t done = 0;
+    while (done < count) {
+        const int64_t pos = (first + done) % ZF_RING;
+        int64_t len = count - done;
+        if (len > ZF_RING - pos) len = ZF_RING - pos;
+        ZF_HIP(hipMemcpyAsync(s->beta_ring + pos, beta_host + done, sizeof(double) * len,
+                              hipMemcpyHostToDevice, s->stream));
+        done += len;
+    }
+    ZF_HIP(hipStreamSynchronize(s->stream));   // beta_host may be reused by the caller
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_enqueue_trial(zf_solver* s) {
+    ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_trial: solver not initialised");
+    int rc = zf_launch_trial(s);
+    if (rc) return rc;
+    zf_fin_args F = zf_make_fin(s);
+    hipLaunchKernelGGL(zf_finalize_kernel, dim3(1), dim3(ZF_FIN_BLOCK), 0, s->stream, F, s->ctl);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_enqueue_decide(zf_solver* s) {
+    ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_decide: solver not initialised");
+    hipLaunchKernelGGL(zf_decide_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, s->trace);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
+    ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_steps: solver not initialised");
+    ZF_REQUIRE(s->desc.world == 1, "zf_solver_enqueue_steps: world > 1 needs trial/gather/decide");
+    ZF_REQUIRE(steps >= 0 && steps <= ZF_RING, "zf_solver_enqueue_steps: steps must be in [0, ZF_RING]");
+    zf_fin_args F = zf_make_fin(s);
+    for (int64_t k = 0; k < steps; ++k) {
+        int rc = zf_launch_trial(s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(zf_finalize_decide_kernel, dim3(1), dim3(ZF_FIN_BLOCK), 0, s->stream, F, s->ctl,
+                           s->trace);
+    }
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_pack_ptrs(zf_solver* s, double** pack_local_dev, double** pack_all_dev) {
+    ZF_REQUIRE(s && pack_local_dev && pack_all_dev, "zf_solver_pack_ptrs: null argument");
+    *pack_local_dev = s->pack_local;
+    *pack_all_dev = s->pack_all;
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_set_pack_buffers(zf_solver* s, double* pack_local_dev, double* pack_all_dev) {
+    ZF_REQUIRE(s && pack_local_dev && pack_all_dev, "zf_solver_set_pack_buffers: null argument");
+    ZF_REQUIRE(!s->initialised, "zf_solver_set_pack_buffers: call before zf_solver_enqueue_init");
+    if (s->pack_local && s->own_packs) (void)hipFree(s->pack_local);
+    if (s->pack_all && s->own_packs) (void)hipFree(s->pack_all);
+    s->own_packs = false;
+    s->pack_local = pack_local_dev;
+    s->pack_all = pack_all_dev;
+    return ZF_OK;
+}
+
+static int zf_collect_timing(zf_solver* s) {
+    for (size_t k = 0; k < s->ev_used; ++k) {
+        float ms = 0.f;
+        ZF_HIP(hipEventElapsedTime(&ms, s->ev_pool[k].first, s->ev_pool[k].second));
+        s->ms_total += ms;
+        s->ms_count += 1;
+    }
+    s->ev_used = 0;
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, double* trace_host) {
+    ZF_REQUIRE(s && ctl_host, "zf_solver_poll: null argument");
+    ZF_HIP(hipMemcpyAsync(ctl_host, s->ctl, sizeof(zf_control), hipMemcpyDeviceToHost, s->stream));
+    if (trace_host)
+        ZF_HIP(hipMemcpyAsync(trace_host, s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS,
+                              hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return zf_collect_timing(s);
+}
+
+extern "C" int zf_solver_x_dev(zf_solver* s, const double** x_dev) {
+    ZF_REQUIRE(s && x_dev, "zf_solver_x_dev: null argument");
+    zf_control c;
+    ZF_HIP(hipMemcpyAsync(&c, s->ctl, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    *x_dev = s->xb[c.cur];
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_get_x(zf_solver* s, double* x_host) {
+    ZF_REQUIRE(s && x_host, "zf_solver_get_x: null argument");
+    const double* xd = nullptr;
+    int rc = zf_solver_x_dev(s, &xd);
+    if (rc) return rc;
+    ZF_HIP(hipMemcpyAsync(x_host, xd, sizeof(double) * s->desc.n, hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_set_timing(zf_solver* s, int32_t enabled) {
+    ZF_REQUIRE(s, "zf_solver_set_timing: null solver");
+    s->timing = enabled != 0;
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches) {
+    ZF_REQUIRE(s && avg_ms && launches, "zf_solver_trial_kernel_ms: null argument");
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    int rc = zf_collect_timing(s);
+    if (rc) return rc;
+    *launches = s->ms_count;
+    *avg_ms = s->ms_count ? s->ms_total / (double)s->ms_count : 0.0;
+    s->ms_total = 0.0;
+    s->ms_count = 0;
+    return ZF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// library / device / memory
+// ---------------------------------------------------------------------------
+extern "C" int zf_abi_version(void) { return ZF_ABI_VERSION; }
+extern "C" const char* zf_last_error(void) { return zf_errbuf; }
+extern "C" int64_t zf_sizeof_control(void) { return (int64_t)sizeof(zf_control); }
+
+extern "C" int zf_device_count(int* count) {
+    ZF_REQUIRE(count, "zf_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return zf_fail(ZF_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return ZF_OK;
+}
+extern "C" int zf_set_device(int device) {
+    ZF_HIP(hipSetDevice(device));
+    return ZF_OK;
+}
+extern "C" int zf_malloc(void** dev_ptr, int64_t bytes) {
+    ZF_REQUIRE(dev_ptr && bytes >= 0, "zf_malloc: bad argument");
+    ZF_HIP(hipMalloc(dev_ptr, (size_t)(bytes > 0 ? bytes : 16)));
+    return ZF_OK;
+}
+extern "C" int zf_free(void* dev_ptr) {
+    if (dev_ptr) ZF_HIP(hipFree(dev_ptr));
+    return ZF_OK;
+}
+extern "C" int zf_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream) {
+    ZF_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    ZF_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return ZF_OK;
+}
+extern "C" int zf_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream) {
+    ZF_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ZF_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return ZF_OK;
+}
+extern "C" int zf_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream) {
+    ZF_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ZF_OK;
+}
+extern "C" int zf_stream_synchronize(void* stream) {
+    ZF_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return ZF_OK;
+}
+
+extern "C" int zf_decide_host(zf_control* ctl, const double* packs, double* trace) {
+    ZF_REQUIRE(ctl && packs && trace, "zf_decide_host: null argument");
+    zf_decide_step(ctl, packs, trace);
+    return ZF_OK;
+}
+
+// ---------------------------------------------------------------------------
+// least-squares operator at a host point (callback contract, not the hot loop)
+// ---------------------------------------------------------------------------
+extern "C" int zf_ls_eval(const double* A_dev, const double* b_dev, int64_t m_rows, int64_t n, double scale,
+                          const double* x_host, double* f_out, double* grad_out_host) {
+    ZF_REQUIRE(A_dev && b_dev && x_host && f_out && m_rows >= 1 && n >= 1, "zf_ls_eval: bad argument");
+    ZF_REQUIRE(zf_aligned16(A_dev), "zf_ls_eval: A must be 16-byte aligned");
+    const int V = (n % 2 == 0) ? 2 : 1;
+    const int64_t nv = n / V;
+    const int64_t panels = (nv + ZF_BLOCK - 1) / ZF_BLOCK;
+    int64_t slices = (ZF_MAX_GRID + panels - 1) / panels;
+    if (slices > (m_rows + 7) / 8) slices = (m_rows + 7) / 8;
+    if (slices < 1) slices = 1;
+    if (slices > 64) slices = 64;
+    const int64_t rps = (m_rows + slices - 1) / slices;
+    slices = (m_rows + rps - 1) / rps;
+    double *x = nullptr, *s = nullptr, *slab = nullptr, *grad = nullptr, *fdev = nullptr;
+    int rc = ZF_OK;
+#define ZF_LS(expr)                                                               \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess && rc == ZF_OK)                                      \
+            rc = zf_fail(ZF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));     \
+    } while (0)
+    ZF_LS(hipMalloc(&x, sizeof(double) * (n + 2)));
+    ZF_LS(hipMalloc(&s, sizeof(double) * (m_rows + 2)));
+    ZF_LS(hipMalloc(&fdev, sizeof(double) * 2));
+    if (grad_out_host) {
+        ZF_LS(hipMalloc(&slab, sizeof(double) * slices * n));
+        ZF_LS(hipMalloc(&grad, sizeof(double) * n));
+    }
+    if (rc == ZF_OK) {
+        ZF_LS(hipMemcpyAsync(x, x_host, sizeof(double) * n, hipMemcpyHostToDevice, nullptr));
+        zf_ring3 xr = {{x, x, x}}, sr = {{s, s, s}};
+        int gr = (int)((m_rows + GEMV_ROWS - 1) / GEMV_ROWS);
+        if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
+        if (V == 2)
+            hipLaunchKernelGGL(zf_gemv_rows_kernel<2>, dim3(gr), dim3(ZF_BLOCK), 0, nullptr, nullptr, A_dev, xr, sr,
+                               -1, m_rows, n);
+        else
+            hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, nullptr, nullptr, A_dev, xr, sr,
+                               -1, m_rows, n);
+        hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, nullptr, nullptr, sr, -1, b_dev, scale,
+                           m_rows, fdev);
+        if (grad_out_host) {
+            // r = s - b in place, then column sums
+            hipLaunchKernelGGL(zf_axmb_kernel, dim3(zf_grid_for(m_rows)), dim3(ZF_BLOCK), 0, nullptr, s, b_dev,
+                               m_rows);
+            dim3 gT((unsigned)panels, (unsigned)slices);
+            if (V == 2)
+                hipLaunchKernelGGL(zf_gemvT_partial_kernel<2>, gT, dim3(ZF_BLOCK), 0, nullptr, nullptr, A_dev, s,
+                                   slab, m_rows, n, rps);
+            else
+                hipLaunchKernelGGL(zf_gemvT_partial_kernel<1>, gT, dim3(ZF_BLOCK), 0, nullptr, nullptr, A_dev, s,
+                                   slab, m_rows, n, rps);
+            hipLaunchKernelGGL(zf_gemvT_combine_kernel, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, nullptr, nullptr,
+                               slab, grad, 2 * scale, n, (int)slices);
+            ZF_LS(hipMemcpyAsync(grad_out_host, grad, sizeof(double) * n, hipMemcpyDeviceToHost, nullptr));
+        }
+        ZF_LS(hipGetLastError());
+        ZF_LS(hipMemcpyAsync(f_out, fdev, sizeof(double), hipMemcpyDeviceToHost, nullptr));
+        ZF_LS(hipStreamSynchronize(nullptr));
+    }
+#undef ZF_LS
+    for (void* p : {(void*)x, (void*)s, (void*)slab, (void*)grad, (void*)fdev})
+        if (p) (void)hipFree(p);
+    return rc;
+}

@@ -1,0 +1,148 @@
+"""Host driver of the device-resident solver (``zf_solver`` in libzfista_hip.so).
+
+PyTorch is plumbing here: it owns device allocations handed in by the caller,
+names the HIP stream the kernels are enqueued on, and (for a sharded decision
+vector) carries the per-trial scalar packs between ranks with
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box).  All
+solver arithmetic happens in the library's HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def momentum_factors(count: int, ratio, state=None):
+    """The next ``count`` momentum factors of zfista/proximal_gradient.py:531-535.
+
+    ``t_next = sqrt(t^2 - a t + b) + 1/2``, ``beta = (t - 1) / t_next`` evaluated
+    with the same NumPy scalar expressions as the reference, so the factors the
+    trial kernel multiplies with are bit-identical to the reference's.
+    Returns (betas, state) where state carries ``t`` between calls.
+    """
+    a, b = ratio
+    t_prev = 1 if state is None else state
+    out = np.empty(count, dtype=np.float64)
+    for j in range(count):
+        t_next = np.sqrt(t_prev**2 - a * t_prev + b) + 0.5
+        out[j] = (t_prev - 1) / t_next
+        t_prev = t_next
+    return out, t_prev
+
+
+class DeviceSolver:
+    """One ``zf_solver``: a problem descriptor bound to device buffers + options.
+
+    Parameters
+    ----------
+    desc_fields : dict of ``zf_problem_desc`` fields (device pointers as ints)
+    keepalive   : objects (torch tensors) that own the memory behind those pointers
+    group       : ``torch.distributed`` process group when x is sharded, else None
+    """
+
+    def __init__(self, desc_fields, options, keepalive=(), group=None, stream=None, timing=False):
+        self.lib = _lib.require_gpu()
+        self._keep = list(keepalive)
+        self.group = group
+        self.world = int(desc_fields.get("world", 1))
+        self.rank = int(desc_fields.get("rank", 0))
+        self.n = int(desc_fields["n"])
+        if stream is None:
+            import torch
+
+            stream = torch.cuda.current_stream().cuda_stream
+        self.stream = stream
+        d = _lib.ProblemDesc()
+        for k, v in desc_fields.items():
+            setattr(d, k, v)
+        o = _lib.Options()
+        for k, v in options.items():
+            setattr(o, k, v)
+        self.nesterov = bool(options.get("nesterov", 0))
+        h = C.c_void_p()
+        _lib.check(self.lib.zf_solver_create(C.byref(h), C.byref(d), C.byref(o), C.c_void_p(stream)),
+                   "zf_solver_create")
+        self.handle = h
+        self.ctl = _lib.Control()
+        self.trace = np.zeros((_lib.ZF_RING, _lib.ZF_TRACE_COLS), dtype=np.float64)
+        self._pack_local = self._pack_all = None
+        if timing:
+            _lib.check(self.lib.zf_solver_set_timing(self.handle, 1))
+        if self.world > 1:
+            self._wrap_packs()
+
+    # -- sharded x: the per-trial exchange -------------------------------------
+    def _wrap_packs(self):
+        """torch-owned pack buffers the collective runs on; the library writes /
+        reads them in place (zf_solver_set_pack_buffers)."""
+        import torch
+
+        self._pack_local = torch.zeros(_lib.ZF_PACK_LEN, dtype=torch.float64, device="cuda")
+        self._pack_all = torch.zeros(_lib.ZF_PACK_LEN * self.world, dtype=torch.float64, device="cuda")
+        _lib.check(self.lib.zf_solver_set_pack_buffers(
+            self.handle, C.c_void_p(self._pack_local.data_ptr()), C.c_void_p(self._pack_all.data_ptr())))
+
+    def _gather(self):
+        # C1: one packed all-gather of <= 64 B per rank; every rank then
+        # adds the packs in rank order inside the decide kernel, so all ranks take
+        # bitwise-identical branch decisions.
+        import torch.distributed as dist
+
+        dist.all_gather_into_tensor(self._pack_all, self._pack_local, group=self.group)
+
+    # -- life cycle ---------------------------------------------------------------
+    def init(self, x0_dev_ptr: int):
+        _lib.check(self.lib.zf_solver_enqueue_init(self.handle, C.c_void_p(x0_dev_ptr)), "init")
+        if self.world > 1:
+            self._gather()
+        _lib.check(self.lib.zf_solver_enqueue_init_commit(self.handle), "init_commit")
+
+    def set_beta(self, first: int, betas: np.ndarray):
+        betas = np.ascontiguousarray(betas, dtype=np.float64)
+        _lib.check(self.lib.zf_solver_set_beta(self.handle, first, C.c_void_p(_lib.ptr(betas)), betas.size),
+                   "set_beta")
+
+    def enqueue(self, steps: int):
+        """Enqueue ``steps`` line-search trials; no host synchronisation."""
+        if self.world == 1:
+            _lib.check(self.lib.zf_solver_enqueue_steps(self.handle, steps), "enqueue_steps")
+            return
+        for _ in range(steps):
+            _lib.check(self.lib.zf_solver_enqueue_trial(self.handle), "enqueue_trial")
+            self._gather()
+            _lib.check(self.lib.zf_solver_enqueue_decide(self.handle), "enqueue_decide")
+
+    def poll(self):
+        """Synchronise and fetch the control block + trace ring."""
+        _lib.check(self.lib.zf_solver_poll(self.handle, C.byref(self.ctl), C.c_void_p(_lib.ptr(self.trace))),
+                   "poll")
+        return self.ctl, self.trace
+
+    def get_x(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        _lib.check(self.lib.zf_solver_get_x(self.handle, C.c_void_p(_lib.ptr(out))), "get_x")
+        return out
+
+    def x_dev_ptr(self) -> int:
+        p = C.c_void_p()
+        _lib.check(self.lib.zf_solver_x_dev(self.handle, C.byref(p)))
+        return p.value
+
+    def trial_kernel_ms(self):
+        ms, cnt = C.c_double(0.0), C.c_int64(0)
+        _lib.check(self.lib.zf_solver_trial_kernel_ms(self.handle, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.zf_solver_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,200 @@
+"""Native operator objects: callback providers the engine recognises.
+
+The reference's solver takes four opaque callables (``f, g, jac_f,
+prox_wsum_g``; zfista/proximal_gradient.py:311-316) and its problem library
+supplies them as bound methods (zfista/problems.py:140-150).  The objects here
+keep that contract - ``prob.f(x)`` etc. are ordinary callables on NumPy arrays,
+evaluated on the GPU - and additionally carry a descriptor.  When
+``zfista_amd.minimize_proximal_gradient`` is handed the four bound methods of
+ONE such object it runs the device-resident fused path instead of calling them.
+
+Problem data lives in HBM (torch CUDA tensors are accepted as-is; NumPy arrays
+are uploaded once).  There is no host implementation of any of these methods.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _to_device(a, name):
+    """float64 contiguous CUDA tensor from a NumPy array or a torch tensor."""
+    import torch
+
+    _lib.require_gpu()
+    if isinstance(a, torch.Tensor):
+        t = a
+        if not t.is_cuda:
+            t = t.cuda()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).cuda()
+    if t.dtype != torch.float64:
+        raise TypeError(f"{name} must be float64 (the reference path is float64 throughout)")
+    return t.contiguous()
+
+
+def _as_host(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+class NativeProblem:
+    """Marker base: a single-objective problem with a device descriptor."""
+
+    n_features: int
+
+    def callbacks(self):
+        return self.f, self.g, self.jac_f, self.prox_wsum_g
+
+    def minimize_proximal_gradient(self, x0, **kwargs):
+        """Bound-method form, as zfista/problems.py:140-150."""
+        from .proximal_gradient import minimize_proximal_gradient
+
+        return minimize_proximal_gradient(self.f, self.g, self.jac_f, self.prox_wsum_g, x0, **kwargs)
+
+    # -- shared g / prox: lam * |x|_1 (+ box) ------------------------------------------
+    def g(self, x):
+        x = _as_host(x)
+        if self._has_box() and ((x < self.box[0]).any() or (x > self.box[1]).any()):
+            return np.float64(np.inf)   # zfista/problems.py:104-106
+        return self._eval_fg(x)[1]
+
+    def prox_wsum_g(self, weight, x):
+        x = _as_host(x)
+        out = np.empty_like(x)
+        lib = _lib.require_gpu()
+        _lib.check(lib.zf_host_prox_l1_box(C.c_void_p(_lib.ptr(out)), C.c_void_p(_lib.ptr(x)),
+                                           float(self.lam * weight), self.box[0], self.box[1], x.size),
+                   "zf_host_prox_l1_box")
+        return out
+
+    def _has_box(self):
+        return not (self.box[0] == -np.inf and self.box[1] == np.inf)
+
+
+class DiagQuadL1(NativeProblem):
+    r"""f(x) = 1/2 \sum_i d_i (x_i - c_i)^2,  g(x) = lam \|x\|_1 (+ optional box).
+
+    The single-objective analogue of the diagonal-gradient problems of
+    zfista/problems.py:193-205 (BASELINE cfg2 / the headline metric).  With
+    ``group`` set, ``d`` and ``c`` are this rank's contiguous shard of a
+    decision vector partitioned across the ranks of that process group.
+    """
+
+    kind = _lib.ZF_PROBLEM_DIAG_QUAD_L1
+
+    def __init__(self, d, c, lam, bounds=None, group=None):
+        self.d = _to_device(d, "d")
+        self.c = _to_device(c, "c")
+        if self.d.ndim != 1 or self.d.shape != self.c.shape:
+            raise ValueError("d and c must be 1-D of equal length")
+        self.lam = float(lam)
+        self.box = (-np.inf, np.inf) if bounds is None else (float(bounds[0]), float(bounds[1]))
+        self.n_features = int(self.d.numel())
+        self.group = group
+
+    def _eval_fg(self, x):
+        import torch
+
+        if x.size != self.n_features:
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        lib = _lib.require_gpu()
+        xd = torch.from_numpy(x).cuda()
+        out = np.zeros(2)
+        _lib.check(lib.zf_eval_diag_l1(C.c_void_p(xd.data_ptr()), C.c_void_p(self.d.data_ptr()),
+                                       C.c_void_p(self.c.data_ptr()), self.lam, x.size,
+                                       C.c_void_p(_lib.ptr(out)),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "zf_eval_diag_l1")
+        return np.float64(out[0]), np.float64(out[1])
+
+    def f(self, x):
+        return self._eval_fg(_as_host(x))[0]
+
+    def jac_f(self, x):
+        x = _as_host(x)
+        if x.size != self.n_features:
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        out = np.empty_like(x)
+        lib = _lib.require_gpu()
+        _lib.check(lib.zf_host_diag_grad(C.c_void_p(_lib.ptr(out)), C.c_void_p(_lib.ptr(x)),
+                                         C.c_void_p(self.d.data_ptr()), C.c_void_p(self.c.data_ptr()),
+                                         x.size), "zf_host_diag_grad")
+        return out
+
+    def _descriptor(self):
+        import torch.distributed as dist
+
+        world = dist.get_world_size(self.group) if self.group is not None else 1
+        rank = dist.get_rank(self.group) if self.group is not None else 0
+        fields = dict(kind=self.kind, world=world, rank=rank, n=self.n_features, m_rows=0,
+                      d=self.d.data_ptr(), c=self.c.data_ptr(), A=None, b=None,
+                      scale=0.5, lam=self.lam, box_lo=self.box[0], box_hi=self.box[1])
+        return fields, (self.d, self.c)
+
+
+class LeastSquaresL1(NativeProblem):
+    r"""f(x) = scale \|Ax - b\|^2,  g(x) = lam \|x\|_1 (+ optional box); A dense row-major.
+
+    The LASSO closures of tests/test_proximal_gradient.py:49-61,81-97 are the
+    ``scale = 1/6`` member; BASELINE cfg1 / cfg3 use ``scale = 1/2``.
+    """
+
+    kind = _lib.ZF_PROBLEM_LEAST_SQUARES_L1
+
+    def __init__(self, A, b, lam, scale=0.5, bounds=None):
+        self.A = _to_device(A, "A")
+        self.b = _to_device(b, "b")
+        if self.A.ndim != 2 or self.b.ndim != 1 or self.A.shape[0] != self.b.shape[0]:
+            raise ValueError("A must be (m, n) and b (m,)")
+        self.lam, self.scale = float(lam), float(scale)
+        self.box = (-np.inf, np.inf) if bounds is None else (float(bounds[0]), float(bounds[1]))
+        self.m_rows, self.n_features = int(self.A.shape[0]), int(self.A.shape[1])
+        self.group = None
+
+    def _ls(self, x, want_grad):
+        x = _as_host(x)
+        if x.size != self.n_features:
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        lib = _lib.require_gpu()
+        fval = C.c_double(0.0)
+        grad = np.empty_like(x) if want_grad else None
+        _lib.check(lib.zf_ls_eval(C.c_void_p(self.A.data_ptr()), C.c_void_p(self.b.data_ptr()),
+                                  self.m_rows, self.n_features, self.scale, C.c_void_p(_lib.ptr(x)),
+                                  C.byref(fval), C.c_void_p(_lib.ptr(grad)) if want_grad else None),
+                   "zf_ls_eval")
+        return np.float64(fval.value), grad
+
+    def f(self, x):
+        return self._ls(x, False)[0]
+
+    def jac_f(self, x):
+        return self._ls(x, True)[1]
+
+    def _eval_fg(self, x):
+        lib = _lib.require_gpu()
+        s = C.c_double(0.0)
+        _lib.check(lib.zf_host_asum(C.c_void_p(_lib.ptr(x)), x.size, C.byref(s)), "zf_host_asum")
+        return None, np.float64(self.lam * s.value)
+
+    def _descriptor(self):
+        fields = dict(kind=self.kind, world=1, rank=0, n=self.n_features, m_rows=self.m_rows,
+                      d=None, c=None, A=self.A.data_ptr(), b=self.b.data_ptr(),
+                      scale=self.scale, lam=self.lam, box_lo=self.box[0], box_hi=self.box[1])
+        return fields, (self.A, self.b)
+
+
+def match_native(f, g, jac_f, prox_wsum_g):
+    """The NativeProblem whose four bound methods these are, else None."""
+    owner = getattr(f, "__self__", None)
+    if not isinstance(owner, NativeProblem):
+        return None
+    want = ("f", "g", "jac_f", "prox_wsum_g")
+    for cb, name in zip((f, g, jac_f, prox_wsum_g), want):
+        if getattr(cb, "__self__", None) is not owner:
+            return None
+        if getattr(cb, "__func__", None) is not getattr(type(owner), name):
+            return None
+    return owner

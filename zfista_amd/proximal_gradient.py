@@ -1,0 +1,336 @@
+"""``minimize_proximal_gradient`` - drop-in for zfista's solver entry point.
+
+Same signature, keyword defaults, result fields, warnings and error behaviour
+as ``zfista.minimize_proximal_gradient`` (zfista/proximal_gradient.py:311-555).
+Two execution paths, both on the GPU (there is no host fallback):
+
+* native   - the four callbacks are the bound methods of one
+             ``zfista_amd.problems.NativeProblem``: the iteration runs
+             device-resident (fused trial kernel + decide kernel, see
+             ``csrc/zf_solver.hip``); the host polls once per chunk of trials.
+* generic  - arbitrary Python callables: the callbacks run where the user wrote
+             them (host), the solver's own vector arithmetic (:148, :150-152,
+             :510, :534, and the dual terms :162-173) runs in HIP kernels through
+             ``zf_host_*``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from warnings import warn
+
+import numpy as np
+from scipy.optimize import OptimizeResult
+
+from . import _lib
+from .engine import DeviceSolver, momentum_factors
+from .problems import match_native
+
+_MSG_OK = "Optimization terminated successfully"   # proximal_gradient.py:527
+_MSG_MAXITER = "Maximum number of iterations reached"   # :541
+_MSG_BACKTRACK = "Backtracking failed to find a suitable stepsize."   # :307
+_MSG_DEPRECATED = (
+    "Using the deprecated option is not mathematically proven to converge. "
+    "Please consider using the recommended condition instead."
+)   # :446-447
+_HEADER = ["niter", "nit internal", "max(abs(xk - yk)))", "subprob func", "learning rate"]   # :24-30
+_WIDTHS = [7, 7, 13, 13, 10]
+
+
+def _print_header():
+    fmt = "|" + "|".join(f"{{:^{w}}}" for w in _WIDTHS) + "|"
+    print(fmt.format(*_HEADER))
+    print(fmt.format(*["-" * w for w in _WIDTHS]))
+
+
+def _print_row(nit, nit_internal, err, fun, lr):
+    # The reference formats five columns from four values and raises IndexError
+    # (:511-520); this prints the row the header promises (documented deviation).
+    print(f"|{nit:^7}|{nit_internal:^7}|{err:^+13.4e}|{fun:^+13.4e}|{lr:^10.2e}|")
+
+
+def minimize_proximal_gradient(
+    f, g, jac_f, prox_wsum_g, x0,
+    lr=1, tol=1e-5, tol_internal=1e-12, max_iter=1000000, max_iter_internal=100000,
+    max_backtrack_iter=100, warm_start=False, decay_rate=0.5, nesterov=False,
+    nesterov_ratio=(0, 0.25), return_all=False, verbose=False, deprecated=False,
+):
+    """Minimise F = f + g by the (accelerated) proximal gradient method on MI355X.
+
+    Parameters, returned ``OptimizeResult`` fields and messages are those of
+    zfista/proximal_gradient.py:332-443.  ``x0`` may be a NumPy array (or, on the
+    native path, a float64 CUDA tensor holding this rank's shard).
+    """
+    if deprecated:
+        warn(_MSG_DEPRECATED, stacklevel=2)
+    opts = dict(
+        lr=lr, tol=tol, tol_internal=tol_internal, max_iter=max_iter,
+        max_iter_internal=max_iter_internal, max_backtrack_iter=max_backtrack_iter,
+        warm_start=warm_start, decay_rate=decay_rate, nesterov=nesterov,
+        nesterov_ratio=nesterov_ratio, return_all=return_all, verbose=verbose,
+        deprecated=deprecated,
+    )
+    native = match_native(f, g, jac_f, prox_wsum_g)
+    if native is not None:
+        res, status = _solve_native(native, x0, opts)
+    else:
+        res, status = _solve_generic(f, g, jac_f, prox_wsum_g, x0, opts)
+    if status == _lib.ZF_MAXITER:
+        warn(res.message, stacklevel=2)   # :543
+    return res
+
+
+# ---------------------------------------------------------------------------
+# native path: device-resident iteration
+# ---------------------------------------------------------------------------
+class NativeRun:
+    """A device-resident solve that can be advanced in chunks (used by bench.py
+    to time exactly K iterations with the inputs already resident in HBM)."""
+
+    def __init__(self, problem, x0, opts, timing=False):
+        import torch
+
+        self.problem = problem
+        self.opts = opts
+        fields, keep = problem._descriptor()
+        options = dict(
+            lr=float(opts["lr"]), tol=float(opts["tol"]), tol_internal=float(opts["tol_internal"]),
+            decay_rate=float(opts["decay_rate"]), max_iter=int(opts["max_iter"]),
+            max_backtrack_iter=int(opts["max_backtrack_iter"]),
+            nesterov=int(bool(opts["nesterov"])), deprecated=int(bool(opts["deprecated"])),
+        )
+        if isinstance(x0, torch.Tensor):
+            x0_dev = x0.to(device="cuda", dtype=torch.float64).contiguous()
+        else:
+            x0_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(x0, dtype=np.float64))).cuda()
+        if x0_dev.numel() != problem.n_features:
+            raise ValueError(f"len(x) should be equal to n_features, got {x0}.")
+        self.solver = DeviceSolver(fields, options, keepalive=keep, group=problem.group, timing=timing)
+        self.solver.init(x0_dev.data_ptr())
+        self._x0_dev = x0_dev
+        self.ratio = opts["nesterov_ratio"]
+        self._t_state = None
+        self._beta_filled = 0     # momentum factors uploaded for accepted counts < this
+        self.nit_seen = 0
+        self.status = _lib.ZF_RUNNING
+        ctl, _ = self.solver.poll()
+        self.F0 = ctl.F_old
+        self.status = ctl.status
+
+    def _fill_beta(self, upto):
+        """Upload momentum factors for accepted-iteration counts < upto."""
+        if not self.opts["nesterov"] or upto <= self._beta_filled:
+            return
+        first = self._beta_filled
+        count = upto - first
+        betas = np.zeros(count)
+        lo = 0
+        if first == 0:
+            betas[0] = 0.0   # y_1 = x_0 (:465)
+            lo = 1
+        if count - lo > 0:
+            vals, self._t_state = momentum_factors(count - lo, self.ratio, self._t_state)
+            betas[lo:] = vals
+        self.solver.set_beta(first, betas)
+        self._beta_filled = upto
+
+    def advance(self, steps):
+        """Enqueue ``steps`` trials, then synchronise.  Returns the trace rows of
+        the iterations accepted meanwhile (array [k, ZF_TRACE_COLS])."""
+        steps = int(min(steps, _lib.ZF_RING))
+        self._fill_beta(self.nit_seen + steps)
+        self.solver.enqueue(steps)
+        return self.collect()
+
+    def enqueue_only(self, steps):
+        steps = int(min(steps, _lib.ZF_RING))
+        self._fill_beta(self.nit_seen + steps)
+        self.solver.enqueue(steps)
+
+    def collect(self):
+        ctl, trace = self.solver.poll()
+        idx = np.arange(self.nit_seen, ctl.nit) % _lib.ZF_RING
+        rows = trace[idx].copy()
+        self.nit_seen = int(ctl.nit)
+        self.status = int(ctl.status)
+        return rows
+
+
+def _solve_native(problem, x0, opts):
+    t0 = time.time()
+    res = OptimizeResult(
+        x0=x0, tol=opts["tol"], tol_internal=opts["tol_internal"],
+        nesterov=opts["nesterov"], nesterov_ratio=opts["nesterov_ratio"],
+    )
+    if opts["verbose"]:
+        _print_header()
+    run = NativeRun(problem, x0, opts)
+    return_all, verbose = opts["return_all"], opts["verbose"]
+    allvecs = allfuns = allerrs = None
+    if return_all:
+        allvecs = [x0]
+        allfuns = [np.float64(run.F0)]
+        allerrs = []
+    chunk = 1
+    last_lr = float(opts["lr"])
+    while run.status == _lib.ZF_RUNNING:
+        before = run.nit_seen
+        rows = run.advance(chunk)
+        for k, row in enumerate(rows):
+            if verbose:
+                _print_row(before + k + 1, 1, row[_lib.TR_ERR], row[_lib.TR_FUN], row[_lib.TR_LR])
+            if return_all:
+                allfuns.append(np.float64(row[_lib.TR_F]))
+                allerrs.append(np.float64(row[_lib.TR_ERR]))
+            last_lr = row[_lib.TR_LR]
+        if return_all and len(rows):
+            allvecs.append(run.solver.get_x())   # chunk == 1: exactly this iterate
+        if not return_all:
+            chunk = min(chunk * 2, 256)
+    ctl = run.solver.ctl
+    x = run.solver.get_x()
+    F = np.float64(ctl.F_old)
+    if run.status == _lib.ZF_BACKTRACK_FAILED:
+        # proximal_gradient.py:493-509: reported, not raised
+        print(f"An error occurred: {_MSG_BACKTRACK}")
+        err = OptimizeResult()
+        err.update(success=False, message=f"Error: {_MSG_BACKTRACK}", x=x, fun=F, nit=int(ctl.nit),
+                   time=time.time() - t0, allvecs=allvecs, allfuns=allfuns, allerrs=allerrs)
+        run.solver.close()
+        return err, run.status
+    if run.status == _lib.ZF_CONVERGED:
+        res.status, res.message, res.success = 1, _MSG_OK, True
+    else:
+        res.status, res.message, res.success = 0, _MSG_MAXITER, False
+    res.update(x=x, fun=F, nit=int(ctl.nit), allvecs=allvecs, allfuns=allfuns, allerrs=allerrs,
+               time=time.time() - t0)
+    run.solver.close()
+    return res, run.status
+
+
+# ---------------------------------------------------------------------------
+# generic path: opaque callbacks, solver arithmetic in HIP kernels
+# ---------------------------------------------------------------------------
+class _VecOps:
+    """The solver's own vector expressions, evaluated on the GPU (zf_host_*)."""
+
+    def __init__(self):
+        self.lib = _lib.require_gpu()
+
+    @staticmethod
+    def _h(a):
+        return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+
+    def grad_step(self, y, jac, lr):   # :148  y - lr * jac.flatten()
+        y, jac = self._h(y), self._h(jac)
+        out = np.empty_like(y)
+        _lib.check(self.lib.zf_host_grad_step(C.c_void_p(_lib.ptr(out)), C.c_void_p(_lib.ptr(y)),
+                                              C.c_void_p(_lib.ptr(jac)), float(lr), y.size))
+        return out
+
+    def model_terms(self, jac, x, y):   # :150-152, :510
+        jac, x, y = self._h(jac), self._h(x), self._h(y)
+        out = np.zeros(3)
+        _lib.check(self.lib.zf_host_model_terms(C.c_void_p(_lib.ptr(jac)), C.c_void_p(_lib.ptr(x)),
+                                                C.c_void_p(_lib.ptr(y)), x.size, C.c_void_p(_lib.ptr(out))))
+        return np.float64(out[0]), np.float64(out[1]), np.float64(out[2])
+
+    def momentum(self, x, x_old, beta):   # :534
+        x, x_old = self._h(x), self._h(x_old)
+        out = np.empty_like(x)
+        _lib.check(self.lib.zf_host_momentum(C.c_void_p(_lib.ptr(out)), C.c_void_p(_lib.ptr(x)),
+                                             C.c_void_p(_lib.ptr(x_old)), float(beta), x.size))
+        return out
+
+
+def _objectives(value):
+    return value.shape[0] if isinstance(value, np.ndarray) else 1   # :143,:467
+
+
+def _trial_generic_single(ops, f, g, jac_f, prox, lr, x_old, y, deprecated):
+    """(:140-157) with the vector arithmetic on the device."""
+    f_y = f(y)
+    F_old = f(x_old) + g(x_old)
+    jac = jac_f(y)
+    x_new = prox(lr, ops.grad_step(y, jac, lr))
+    dot, ss, err = ops.model_terms(jac, x_new, y)
+    fun = float(dot + g(x_new) + np.sqrt(ss) ** 2 / 2 / lr)
+    if not deprecated:
+        fun += f_y - F_old
+    return x_new, fun, 1, None, err
+
+
+def _solve_generic(f, g, jac_f, prox, x0, o):
+    from . import multiobjective
+
+    ops = _VecOps()
+    t0 = time.time()
+    res = OptimizeResult(x0=x0, tol=o["tol"], tol_internal=o["tol_internal"],
+                         nesterov=o["nesterov"], nesterov_ratio=o["nesterov_ratio"])
+    if o["verbose"]:
+        _print_header()
+    x_old = x_cur = y = x0
+    f_x0 = f(x0)
+    m = _objectives(f_x0)
+    w0 = np.ones(m) / m if m > 1 else None
+    lr = o["lr"]
+    allvecs = allfuns = allerrs = None
+    if o["return_all"]:
+        allvecs, allfuns, allerrs = [x0], [f_x0 + g(x0)], []
+    t_state = None
+    status = _lib.ZF_MAXITER
+    nit = 0
+    for nit in range(1, o["max_iter"] + 1):
+        try:
+            F_old = f(x_old) + g(x_old)   # :279
+            accepted = False
+            for _ in range(o["max_backtrack_iter"]):
+                if m == 1:
+                    x_cur, fun, nit_int, weight, err = _trial_generic_single(
+                        ops, f, g, jac_f, prox, lr, x_old, y, o["deprecated"])
+                else:
+                    x_cur, fun, nit_int, weight, err = multiobjective.trial_generic(
+                        ops, f, g, jac_f, prox, lr, x_old, y, w0, o["tol_internal"],
+                        o["max_iter_internal"], o["deprecated"])
+                F_new = f(x_cur) + g(x_cur)   # :295
+                if w0 is not None and o["warm_start"]:
+                    w0 = weight
+                if o["decay_rate"] == 1:
+                    accepted = True
+                elif o["deprecated"]:
+                    accepted = bool(np.all(f(x_cur) - f(y) <= fun + o["tol_internal"]))
+                else:
+                    accepted = bool(np.all(F_new - F_old <= fun + o["tol_internal"]))
+                if accepted:
+                    break
+                lr *= o["decay_rate"]
+            if not accepted:
+                raise RuntimeError(_MSG_BACKTRACK)
+        except Exception as exc:   # :493-509
+            print(f"An error occurred: {exc}")
+            bad = OptimizeResult()
+            bad.update(success=False, message=f"Error: {str(exc)}", x=x_old, fun=f(x_old) + g(x_old),
+                       nit=nit - 1, time=time.time() - t0,
+                       allvecs=allvecs, allfuns=allfuns, allerrs=allerrs)
+            return bad, _lib.ZF_BACKTRACK_FAILED
+        if o["verbose"]:
+            _print_row(nit, nit_int, err, fun, lr)
+        if o["return_all"]:
+            allvecs.append(x_cur)
+            allfuns.append(f(x_cur) + g(x_cur))
+            allerrs.append(err)
+        if err < o["tol"]:   # :525
+            res.status, res.message, res.success = 1, _MSG_OK, True
+            status = _lib.ZF_CONVERGED
+            break
+        if o["nesterov"]:
+            beta, t_state = momentum_factors(1, o["nesterov_ratio"], t_state)
+            y = ops.momentum(x_cur, x_old, beta[0])
+        else:
+            y = x_cur
+        x_old = x_cur
+    if status == _lib.ZF_MAXITER:
+        res.status, res.message, res.success = 0, _MSG_MAXITER, False
+    res.update(x=x_cur, fun=f(x_cur) + g(x_cur), nit=nit, allvecs=allvecs, allfuns=allfuns,
+               allerrs=allerrs, time=time.time() - t0)
+    return res, status
