@@ -1,0 +1,101 @@
+"""Test-only stand-in for ``zfista_amd.engine.DeviceSolver`` (no GPU needed).
+
+The O(n) work of one trial is done with the ORACLE's NumPy expressions
+(oracle/problems_ref.py); the control logic is the product's own decide step,
+run on the host through the C ABI (``zf_decide_host`` - the very function the
+decide kernel executes).  Used by the ``-m "not gpu"`` tests to exercise the
+host driver (``NativeRun`` / ``_solve_native``), the result assembly and the
+world_size-2 gloo exchange.  Never imported by the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from oracle import problems_ref as P
+from zfista_amd import _lib
+from zfista_amd.engine import gather_packs
+
+
+class FakeProblem:
+    """Duck-typed NativeProblem for P-diag: data stays in host NumPy arrays."""
+
+    def __init__(self, d, c, lam, group=None, world=1, rank=0):
+        self.d, self.c, self.lam = np.asarray(d, float), np.asarray(c, float), float(lam)
+        self.n_features = self.d.size
+        self.group, self.world, self.rank = group, world, rank
+
+    def _descriptor(self):
+        return dict(kind=_lib.ZF_PROBLEM_DIAG_QUAD_L1, world=self.world, rank=self.rank,
+                    n=self.n_features, lam=self.lam), ()
+
+
+class FakeSolver:
+    def __init__(self, fields, options, problem, x0):
+        self.lib = _lib.load()
+        self.p = problem
+        self.world, self.group = fields["world"], problem.group
+        self.n = fields["n"]
+        c = _lib.Control()
+        c.lr, c.tol, c.tol_internal = options["lr"], options["tol"], options["tol_internal"]
+        c.decay_rate, c.max_iter = options["decay_rate"], options["max_iter"]
+        c.max_backtrack = options["max_backtrack_iter"]
+        c.status = _lib.ZF_BACKTRACK_FAILED if c.max_backtrack == 0 else _lib.ZF_RUNNING
+        c.nesterov, c.deprecated = options["nesterov"], options["deprecated"]
+        c.need_grad, c.world, c.cur = 1, self.world, 0
+        self.ctl = c
+        self.trace = np.zeros((_lib.ZF_RING, _lib.ZF_TRACE_COLS))
+        self.beta = np.zeros(_lib.ZF_RING)
+        x0 = np.asarray(x0, float)
+        self.xb = [x0.copy(), np.zeros_like(x0), x0.copy()]
+        ref = P.DiagQuadL1Ref(problem.d, problem.c, problem.lam)
+        packs = self._exchange(np.array([ref.f(x0), ref.g(x0), 0, 0, 0, 0, 0, 0], float))
+        f = sum(packs[r * 8 + 0] for r in range(self.world))
+        g = sum(packs[r * 8 + 1] for r in range(self.world))
+        c.f_x, c.g_x, c.F_old = f, g, f + g
+
+    def _exchange(self, pack_local):
+        if self.world == 1:
+            return pack_local.copy()
+        import torch
+
+        local = torch.from_numpy(np.ascontiguousarray(pack_local))
+        allp = torch.zeros(_lib.ZF_PACK_LEN * self.world, dtype=torch.float64)
+        gather_packs(allp, local, self.group)
+        return allp.numpy()
+
+    def set_beta(self, first, betas):
+        for k, b in enumerate(betas):
+            self.beta[(first + k) % _lib.ZF_RING] = b
+
+    def _trial_pack(self):
+        c, p = self.ctl, self.p
+        xk, xo = self.xb[c.cur], self.xb[(c.cur + 2) % 3]
+        beta = self.beta[c.nit % _lib.ZF_RING] if c.nesterov else 0.0
+        y = xk + beta * (xk - xo) if c.nesterov else xk
+        ref = P.DiagQuadL1Ref(p.d, p.c, p.lam)
+        grad = ref.jac_f(y)
+        xn = ref.prox_wsum_g(c.lr, y - c.lr * grad)
+        dx = xn - y
+        self.xb[(c.cur + 1) % 3] = xn
+        return np.array([ref.f(y), grad @ dx, np.sum(dx * dx), ref.g(xn), ref.f(xn),
+                         np.max(np.abs(dx)) if dx.size else 0.0, 0.0, 0.0])
+
+    def enqueue(self, steps):
+        for _ in range(steps):
+            running = self.ctl.status == _lib.ZF_RUNNING
+            pack = self._trial_pack() if running else np.zeros(_lib.ZF_PACK_LEN)
+            packs = np.ascontiguousarray(self._exchange(pack))
+            if running:
+                _lib.check(self.lib.zf_decide_host(C.byref(self.ctl), C.c_void_p(_lib.ptr(packs)),
+                                                   C.c_void_p(_lib.ptr(self.trace))))
+
+    def poll(self):
+        return self.ctl, self.trace
+
+    def get_x(self):
+        return self.xb[self.ctl.cur].copy()
+
+    def close(self):
+        pass

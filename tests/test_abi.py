@@ -1,0 +1,59 @@
+"""CPU: the C-ABI shared library loads without a GPU and exports exactly the
+symbols include/zfista_hip.h declares; struct mirrors agree; the product fails
+loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from zfista_amd import _lib
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "zfista_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(zf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in zfista_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.zf_abi_version() == 1
+
+
+def test_struct_mirrors():
+    lib = _lib.load()
+    assert lib.zf_sizeof_control() == C.sizeof(_lib.Control) == 152
+    assert C.sizeof(_lib.ProblemDesc) == 96
+    assert C.sizeof(_lib.Options) == 56
+
+
+def test_error_reporting_is_c_style():
+    lib = _lib.load()
+    rc = lib.zf_decide_host(None, None, None)
+    assert rc == -2 and b"zf_decide_host" in lib.zf_last_error()
+    with pytest.raises(_lib.ZfError):
+        _lib.check(rc, "zf_decide_host")
+
+
+def test_product_fails_loudly_without_gpu():
+    lib = _lib.load()
+    n = C.c_int(0)
+    lib.zf_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.problems import DiagQuadL1
+
+    with pytest.raises(_lib.HipUnavailable):
+        DiagQuadL1(np.ones(4), np.zeros(4), 0.1)
+    cb = (lambda x: 0.5 * float(x @ x), lambda x: 0.0, lambda x: x, lambda w, x: x)
+    with pytest.raises(_lib.HipUnavailable):
+        minimize_proximal_gradient(*cb, np.ones(3))

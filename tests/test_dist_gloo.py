@@ -1,0 +1,78 @@
+"""CPU, world_size 2 over gloo: the sharded (N > 1) path of the host driver.
+
+Each rank owns a contiguous block of x, d, c (SURVEY 8e, P-diag); per trial the
+ranks exchange ONE packed all-gather (zfista_amd.engine.gather_packs - the same
+function the GPU path calls on RCCL) and each runs the product's decide step on
+the gathered packs.  Checks: both ranks take identical decisions, the
+concatenated iterates equal the single-process oracle on the full vector
+(bit-exact: the element recursion never sees a reduced sum), and the scalar
+traces agree to 1e-12."""
+import os
+import socket
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, kw, outdir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    from fake_engine import FakeProblem, FakeSolver
+    from oracle import problems_ref as P
+    from zfista_amd.proximal_gradient import _solve_native
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    d, c, lam = P.make_pdiag(n, seed=1)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    prob = FakeProblem(d[lo:hi], c[lo:hi], lam, group=dist.group.WORLD, world=world, rank=rank)
+    base = dict(lr=1, tol=1e-5, tol_internal=1e-12, max_iter=1000000, max_iter_internal=100000,
+                max_backtrack_iter=100, warm_start=False, decay_rate=0.5, nesterov=False,
+                nesterov_ratio=(0, 0.25), return_all=True, verbose=False, deprecated=False)
+    res, status = _solve_native(prob, np.zeros(hi - lo), base | kw,
+                                solver_factory=lambda f, o, p, x0: FakeSolver(f, o, p, x0))
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), x=res.x, nit=res.nit, status=status,
+             allerrs=np.asarray(res.allerrs), allfuns=np.asarray(res.allfuns),
+             vecs=np.stack(res.allvecs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(lr=0.45, nesterov=True, tol=0.0, max_iter=40),
+    dict(lr=4.0, nesterov=True, tol=1e-6, max_iter=500),      # backtracking: lr decisions must agree
+    dict(lr=0.45, nesterov=False, tol=1e-4, max_iter=500),
+])
+def test_sharded_pdiag_world2(tmp_path, kw):
+    import torch.multiprocessing as mp
+
+    from oracle import cpu_ref, problems_ref as P
+
+    n, world = 10007, 2
+    mp.spawn(_worker, args=(world, _free_port(), n, kw, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    d, c, lam = P.make_pdiag(n, seed=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*P.DiagQuadL1Ref(d, c, lam).callbacks(), np.zeros(n),
+                                                 return_all=True, **kw)
+    assert int(r[0]["nit"]) == int(r[1]["nit"]) == exp.nit
+    assert int(r[0]["status"]) == int(r[1]["status"])
+    assert np.array_equal(r[0]["allerrs"], r[1]["allerrs"]) and np.array_equal(r[0]["allfuns"], r[1]["allfuns"])
+    full = np.concatenate([r[0]["vecs"], r[1]["vecs"]], axis=1)
+    assert np.array_equal(full, np.stack(exp.allvecs))
+    np.testing.assert_allclose(r[0]["allerrs"], exp.allerrs, rtol=0, atol=0)
+    np.testing.assert_allclose(r[0]["allfuns"], exp.allfuns, rtol=1e-12)

@@ -1,0 +1,186 @@
+"""CPU: the product's control logic without a GPU.
+
+* zf_decide_host (the function the decide kernel runs) against the oracle's line
+  search on identical reduced scalars;
+* the host driver (NativeRun / _solve_native: chunking, momentum table, trace ring,
+  result assembly, warnings, error results) driven by tests/fake_engine.FakeSolver,
+  compared with the oracle and the golden vectors of the reference."""
+import ctypes as C
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from fake_engine import FakeProblem, FakeSolver
+from oracle import cpu_ref, problems_ref as P
+from zfista_amd import _lib
+from zfista_amd.proximal_gradient import NativeRun, _solve_native
+
+BASE = dict(lr=1, tol=1e-5, tol_internal=1e-12, max_iter=1000000, max_iter_internal=100000,
+            max_backtrack_iter=100, warm_start=False, decay_rate=0.5, nesterov=False,
+            nesterov_ratio=(0, 0.25), return_all=False, verbose=False, deprecated=False)
+
+
+def _ctl(**kw):
+    c = _lib.Control()
+    c.lr, c.tol, c.tol_internal, c.decay_rate = 1.0, 1e-5, 1e-12, 0.5
+    c.max_iter, c.max_backtrack, c.world, c.F_old = 100, 3, 1, 10.0
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _decide(c, pack, world=1):
+    lib = _lib.load()
+    trace = np.zeros((_lib.ZF_RING, _lib.ZF_TRACE_COLS))
+    p = np.ascontiguousarray(np.asarray(pack, float))
+    _lib.check(lib.zf_decide_host(C.byref(c), C.c_void_p(_lib.ptr(p)), C.c_void_p(_lib.ptr(trace))))
+    return trace
+
+
+def test_decide_accept_reject_and_failure():
+    # pack: f_y, dot, ss, g_x, f_x, err
+    c = _ctl()
+    # F_x = 9, fun = dot+g + ss/2/lr + f_y - F_old = -2+1+0.5+10.2-10 = -0.3 ; 9-10 <= -0.3 -> accept
+    tr = _decide(c, [10.2, -2.0, 1.0, 1.0, 8.0, 0.5, 0, 0])
+    assert (c.nit, c.trial, c.cur, c.status) == (1, 0, 1, _lib.ZF_RUNNING)
+    assert c.F_old == 9.0 and c.lr == 1.0 and c.need_grad == 1
+    assert tr[0, _lib.TR_ERR] == 0.5 and tr[0, _lib.TR_F] == 9.0 and tr[0, _lib.TR_TRIALS] == 1
+    assert tr[0, _lib.TR_FUN] == (-2.0 + 1.0) + np.sqrt(1.0) ** 2 / 2 / 1.0 + (10.2 - 10.0)   # :150-155 order
+    # reject: F_x - F_old = 0.5 > fun
+    c = _ctl()
+    _decide(c, [10.0, -2.0, 1.0, 1.0, 9.5, 0.5, 0, 0])
+    assert (c.nit, c.trial, c.cur, c.lr, c.need_grad) == (0, 1, 0, 0.5, 0)
+    _decide(c, [10.0, -2.0, 1.0, 1.0, 20.0, 0.5, 0, 0])
+    _decide(c, [10.0, -2.0, 1.0, 1.0, 20.0, 0.5, 0, 0])
+    assert c.status == _lib.ZF_BACKTRACK_FAILED and c.lr == 0.125 and c.nit == 0
+    # further steps are no-ops
+    _decide(c, [10.2, -2.0, 1.0, 1.0, 8.0, 0.5, 0, 0])
+    assert c.nit == 0 and c.total_trials == 3
+
+
+def test_decide_termination_order_and_flags():
+    c = _ctl(max_iter=1)
+    _decide(c, [10.2, -2.0, 1.0, 1.0, 8.0, 1e-6, 0, 0])      # err < tol wins over max_iter (:525 before :539)
+    assert c.status == _lib.ZF_CONVERGED
+    c = _ctl(max_iter=1)
+    _decide(c, [10.2, -2.0, 1.0, 1.0, 8.0, 1e-5, 0, 0])      # strict <
+    assert c.status == _lib.ZF_MAXITER
+    c = _ctl(decay_rate=1.0)
+    _decide(c, [0.0, 0.0, 0.0, 0.0, 99.0, 1.0, 0, 0])        # decay_rate == 1 accepts unconditionally (:298)
+    assert c.nit == 1
+    c = _ctl(deprecated=1)
+    # deprecated: f_x - f_y <= dot + g + ss/2/lr + tol  (:301); 8-10.2=-2.2 <= -0.5
+    _decide(c, [10.2, -2.0, 1.0, 1.0, 8.0, 1.0, 0, 0])
+    assert c.nit == 1 and abs(c.fun - (-0.5)) < 1e-15
+    c = _ctl(F_old=np.inf)                                     # x0 outside the box: everything is accepted
+    _decide(c, [1.0, 0.0, 0.0, 0.0, 5.0, 1.0, 0, 0])
+    assert c.nit == 1
+    c = _ctl()
+    _decide(c, [np.nan, 0.0, 0.0, 0.0, 5.0, 1.0, 0, 0])       # NaN never satisfies <= (np.all(nan<=..) is False)
+    assert c.nit == 0 and c.trial == 1
+
+
+def test_decide_sums_packs_in_rank_order():
+    c = _ctl(world=3)
+    packs = np.array([[1.0, -1.0, 0.25, 0.5, 2.0, 0.1, 0, 0],
+                      [2.0, -0.5, 0.25, 0.25, 3.0, 0.7, 0, 0],
+                      [7.2, -0.5, 0.5, 0.25, 3.0, 0.3, 0, 0]])
+    tr = _decide(c, packs.ravel())
+    assert c.nit == 1 and tr[0, _lib.TR_ERR] == 0.7 and tr[0, _lib.TR_F] == 9.0
+    assert tr[0, _lib.TR_FY] == (1.0 + 2.0) + 7.2
+
+
+def _factory(fields, options, problem, x0):
+    return FakeSolver(fields, options, problem, x0)
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("fista_lr0.45", dict(lr=0.45, nesterov=True, tol=0.0, max_iter=60)),
+    ("ista_lr0.45", dict(lr=0.45, nesterov=False, tol=0.0, max_iter=60)),
+    ("fista_lr4_backtrack", dict(lr=4.0, nesterov=True, tol=0.0, max_iter=60)),
+    ("fista_tol1e-6", dict(lr=0.45, nesterov=True, tol=1e-6, max_iter=10000)),
+    ("fista_ab_0.5_0.25", dict(lr=0.45, nesterov=True, nesterov_ratio=(0.5, 0.25), tol=0.0, max_iter=60)),
+])
+@pytest.mark.parametrize("return_all", [True, False])
+def test_host_driver_against_golden(golden, tag, kw, return_all):
+    G = golden("g3_diag_n10007.npz")
+    d, c, lam = P.make_pdiag(10007, seed=1)
+    prob = FakeProblem(d, c, lam)
+    o = BASE | kw | dict(return_all=return_all)
+    res, status = _solve_native(prob, np.zeros(10007), o, solver_factory=_factory)
+    assert res.nit == int(G(f"{tag}.nit"))
+    assert np.array_equal(res.x, G(f"{tag}.x"))
+    np.testing.assert_allclose(res.fun, G(f"{tag}.fun"), rtol=1e-12)
+    assert res.status == int(G(f"{tag}.status"))
+    if return_all:
+        assert np.array_equal(np.stack([res.allvecs[k] for k in G(f"{tag}.kept")]), G(f"{tag}.vecs"))
+        np.testing.assert_allclose(res.allerrs, G(f"{tag}.allerrs"), rtol=0, atol=0)
+        np.testing.assert_allclose(res.allfuns, G(f"{tag}.allfuns"), rtol=1e-12)
+    else:
+        assert res.allvecs is None and res.allfuns is None and res.allerrs is None
+
+
+def test_host_driver_chunks_cross_the_ring():
+    """More iterations than ZF_RING: momentum ring and trace ring wrap correctly."""
+    n = 257
+    d, c, lam = P.make_pdiag(n, seed=5)
+    prob = FakeProblem(d, c, lam)
+    K = 2 * _lib.ZF_RING + 77
+    o = BASE | dict(lr=0.05, nesterov=True, tol=0.0, max_iter=K)
+    run = NativeRun(prob, np.zeros(n), o, solver_factory=_factory)
+    errs = []
+    while run.status == _lib.ZF_RUNNING:
+        errs.extend(run.advance(700)[:, _lib.TR_ERR])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*P.DiagQuadL1Ref(d, c, lam).callbacks(), np.zeros(n),
+                                                 lr=0.05, nesterov=True, tol=0.0, max_iter=K, return_all=True)
+    assert run.nit_seen == K and len(errs) == K
+    assert np.array_equal(np.asarray(errs), np.asarray(exp.allerrs))
+    assert np.array_equal(run.solver.get_x(), exp.x)
+
+
+def test_host_driver_result_shapes_and_messages(capsys):
+    """Result keys / messages / warnings equal the reference's (fixture G6)."""
+    shapes = json.load(open(os.path.join(GOLDEN, "g6_result_shapes.json")))
+    d, c, lam = P.make_pdiag(33, seed=2)
+    prob = FakeProblem(d, c, lam)
+    x0 = np.zeros(33)
+    res, st = _solve_native(prob, x0, BASE | dict(lr=0.4, tol=1e-9), solver_factory=_factory)
+    assert sorted(res.keys()) == shapes["success"]["keys"]
+    assert (res.status, res.message, res.success) == (1, shapes["success"]["message"], True)
+    res, st = _solve_native(prob, x0, BASE | dict(lr=0.4, max_iter=3, tol=0.0), solver_factory=_factory)
+    assert sorted(res.keys()) == shapes["max_iter"]["keys"]
+    assert (res.status, res.message, res.success, res.nit) == (0, shapes["max_iter"]["message"], False, 3)
+    assert st == _lib.ZF_MAXITER
+    # backtracking failure -> error-shaped result, printed not raised (:493-509)
+    res, st = _solve_native(prob, x0, BASE | dict(lr=1e6, max_backtrack_iter=2), solver_factory=_factory)
+    assert sorted(res.keys()) == shapes["backtracking_failure"]["keys"]
+    assert res.message == shapes["backtracking_failure"]["message"] and res.nit == 0 and not res.success
+    assert np.array_equal(res.x, x0)
+    assert capsys.readouterr().out.splitlines()[-1] == shapes["backtracking_failure"]["stdout_ref"][0]
+    res, st = _solve_native(prob, x0, BASE | dict(lr=0.4, max_backtrack_iter=0), solver_factory=_factory)
+    assert res.message == shapes["backtracking_failure"]["message"]
+
+
+def test_public_entry_warns_like_the_reference(monkeypatch):
+    """UserWarning on max-iter and on deprecated=True (:445,:543) from the public function."""
+    import zfista_amd.proximal_gradient as pg
+
+    d, c, lam = P.make_pdiag(17, seed=3)
+    prob = FakeProblem(d, c, lam)
+    monkeypatch.setattr(pg, "match_native", lambda *a: prob)
+    real = pg._solve_native
+    monkeypatch.setattr(pg, "_solve_native", lambda p, x0, o: real(p, x0, o, solver_factory=_factory))
+    with pytest.warns(UserWarning, match="Maximum number of iterations reached"):
+        res = pg.minimize_proximal_gradient(None, None, None, None, np.zeros(17), lr=0.4, max_iter=2, tol=0.0)
+    assert res.nit == 2
+    with pytest.warns(UserWarning, match="deprecated option"):
+        pg.minimize_proximal_gradient(None, None, None, None, np.zeros(17), lr=0.4, deprecated=True)
+    # verbose prints a header and one row per iteration (documented deviation: the reference raises)
+    res = pg.minimize_proximal_gradient(None, None, None, None, np.zeros(17), lr=0.4, tol=1e-3, verbose=True)
+    assert res.success

@@ -33,6 +33,17 @@ def momentum_factors(count: int, ratio, state=None):
     return out, t_prev
 
 
+def gather_packs(pack_all, pack_local, group):
+    """C1: the one collective of a sharded trial - a packed
+    all-gather of ZF_PACK_LEN doubles (64 B) per rank, rank-major.  Every rank
+    then adds the packs in rank order inside the decide step, so all ranks take
+    bitwise-identical branch decisions.  Runs on RCCL for CUDA tensors (backend
+    "nccl") and on gloo for the CPU tests."""
+    import torch.distributed as dist
+
+    dist.all_gather_into_tensor(pack_all, pack_local, group=group)
+
+
 class DeviceSolver:
     """One ``zf_solver``: a problem descriptor bound to device buffers + options.
 
@@ -86,19 +97,28 @@ class DeviceSolver:
             self.handle, C.c_void_p(self._pack_local.data_ptr()), C.c_void_p(self._pack_all.data_ptr())))
 
     def _gather(self):
-        # C1: one packed all-gather of <= 64 B per rank; every rank then
-        # adds the packs in rank order inside the decide kernel, so all ranks take
-        # bitwise-identical branch decisions.
-        import torch.distributed as dist
+        gather_packs(self._pack_all, self._pack_local, self.group)
 
-        dist.all_gather_into_tensor(self._pack_all, self._pack_local, group=self.group)
+    # the two halves of a sharded step, and of the sharded initialisation; the
+    # caller runs the exchange between them (enqueue()/init() do exactly that)
+    def enqueue_trial(self):
+        _lib.check(self.lib.zf_solver_enqueue_trial(self.handle), "enqueue_trial")
+
+    def enqueue_decide(self):
+        _lib.check(self.lib.zf_solver_enqueue_decide(self.handle), "enqueue_decide")
+
+    def init_begin(self, x0_dev_ptr: int):
+        _lib.check(self.lib.zf_solver_enqueue_init(self.handle, C.c_void_p(x0_dev_ptr)), "init")
+
+    def init_commit(self):
+        _lib.check(self.lib.zf_solver_enqueue_init_commit(self.handle), "init_commit")
 
     # -- life cycle ---------------------------------------------------------------
     def init(self, x0_dev_ptr: int):
-        _lib.check(self.lib.zf_solver_enqueue_init(self.handle, C.c_void_p(x0_dev_ptr)), "init")
+        self.init_begin(x0_dev_ptr)
         if self.world > 1:
             self._gather()
-        _lib.check(self.lib.zf_solver_enqueue_init_commit(self.handle), "init_commit")
+        self.init_commit()
 
     def set_beta(self, first: int, betas: np.ndarray):
         betas = np.ascontiguousarray(betas, dtype=np.float64)
@@ -111,9 +131,9 @@ class DeviceSolver:
             _lib.check(self.lib.zf_solver_enqueue_steps(self.handle, steps), "enqueue_steps")
             return
         for _ in range(steps):
-            _lib.check(self.lib.zf_solver_enqueue_trial(self.handle), "enqueue_trial")
+            self.enqueue_trial()
             self._gather()
-            _lib.check(self.lib.zf_solver_enqueue_decide(self.handle), "enqueue_decide")
+            self.enqueue_decide()
 
     def poll(self):
         """Synchronise and fetch the control block + trace ring."""

@@ -87,9 +87,7 @@ class NativeRun:
     """A device-resident solve that can be advanced in chunks (used by bench.py
     to time exactly K iterations with the inputs already resident in HBM)."""
 
-    def __init__(self, problem, x0, opts, timing=False):
-        import torch
-
+    def __init__(self, problem, x0, opts, timing=False, solver_factory=None):
         self.problem = problem
         self.opts = opts
         fields, keep = problem._descriptor()
@@ -99,15 +97,21 @@ class NativeRun:
             max_backtrack_iter=int(opts["max_backtrack_iter"]),
             nesterov=int(bool(opts["nesterov"])), deprecated=int(bool(opts["deprecated"])),
         )
-        if isinstance(x0, torch.Tensor):
-            x0_dev = x0.to(device="cuda", dtype=torch.float64).contiguous()
+        if solver_factory is not None:
+            # test seam: a stand-in with DeviceSolver's interface (tests/fake_engine.py)
+            self.solver = solver_factory(fields, options, problem, x0)
         else:
-            x0_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(x0, dtype=np.float64))).cuda()
-        if x0_dev.numel() != problem.n_features:
-            raise ValueError(f"len(x) should be equal to n_features, got {x0}.")
-        self.solver = DeviceSolver(fields, options, keepalive=keep, group=problem.group, timing=timing)
-        self.solver.init(x0_dev.data_ptr())
-        self._x0_dev = x0_dev
+            import torch
+
+            if isinstance(x0, torch.Tensor):
+                x0_dev = x0.to(device="cuda", dtype=torch.float64).contiguous()
+            else:
+                x0_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(x0, dtype=np.float64))).cuda()
+            if x0_dev.numel() != problem.n_features:
+                raise ValueError(f"len(x) should be equal to n_features, got {x0}.")
+            self.solver = DeviceSolver(fields, options, keepalive=keep, group=problem.group, timing=timing)
+            self.solver.init(x0_dev.data_ptr())
+            self._x0_dev = x0_dev
         self.ratio = opts["nesterov_ratio"]
         self._t_state = None
         self._beta_filled = 0     # momentum factors uploaded for accepted counts < this
@@ -156,7 +160,7 @@ class NativeRun:
         return rows
 
 
-def _solve_native(problem, x0, opts):
+def _solve_native(problem, x0, opts, solver_factory=None):
     t0 = time.time()
     res = OptimizeResult(
         x0=x0, tol=opts["tol"], tol_internal=opts["tol_internal"],
@@ -164,7 +168,7 @@ def _solve_native(problem, x0, opts):
     )
     if opts["verbose"]:
         _print_header()
-    run = NativeRun(problem, x0, opts)
+    run = NativeRun(problem, x0, opts, solver_factory=solver_factory)
     return_all, verbose = opts["return_all"], opts["verbose"]
     allvecs = allfuns = allerrs = None
     if return_all:
