@@ -1,0 +1,268 @@
+// tune_trial.hip - sweep launch geometry / unroll / cache policy of the fused
+// P-diag trial kernel at n = 1e8 (development tool, not part of the library).
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -I include tools/tune_trial.hip -o tools/tune_trial
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "../zfista_amd/csrc/zf_kernels_step.h"
+
+thread_local char zf_errbuf[512] = "";
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+template <bool NT> __device__ __forceinline__ double2 ld2(const double2* p) {
+    if (NT) { double2 v; v.x = __builtin_nontemporal_load(&p->x); v.y = __builtin_nontemporal_load(&p->y); return v; }
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ void st2(double2* p, double2 v) {
+    if (NT) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); }
+    else *p = v;
+}
+
+// U = 16-byte units per thread per trip; BS = block size
+template <int U, int BS, bool NTL, bool NTS>
+__global__ __launch_bounds__(BS) void trial_v(const double* __restrict__ xk, const double* __restrict__ xo,
+                                             const double* __restrict__ d, const double* __restrict__ c,
+                                             double* __restrict__ xn, double beta, double lr, double lam,
+                                             int64_t n, double* partials) {
+    __shared__ double lds[(BS / 64) * ZF_NPART];
+    const double tau = lam * lr;
+    zf_elem_acc acc = {0, 0, 0, 0, 0, 0};
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    const double2* xk2 = (const double2*)xk; const double2* xo2 = (const double2*)xo;
+    const double2* d2 = (const double2*)d; const double2* c2 = (const double2*)c;
+    double2* xn2 = (double2*)xn;
+    int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    for (; i + (U - 1) * stride < n2; i += U * stride) {
+        double2 a[U], o[U], q[U], cc[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = ld2<false>(xk2 + i + u * stride); o[u] = ld2<false>(xo2 + i + u * stride);
+            q[u] = ld2<NTL>(d2 + i + u * stride); cc[u] = ld2<NTL>(c2 + i + u * stride); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            r[u].x = zf_elem_diag<true, false>(a[u].x, o[u].x, q[u].x, cc[u].x, beta, lr, tau, 0, 0, acc);
+            r[u].y = zf_elem_diag<true, false>(a[u].y, o[u].y, q[u].y, cc[u].y, beta, lr, tau, 0, 0, acc);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) st2<NTS>(xn2 + i + u * stride, r[u]);
+    }
+    for (; i < n2; i += stride) {
+        double2 a = xk2[i], o = xo2[i], q = d2[i], cc = c2[i], r;
+        r.x = zf_elem_diag<true, false>(a.x, o.x, q.x, cc.x, beta, lr, tau, 0, 0, acc);
+        r.y = zf_elem_diag<true, false>(a.y, o.y, q.y, cc.y, beta, lr, tau, 0, 0, acc);
+        xn2[i] = r;
+    }
+    const double sums[5] = {acc.fy, acc.dot, acc.ss, acc.l1, acc.fx};
+    const double maxs[1] = {acc.mx};
+    double out = 0.0;
+    zf_block_reduce<5, 1, BS / 64>(sums, maxs, lds, out);
+    if (threadIdx.x < ZF_NPART) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+}
+
+// block-contiguous: a block owns U consecutive tiles of BS 16-B units; MASK bits: 1 = d,c nt; 2 = xo nt; 4 = xk nt; 8 = store nt
+template <int U, int BS, int MASK>
+__global__ __launch_bounds__(BS) void trial_c(const double* __restrict__ xk, const double* __restrict__ xo,
+                                             const double* __restrict__ d, const double* __restrict__ c,
+                                             double* __restrict__ xn, double beta, double lr, double lam,
+                                             int64_t n, double* partials) {
+    __shared__ double lds[(BS / 64) * ZF_NPART];
+    const double tau = lam * lr;
+    zf_elem_acc acc = {0, 0, 0, 0, 0, 0};
+    const int64_t n2 = n >> 1;
+    const double2* xk2 = (const double2*)xk; const double2* xo2 = (const double2*)xo;
+    const double2* d2 = (const double2*)d; const double2* c2 = (const double2*)c;
+    double2* xn2 = (double2*)xn;
+    const int64_t base = (int64_t)blockIdx.x * (U * BS) + threadIdx.x;
+    if (base + (U - 1) * BS < n2) {
+        double2 a[U], o[U], q[U], cc[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = ld2<(MASK & 4) != 0>(xk2 + base + u * BS); o[u] = ld2<(MASK & 2) != 0>(xo2 + base + u * BS);
+            q[u] = ld2<(MASK & 1) != 0>(d2 + base + u * BS); cc[u] = ld2<(MASK & 1) != 0>(c2 + base + u * BS); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            r[u].x = zf_elem_diag<true, false>(a[u].x, o[u].x, q[u].x, cc[u].x, beta, lr, tau, 0, 0, acc);
+            r[u].y = zf_elem_diag<true, false>(a[u].y, o[u].y, q[u].y, cc[u].y, beta, lr, tau, 0, 0, acc);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) st2<(MASK & 8) != 0>(xn2 + base + u * BS, r[u]);
+    } else {
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + u * BS;
+            if (i < n2) {
+                double2 a = xk2[i], o = xo2[i], q = d2[i], cc = c2[i], r;
+                r.x = zf_elem_diag<true, false>(a.x, o.x, q.x, cc.x, beta, lr, tau, 0, 0, acc);
+                r.y = zf_elem_diag<true, false>(a.y, o.y, q.y, cc.y, beta, lr, tau, 0, 0, acc);
+                xn2[i] = r;
+            }
+        }
+    }
+    const double sums[5] = {acc.fy, acc.dot, acc.ss, acc.l1, acc.fx};
+    const double maxs[1] = {acc.mx};
+    double out = 0.0;
+    zf_block_reduce<5, 1, BS / 64>(sums, maxs, lds, out);
+    if (threadIdx.x < ZF_NPART) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+}
+
+// persistent: workgroup b walks tiles b, b+G, b+2G, ... (tile = U*BS consecutive units); PF = prefetch next tile
+template <int U, int BS, int MASK, bool PF>
+__global__ __launch_bounds__(BS) void trial_p(const double* __restrict__ xk, const double* __restrict__ xo,
+                                             const double* __restrict__ d, const double* __restrict__ c,
+                                             double* __restrict__ xn, double beta, double lr, double lam,
+                                             int64_t n, double* partials) {
+    __shared__ double lds[(BS / 64) * ZF_NPART];
+    const double tau = lam * lr;
+    zf_elem_acc acc = {0, 0, 0, 0, 0, 0};
+    const int64_t n2 = n >> 1;
+    const int64_t ntiles = n2 / (U * BS);   // ragged tail ignored in this tool
+    const double2* xk2 = (const double2*)xk; const double2* xo2 = (const double2*)xo;
+    const double2* d2 = (const double2*)d; const double2* c2 = (const double2*)c;
+    double2* xn2 = (double2*)xn;
+    double2 a[U], o[U], q[U], cc[U], r[U];
+    double2 a1[U], o1[U], q1[U], c1[U];
+    int64_t t = blockIdx.x;
+    if (PF && t < ntiles) {
+        const int64_t base = t * (U * BS) + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a1[u] = ld2<(MASK & 4) != 0>(xk2 + base + u * BS); o1[u] = ld2<(MASK & 2) != 0>(xo2 + base + u * BS);
+            q1[u] = ld2<(MASK & 1) != 0>(d2 + base + u * BS); c1[u] = ld2<(MASK & 1) != 0>(c2 + base + u * BS); }
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        const int64_t base = t * (U * BS) + threadIdx.x;
+        if (PF) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u] = a1[u]; o[u] = o1[u]; q[u] = q1[u]; cc[u] = c1[u]; }
+            const int64_t tn = t + gridDim.x;
+            if (tn < ntiles) {
+                const int64_t bn = tn * (U * BS) + threadIdx.x;
+#pragma unroll
+                for (int u = 0; u < U; ++u) { a1[u] = ld2<(MASK & 4) != 0>(xk2 + bn + u * BS); o1[u] = ld2<(MASK & 2) != 0>(xo2 + bn + u * BS);
+                    q1[u] = ld2<(MASK & 1) != 0>(d2 + bn + u * BS); c1[u] = ld2<(MASK & 1) != 0>(c2 + bn + u * BS); }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u] = ld2<(MASK & 4) != 0>(xk2 + base + u * BS); o[u] = ld2<(MASK & 2) != 0>(xo2 + base + u * BS);
+                q[u] = ld2<(MASK & 1) != 0>(d2 + base + u * BS); cc[u] = ld2<(MASK & 1) != 0>(c2 + base + u * BS); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            r[u].x = zf_elem_diag<true, false>(a[u].x, o[u].x, q[u].x, cc[u].x, beta, lr, tau, 0, 0, acc);
+            r[u].y = zf_elem_diag<true, false>(a[u].y, o[u].y, q[u].y, cc[u].y, beta, lr, tau, 0, 0, acc);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) st2<(MASK & 8) != 0>(xn2 + base + u * BS, r[u]);
+    }
+    const double sums[5] = {acc.fy, acc.dot, acc.ss, acc.l1, acc.fx};
+    const double maxs[1] = {acc.mx};
+    double out = 0.0;
+    zf_block_reduce<5, 1, BS / 64>(sums, maxs, lds, out);
+    if (threadIdx.x < ZF_NPART) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+}
+// calibration: pure streams (R reads, 1 write), 16 B per lane
+template <int R, int U, int BS>
+__global__ __launch_bounds__(BS) void stream_v(const double2* __restrict__ a, const double2* __restrict__ b,
+                                              const double2* __restrict__ c, const double2* __restrict__ d,
+                                              double2* __restrict__ o, int64_t n2) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    for (; i + (U - 1) * stride < n2; i += U * stride) {
+        double2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = a[i + u * stride];
+            if (R > 1) { double2 t = b[i + u * stride]; v[u].x += t.x; v[u].y += t.y; }
+            if (R > 2) { double2 t = c[i + u * stride]; v[u].x += t.x; v[u].y += t.y; }
+            if (R > 3) { double2 t = d[i + u * stride]; v[u].x += t.x; v[u].y += t.y; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) o[i + u * stride] = v[u];
+    }
+    for (; i < n2; i += stride) { double2 v = a[i]; o[i] = v; }
+}
+
+struct Bufs { double *xk, *xo, *d, *c, *xn, *partials; int64_t n; };
+
+template <typename F> double time_ms(F launch, int reps = 20) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch();
+    std::vector<float> ts;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0, 0)); launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
+template <int U, int BS, bool NTL, bool NTS> void run_trial(const Bufs& B, int grid, const char* tag) {
+    double ms = time_ms([&] { hipLaunchKernelGGL((trial_v<U, BS, NTL, NTS>), dim3(grid), dim3(BS), 0, 0, B.xk, B.xo, B.d, B.c,
+                                                 B.xn, 0.3, 0.45, 0.1, B.n, B.partials); });
+    printf("trial U=%d BS=%4d ntl=%d nts=%d grid=%6d %-8s : %7.3f ms  %7.1f GB/s (40 B/elem)\n", U, BS, (int)NTL, (int)NTS, grid,
+           tag, ms, 40.0 * B.n / ms / 1e6);
+}
+template <int U, int BS, int MASK> void run_c(const Bufs& B) {
+    const int64_t n2 = B.n / 2;
+    int grid = (int)((n2 + (int64_t)U * BS - 1) / ((int64_t)U * BS));
+    double ms = time_ms([&] { hipLaunchKernelGGL((trial_c<U, BS, MASK>), dim3(grid), dim3(BS), 0, 0, B.xk, B.xo, B.d, B.c,
+                                                 B.xn, 0.3, 0.45, 0.1, B.n, B.partials); });
+    printf("contig U=%d BS=%4d mask=%2d grid=%6d : %7.3f ms  %7.1f GB/s\n", U, BS, MASK, grid, ms, 40.0 * B.n / ms / 1e6);
+}
+// the library's kernel itself (control block, in-launch reduction tail, rotating ring)
+template <bool NT> void run_lib(const Bufs& B, bool decide) {
+    const int64_t n2 = B.n / 2;
+    int grid = (int)((n2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS);
+    int ngroups = (grid + ZF_GROUP - 1) / ZF_GROUP;
+    zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.world = 1; h.max_iter = 1 << 30;
+    h.max_backtrack = 100; h.decay_rate = 0.5; h.tol_internal = 1e300; h.F_old = 1e300; h.nesterov = 1;
+    zf_control* ctl; CK(hipMalloc(&ctl, sizeof(h))); CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+    double *beta, *trace, *pack; unsigned* cnt; zf_step_args A;
+    CK(hipMalloc(&beta, 8 * ZF_RING)); CK(hipMemset(beta, 0, 8 * ZF_RING)); CK(hipMalloc(&trace, 8 * ZF_RING * 8));
+    CK(hipMalloc(&pack, 64)); CK(hipMalloc(&cnt, 4 * (ngroups + 16))); CK(hipMemset(cnt, 0, 4 * (ngroups + 16)));
+    CK(hipMalloc(&A.ws.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&A.ws.grp_part, 8 * ZF_NPART * ngroups));
+    CK(hipMalloc(&A.ws.totals, 64)); A.ws.grp_cnt = cnt; A.ws.top_cnt = cnt + ngroups;
+    A.ctl = ctl; A.beta_ring = beta; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c;
+    A.lam = 0.1; A.lo = 0; A.hi = 0; A.n = B.n;
+    for (int k = 0; k < ZF_NPART; ++k) A.tail.scale[k] = 1.0;
+    A.tail.pack = pack; A.tail.ctl_rw = decide ? ctl : nullptr; A.tail.trace = trace;
+    double ms = time_ms([&] { hipLaunchKernelGGL((zf_trial_kernel<true, true, false, NT>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A); });
+    printf("LIB kernel nt=%d decide(rotating ring)=%d grid=%6d : %7.3f ms  %7.1f GB/s\n", (int)NT, (int)decide, grid, ms,
+           40.0 * B.n / ms / 1e6);
+}
+template <int U, int BS, int MASK, bool PF> void run_p(const Bufs& B, int grid) {
+    double ms = time_ms([&] { hipLaunchKernelGGL((trial_p<U, BS, MASK, PF>), dim3(grid), dim3(BS), 0, 0, B.xk, B.xo, B.d, B.c,
+                                                 B.xn, 0.3, 0.45, 0.1, B.n, B.partials); });
+    printf("persist U=%d BS=%4d mask=%2d pf=%d grid=%6d : %7.3f ms  %7.1f GB/s\n", U, BS, MASK, (int)PF, grid, ms, 40.0 * B.n / ms / 1e6);
+}
+
+template <int R, int U, int BS> void run_stream(const Bufs& B, int grid) {
+    double ms = time_ms([&] { hipLaunchKernelGGL((stream_v<R, U, BS>), dim3(grid), dim3(BS), 0, 0, (const double2*)B.xk,
+                                                 (const double2*)B.xo, (const double2*)B.d, (const double2*)B.c,
+                                                 (double2*)B.xn, B.n / 2); });
+    printf("stream R=%d U=%d BS=%4d grid=%6d          : %7.3f ms  %7.1f GB/s (%d B/elem)\n", R, U, BS, grid, ms,
+           8.0 * (R + 1) * B.n / ms / 1e6, 8 * (R + 1));
+}
+
+__global__ void fill(double* p, int64_t n, double s) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = s * (double)((i * 2654435761u) % 1000003) / 1000003.0 + 0.5;
+}
+
+int main(int argc, char** argv) {
+    Bufs B; B.n = argc > 1 ? atoll(argv[1]) : 100000000LL;
+    size_t bytes = sizeof(double) * B.n;
+    CK(hipMalloc(&B.xk, bytes)); CK(hipMalloc(&B.xo, bytes)); CK(hipMalloc(&B.d, bytes)); CK(hipMalloc(&B.c, bytes));
+    CK(hipMalloc(&B.xn, bytes)); CK(hipMalloc(&B.partials, sizeof(double) * ZF_NPART * 1000000));
+    fill<<<2048, 256>>>(B.xk, B.n, 1.0); fill<<<2048, 256>>>(B.xo, B.n, 0.9); fill<<<2048, 256>>>(B.d, B.n, 1.5);
+    fill<<<2048, 256>>>(B.c, B.n, -2.0); CK(hipDeviceSynchronize());
+    const int64_t n2 = B.n / 2;
+    auto full = [&](int U, int BS) { return (int)((n2 + (int64_t)U * BS - 1) / ((int64_t)U * BS)); };
+    printf("n = %lld\n", (long long)B.n);
+    run_c<4, 256, 9>(B);
+    run_lib<true>(B, true); run_lib<true>(B, false); run_lib<false>(B, true);
+    run_c<4, 256, 9>(B);
+    run_lib<true>(B, true);
+    return 0;
+}

@@ -15,6 +15,7 @@
 // the summation order of the reductions differs.
 #pragma once
 #include "zf_common.h"
+#include "zf_decide.h"
 
 // number of per-block partial quantities a trial kernel emits
 // [0] f(y) raw  [1] dot  [2] ss  [3] |x+|_1  [4] f(x+) raw  [5] max
@@ -63,6 +64,73 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
     return xn;
 }
 
+// ---------------------------------------------------------------------------
+// launch geometry of the trial kernel (measured on MI355X, tools/tune_trial.hip,
+// n = 1e8: 0.66 ms = 6.05 TB/s for the streaming part; a capped grid-stride loop
+// ran 0.87 ms, persistent tile walks 0.67-0.71 ms depending on the device):
+//   * one STREAMING workgroup per tile of ZF_TILE_UNITS = 4 x 256 consecutive
+//     16-byte units (16 KiB of every stream); the dispatcher hands out tiles in
+//     order, so the resident workgroups sweep each array as one contiguous
+//     window (DRAM locality);
+//   * all 16 loads of a thread are issued before the first use;
+//   * d, c are read once per trial and x+ is written once: nontemporal (nt)
+//     loads / stores keep them from displacing x_k in the caches (+8 %).
+// The reduction is finished inside the same launch (no finalize kernel, no
+// extra launch boundary): every workgroup publishes its six partials
+// write-through (sc1) and takes a ticket on its group's counter; the group's
+// last arriver adds the members' partials (fixed shuffle tree = index order),
+// publishes the group partial and takes a ticket on the launch counter; the
+// launch's last arriver adds the group partials in group order, builds the scalar
+// pack and (unsharded x) runs the decide step.  Wave 0 does the publish/ticket
+// BEFORE it stores its own x+ tile: `s_waitcnt vmcnt(0)` waits for every earlier
+// store of the wave in issue order, and the 8-byte publishes complete in ~1 us
+// while HBM stores take several.  Hand-off protocol: guide section 6
+// Guideline 16 (R1, counter form) / MI355X_MICROARCH "Valid forms": sc1 stores,
+// the storing wave drains vmcnt, one relaxed agent-scope add per workgroup, the
+// reducer takes one agent-scope acquire and reads with sc1 loads.  Sums are
+// added in workgroup / group index order, never arrival order: deterministic.
+// Alternatives measured and rejected (tools/tune_trial.hip, n = 1e8 / 1e7):
+// separate one-workgroup finalize kernel +21 us +2 launch gaps; reducer
+// workgroups appended to the grid that poll the counters: same at 1e8, +10 us
+// at 1e7 (they are dispatched last and start late); persistent tile walk:
+// device-dependent, up to 9 % slower than one workgroup per tile.
+// ---------------------------------------------------------------------------
+constexpr int ZF_TILE_U = 4;
+constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per workgroup
+constexpr int ZF_GROUP = 64;                          // workgroups per reduction group
+
+typedef double zf_d2 __attribute__((ext_vector_type(2)));
+
+template <bool NT> __device__ __forceinline__ zf_d2 zf_ld2(const zf_d2* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ void zf_st2(zf_d2* p, zf_d2 v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+__device__ __forceinline__ void zf_publish(double* p, double v) {   // 8-byte write-through store
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double zf_consume(const double* p) {     // sc1 load, bypasses this CU's L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct zf_reduce_ws {
+    double* blk_part;     // ZF_NPART x nblocks, quantity-major
+    double* grp_part;     // ZF_NPART x ngroups
+    unsigned* grp_cnt;    // ngroups arrival counters (zero between launches)
+    unsigned* top_cnt;    // 1
+    double* totals;       // ZF_NPART launch totals (raw sums / max)
+};
+
+struct zf_tail_args {
+    double scale[ZF_NPART];   // pack[k] = scale[k] * total[k]
+    double* pack;             // local pack out (ZF_PACK_LEN), may be NULL
+    zf_control* ctl_rw;       // decide in-launch when non-NULL (unsharded separable problem)
+    double* trace;
+};
+
 struct zf_step_args {
     const zf_control* ctl;
     const double* beta_ring;  // ZF_RING momentum factors, indexed by accepted count
@@ -71,15 +139,110 @@ struct zf_step_args {
     const double* p1;         // diag: c        vec: unused
     double lam, lo, hi;
     int64_t n;
-    double* partials;         // ZF_NPART x gridDim.x, quantity-major
+    zf_reduce_ws ws;
+    zf_tail_args tail;
 };
+
+// Elect-and-reduce tail, part 1 (wave 0 only; `mine` = this workgroup's total of
+// quantity threadIdx.x, threads < ZF_NPART): publish, drain, ticket.  Sets *s_flag
+// (LDS) to 1 in the workgroup whose ticket is the group's last.  Must run BEFORE
+// the wave issues its x+ stores.
+__device__ __forceinline__ void zf_publish_and_ticket(const zf_reduce_ws& W, double mine, int* s_flag) {
+    const int nblocks = gridDim.x;
+    const int b = blockIdx.x;
+    const int g = b / ZF_GROUP;
+    const int g0 = g * ZF_GROUP;
+    const int gsize = (nblocks - g0 < ZF_GROUP) ? (nblocks - g0) : ZF_GROUP;
+    if (threadIdx.x < ZF_NPART) zf_publish(W.blk_part + (int64_t)threadIdx.x * nblocks + b, mine);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(W.grp_cnt + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned)(gsize - 1));
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_flag = last;
+    }
+}
+
+// part 2 (whole workgroup, after a barrier that follows part 1; only the group's
+// last workgroup calls it).  Returns true in every thread of the launch's last
+// workgroup, with totals[] (LDS) filled.
+__device__ __forceinline__ bool zf_group_and_launch_reduce(const zf_reduce_ws& W, double* lds /* >= 40 */,
+                                                           double* totals /* LDS, 8 */, int* s_flag) {
+    const int nblocks = gridDim.x;
+    const int g = blockIdx.x / ZF_GROUP;
+    const int ngroups = (nblocks + ZF_GROUP - 1) / ZF_GROUP;
+    const int g0 = g * ZF_GROUP;
+    const int gsize = (nblocks - g0 < ZF_GROUP) ? (nblocks - g0) : ZF_GROUP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // group reducer: lane l holds workgroup g0+l; fixed shuffle tree = index order.
+    // wave w reduces quantities w and w+4 (both loads in flight before the first use)
+    {
+        const int k0 = wave, k1 = wave + ZF_WAVES;
+        double v0 = 0.0, v1 = 0.0;
+        if (lane < gsize) {
+            v0 = zf_consume(W.blk_part + (int64_t)k0 * nblocks + g0 + lane);
+            if (k1 < ZF_NPART) v1 = zf_consume(W.blk_part + (int64_t)k1 * nblocks + g0 + lane);
+        }
+        v0 = zf_wave_sum(v0);                                            // k0 < 4: always a sum
+        v1 = (k1 == ZF_NPART - 1) ? zf_wave_max(v1) : zf_wave_sum(v1);
+        if (lane == 0) {
+            zf_publish(W.grp_part + (int64_t)k0 * ngroups + g, v0);
+            if (k1 < ZF_NPART) zf_publish(W.grp_part + (int64_t)k1 * ngroups + g, v1);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(W.grp_cnt + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        const unsigned t = __hip_atomic_fetch_add(W.top_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned)(ngroups - 1));
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return false;
+    // last workgroup of the launch: add the group partials in group order; the six
+    // loads of one group index are independent and issued together
+    double v[ZF_NPART];
+#pragma unroll
+    for (int k = 0; k < ZF_NPART; ++k) v[k] = 0.0;
+    for (int q = threadIdx.x; q < ngroups; q += ZF_BLOCK) {
+        double p[ZF_NPART];
+#pragma unroll
+        for (int k = 0; k < ZF_NPART; ++k) p[k] = zf_consume(W.grp_part + (int64_t)k * ngroups + q);
+#pragma unroll
+        for (int k = 0; k < ZF_NPART - 1; ++k) v[k] += p[k];
+        v[ZF_NPART - 1] = fmax(v[ZF_NPART - 1], p[ZF_NPART - 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < ZF_NPART; ++k) {
+        const double r = (k == ZF_NPART - 1) ? zf_wave_max(v[k]) : zf_wave_sum(v[k]);
+        if (lane == 0) lds[wave * 8 + k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < ZF_NPART) {
+        const int k = threadIdx.x;
+        double r = lds[k];
+        for (int w = 1; w < ZF_WAVES; ++w) r = (k == ZF_NPART - 1) ? fmax(r, lds[w * 8 + k]) : r + lds[w * 8 + k];
+        totals[k] = r;
+        W.totals[k] = r;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(W.top_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return true;
+}
 
 // GRAD_INLINE: true  -> separable quadratic, gradient computed from d, c
 //              false -> gradient vector read from HBM (least squares)
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX>
+// NT: nontemporal policy for the once-touched streams (p0, p1 loads, x+ stores)
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
-    __shared__ double lds[ZF_WAVES * ZF_NPART];
-    // wave-uniform control reads (scalar loads); written by the previous decide kernel
+    __shared__ double lds[ZF_WAVES * 8 + 8];
+    __shared__ double totals[8];
+    __shared__ int s_flag;
+    // wave-uniform control reads (scalar loads); written by the previous launch's decide step
     const int status = A.ctl->status;
     if (status != ZF_RUNNING) return;
     const int cur = A.ctl->cur;
@@ -94,58 +257,61 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     const int64_t n = A.n;
 
     zf_elem_acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const int64_t n2 = n >> 1;  // double2 units
-    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
-    const double2* __restrict__ xk2 = reinterpret_cast<const double2*>(xk);
-    const double2* __restrict__ xo2 = reinterpret_cast<const double2*>(xo);
-    const double2* __restrict__ p02 = reinterpret_cast<const double2*>(p0);
-    const double2* __restrict__ p12 = reinterpret_cast<const double2*>(p1);
-    double2* __restrict__ xn2 = reinterpret_cast<double2*>(xn);
+    const int64_t n2 = n >> 1;  // 16-byte units
+    const zf_d2* __restrict__ xk2 = reinterpret_cast<const zf_d2*>(xk);
+    const zf_d2* __restrict__ xo2 = reinterpret_cast<const zf_d2*>(xo);
+    const zf_d2* __restrict__ p02 = reinterpret_cast<const zf_d2*>(p0);
+    const zf_d2* __restrict__ p12 = reinterpret_cast<const zf_d2*>(p1);
+    zf_d2* __restrict__ xn2 = reinterpret_cast<zf_d2*>(xn);
 
-    int64_t i = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x;
-    // two 16-byte units per thread per trip: 8 independent 16-B loads in flight
-    for (; i + stride < n2; i += 2 * stride) {
-        const int64_t j = i + stride;
-        double2 a0 = xk2[i], a1 = xk2[j];
-        double2 o0 = a0, o1 = a1;
-        if (NESTEROV) { o0 = xo2[i]; o1 = xo2[j]; }
-        double2 q0 = p02[i], q1 = p02[j];
-        double2 c0 = q0, c1 = q1;
-        if (GRAD_INLINE) { c0 = p12[i]; c1 = p12[j]; }
-        double2 r0, r1;
-        if (GRAD_INLINE) {
-            r0.x = zf_elem_diag<NESTEROV, BOX>(a0.x, o0.x, q0.x, c0.x, beta, lr, tau, A.lo, A.hi, acc);
-            r0.y = zf_elem_diag<NESTEROV, BOX>(a0.y, o0.y, q0.y, c0.y, beta, lr, tau, A.lo, A.hi, acc);
-            r1.x = zf_elem_diag<NESTEROV, BOX>(a1.x, o1.x, q1.x, c1.x, beta, lr, tau, A.lo, A.hi, acc);
-            r1.y = zf_elem_diag<NESTEROV, BOX>(a1.y, o1.y, q1.y, c1.y, beta, lr, tau, A.lo, A.hi, acc);
-        } else {
-            r0.x = zf_elem_vec<NESTEROV, BOX>(a0.x, o0.x, q0.x, beta, lr, tau, A.lo, A.hi, acc);
-            r0.y = zf_elem_vec<NESTEROV, BOX>(a0.y, o0.y, q0.y, beta, lr, tau, A.lo, A.hi, acc);
-            r1.x = zf_elem_vec<NESTEROV, BOX>(a1.x, o1.x, q1.x, beta, lr, tau, A.lo, A.hi, acc);
-            r1.y = zf_elem_vec<NESTEROV, BOX>(a1.y, o1.y, q1.y, beta, lr, tau, A.lo, A.hi, acc);
+    const int64_t base = (int64_t)blockIdx.x * ZF_TILE_UNITS + threadIdx.x;
+    const bool full_tile = base - threadIdx.x + ZF_TILE_UNITS <= n2;   // workgroup-uniform
+    zf_d2 r[ZF_TILE_U];
+    if (full_tile) {
+        zf_d2 a[ZF_TILE_U], o[ZF_TILE_U], q[ZF_TILE_U], cc[ZF_TILE_U];
+#pragma unroll
+        for (int u = 0; u < ZF_TILE_U; ++u) {
+            const int64_t i = base + u * ZF_BLOCK;
+            a[u] = xk2[i];
+            o[u] = a[u];
+            if (NESTEROV) o[u] = xo2[i];
+            q[u] = zf_ld2<NT>(p02 + i);
+            cc[u] = q[u];
+            if (GRAD_INLINE) cc[u] = zf_ld2<NT>(p12 + i);
         }
-        xn2[i] = r0;
-        xn2[j] = r1;
-    }
-    for (; i < n2; i += stride) {
-        double2 a0 = xk2[i];
-        double2 o0 = a0;
-        if (NESTEROV) o0 = xo2[i];
-        double2 q0 = p02[i];
-        double2 c0 = q0;
-        if (GRAD_INLINE) c0 = p12[i];
-        double2 r0;
-        if (GRAD_INLINE) {
-            r0.x = zf_elem_diag<NESTEROV, BOX>(a0.x, o0.x, q0.x, c0.x, beta, lr, tau, A.lo, A.hi, acc);
-            r0.y = zf_elem_diag<NESTEROV, BOX>(a0.y, o0.y, q0.y, c0.y, beta, lr, tau, A.lo, A.hi, acc);
-        } else {
-            r0.x = zf_elem_vec<NESTEROV, BOX>(a0.x, o0.x, q0.x, beta, lr, tau, A.lo, A.hi, acc);
-            r0.y = zf_elem_vec<NESTEROV, BOX>(a0.y, o0.y, q0.y, beta, lr, tau, A.lo, A.hi, acc);
+#pragma unroll
+        for (int u = 0; u < ZF_TILE_U; ++u) {
+            if (GRAD_INLINE) {
+                r[u].x = zf_elem_diag<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, cc[u].x, beta, lr, tau, A.lo, A.hi, acc);
+                r[u].y = zf_elem_diag<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, cc[u].y, beta, lr, tau, A.lo, A.hi, acc);
+            } else {
+                r[u].x = zf_elem_vec<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, beta, lr, tau, A.lo, A.hi, acc);
+                r[u].y = zf_elem_vec<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, beta, lr, tau, A.lo, A.hi, acc);
+            }
         }
-        xn2[i] = r0;
+    } else {
+        // ragged last tile: stored at once (at most one workgroup per launch)
+        for (int u = 0; u < ZF_TILE_U; ++u) {
+            const int64_t i = base + u * ZF_BLOCK;
+            if (i < n2) {
+                const zf_d2 a0 = xk2[i];
+                const zf_d2 o0 = NESTEROV ? xo2[i] : a0;
+                const zf_d2 q0 = p02[i];
+                const zf_d2 c0 = GRAD_INLINE ? p12[i] : q0;
+                zf_d2 r0;
+                if (GRAD_INLINE) {
+                    r0.x = zf_elem_diag<NESTEROV, BOX>(a0.x, o0.x, q0.x, c0.x, beta, lr, tau, A.lo, A.hi, acc);
+                    r0.y = zf_elem_diag<NESTEROV, BOX>(a0.y, o0.y, q0.y, c0.y, beta, lr, tau, A.lo, A.hi, acc);
+                } else {
+                    r0.x = zf_elem_vec<NESTEROV, BOX>(a0.x, o0.x, q0.x, beta, lr, tau, A.lo, A.hi, acc);
+                    r0.y = zf_elem_vec<NESTEROV, BOX>(a0.y, o0.y, q0.y, beta, lr, tau, A.lo, A.hi, acc);
+                }
+                xn2[i] = r0;
+            }
+        }
     }
-    // odd tail element
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    // odd trailing element (n odd): last workgroup
+    if ((n & 1) && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         const int64_t t = n - 1;
         const double xo_t = NESTEROV ? xo[t] : xk[t];
         if (GRAD_INLINE)
@@ -156,9 +322,31 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
 
     const double sums[5] = {acc.fy, acc.dot, acc.ss, acc.l1, acc.fx};
     const double maxs[1] = {acc.mx};
-    double out = 0.0;
-    zf_block_reduce<5, 1, ZF_WAVES>(sums, maxs, lds, out);
-    if (threadIdx.x < ZF_NPART) A.partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+    double mine = 0.0;
+    zf_block_reduce<5, 1, ZF_WAVES>(sums, maxs, lds, mine);
+    // wave 0 publishes the partials and takes the ticket while its x+ tile is still in
+    // registers; waves 1-3 stream their x+ out meanwhile
+    if (threadIdx.x < 64) zf_publish_and_ticket(A.ws, mine, &s_flag);
+    if (full_tile) {
+#pragma unroll
+        for (int u = 0; u < ZF_TILE_U; ++u) zf_st2<NT>(xn2 + base + u * ZF_BLOCK, r[u]);
+    }
+    __syncthreads();
+    if (!s_flag) return;
+    if (!zf_group_and_launch_reduce(A.ws, lds, totals, &s_flag)) return;
+    // last workgroup of the launch
+    if (threadIdx.x == 0 && A.tail.pack) {
+        double* pack = A.tail.pack;
+        pack[ZF_PK_FY] = A.tail.scale[0] * totals[0];
+        pack[ZF_PK_DOT] = totals[1];
+        pack[ZF_PK_SS] = totals[2];
+        pack[ZF_PK_GX] = A.tail.scale[3] * totals[3];
+        pack[ZF_PK_FX] = A.tail.scale[4] * totals[4];
+        pack[ZF_PK_ERR] = totals[5];
+        pack[6] = 0.0;
+        pack[7] = 0.0;
+        if (A.tail.ctl_rw) zf_decide_step(A.tail.ctl_rw, pack, A.tail.trace);
+    }
 }
 
 // --- f(x), g(x) at a point (initial F(x0), proximal_gradient.py:466,472) -------

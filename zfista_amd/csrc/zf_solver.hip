@@ -19,50 +19,21 @@ thread_local char zf_errbuf[512] = "";
 // ---------------------------------------------------------------------------
 // finalize / decide kernels
 // ---------------------------------------------------------------------------
-struct zf_fin_args {
-    const double* partials;
-    int nblocks;
-    double scale[ZF_NPART];   // pack[k] = scale[k] * total[k]
-    const double* f_y_ext;    // least squares: f(y), f(x+) computed by the GEMV side
-    const double* f_x_ext;
-    double* pack;             // local pack out (ZF_PACK_LEN)
-};
-
-__device__ __forceinline__ void zf_make_pack(const zf_fin_args& F, const double* totals, double* pack) {
-    // thread 0 only
-    pack[ZF_PK_FY] = F.f_y_ext ? *F.f_y_ext : F.scale[0] * totals[0];
+// least squares: the trial kernel leaves the raw totals; f(y), f(x+) come from the
+// GEMV side.  One thread builds the pack and (unsharded) runs the decide step.
+__global__ void zf_ls_pack_kernel(zf_control* ctl, const double* totals, const double* ls_scal, double lam,
+                                  double* pack, double* trace, int decide) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (ctl->status != ZF_RUNNING) return;
+    pack[ZF_PK_FY] = ls_scal[0];
     pack[ZF_PK_DOT] = totals[1];
     pack[ZF_PK_SS] = totals[2];
-    pack[ZF_PK_GX] = F.scale[3] * totals[3];
-    pack[ZF_PK_FX] = F.f_x_ext ? *F.f_x_ext : F.scale[4] * totals[4];
+    pack[ZF_PK_GX] = lam * totals[3];
+    pack[ZF_PK_FX] = ls_scal[1];
     pack[ZF_PK_ERR] = totals[5];
     pack[6] = 0.0;
     pack[7] = 0.0;
-}
-
-// world == 1: finalize + decide in one launch
-__global__ __launch_bounds__(ZF_FIN_BLOCK) void zf_finalize_decide_kernel(zf_fin_args F, zf_control* ctl,
-                                                                          double* trace) {
-    __shared__ double lds[(ZF_FIN_BLOCK / 64) * 8];
-    __shared__ double totals[8];
-    if (ctl->status != ZF_RUNNING) return;
-    zf_finalize_partials(F.partials, F.nblocks, ZF_NPART, 5, lds, totals);
-    if (threadIdx.x == 0) {
-        zf_make_pack(F, totals, F.pack);
-        zf_decide_step(ctl, F.pack, trace);
-    }
-}
-
-// world > 1: finalize only (-> local pack), the decide kernel runs after the gather
-__global__ __launch_bounds__(ZF_FIN_BLOCK) void zf_finalize_kernel(zf_fin_args F, const zf_control* ctl) {
-    __shared__ double lds[(ZF_FIN_BLOCK / 64) * 8];
-    __shared__ double totals[8];
-    if (ctl->status != ZF_RUNNING) {
-        if (threadIdx.x < ZF_PACK_LEN) F.pack[threadIdx.x] = 0.0;
-        return;
-    }
-    zf_finalize_partials(F.partials, F.nblocks, ZF_NPART, 5, lds, totals);
-    if (threadIdx.x == 0) zf_make_pack(F, totals, F.pack);
+    if (decide) zf_decide_step(ctl, pack, trace);
 }
 
 __global__ void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace) {
@@ -117,7 +88,10 @@ struct zf_solver {
     // device memory owned by the solver
     double* xbuf = nullptr;   // 3 * n_pad
     double* xb[3] = {nullptr, nullptr, nullptr};
-    double* partials = nullptr;
+    double* partials = nullptr;   // init-time evaluation partials
+    zf_reduce_ws ws = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned* counters = nullptr; // ngroups + 1 arrival counters
+    bool nt = true;               // nontemporal policy for once-touched streams
     zf_control* ctl = nullptr;
     double* trace = nullptr;      // ZF_RING * ZF_TRACE_COLS
     double* beta_ring = nullptr;  // ZF_RING
@@ -143,7 +117,7 @@ struct zf_solver {
 };
 
 static int zf_solver_free_all(zf_solver* s) {
-    void* ptrs[] = {s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
+    void* ptrs[] = {s->ws.blk_part, s->ws.grp_part, s->counters, s->ws.totals, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal};
     for (void* p : ptrs)
@@ -184,7 +158,17 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     s->box = !(desc->box_lo == -INFINITY && desc->box_hi == INFINITY);
     const int64_t n = desc->n;
     const int64_t n_pad = (n + 63) & ~int64_t(63);   // keep every ring buffer 512-B aligned
-    s->grid = zf_grid_for((n / 2 + 1) / 2 + 1);      // two 16-B units per thread per trip
+    {   // one workgroup per tile of ZF_TILE_UNITS 16-byte units (zf_kernels_step.h)
+        int64_t nb = (n / 2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
+        if (nb < 1) nb = 1;
+        if (nb > 0x7fffffff) {
+            delete s;
+            return zf_fail(ZF_ERR_ARG, "zf_solver_create: n too large for one rank");
+        }
+        s->grid = (int)nb;
+    }
+    const char* nt_env = getenv("ZF_NT");
+    if (nt_env) s->nt = atoi(nt_env) != 0;
 #define ZF_TRY(expr)                                                                    \
     do {                                                                                \
         hipError_t _e = (expr);                                                         \
@@ -197,6 +181,16 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * 3 * n_pad));
     for (int k = 0; k < 3; ++k) s->xb[k] = s->xbuf + k * n_pad;
     ZF_TRY(hipMalloc(&s->partials, sizeof(double) * ZF_NPART * ZF_MAX_GRID));
+    {
+        const int ngroups = (s->grid + ZF_GROUP - 1) / ZF_GROUP;
+        ZF_TRY(hipMalloc(&s->ws.blk_part, sizeof(double) * ZF_NPART * s->grid));
+        ZF_TRY(hipMalloc(&s->ws.grp_part, sizeof(double) * ZF_NPART * ngroups));
+        ZF_TRY(hipMalloc(&s->counters, sizeof(unsigned) * (ngroups + 16)));
+        ZF_TRY(hipMalloc(&s->ws.totals, sizeof(double) * 8));
+        ZF_TRY(hipMemsetAsync(s->counters, 0, sizeof(unsigned) * (ngroups + 16), s->stream));
+        s->ws.grp_cnt = s->counters;
+        s->ws.top_cnt = s->counters + ngroups;
+    }
     ZF_TRY(hipMalloc(&s->ctl, sizeof(zf_control)));
     ZF_TRY(hipMalloc(&s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS));
     ZF_TRY(hipMalloc(&s->beta_ring, sizeof(double) * ZF_RING));
@@ -238,17 +232,22 @@ extern "C" int zf_solver_destroy(zf_solver* s) {
 }
 
 // ---- launches ---------------------------------------------------------------
-template <bool GI>
-static void zf_launch_trial_t(zf_solver* s, const zf_step_args& a) {
+template <bool GI, bool NT>
+static void zf_launch_trial_t2(zf_solver* s, const zf_step_args& a) {
     const bool nest = s->opt.nesterov != 0;
     dim3 g(s->grid), b(ZF_BLOCK);
-    if (nest && s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, true, true>), g, b, 0, s->stream, a);
-    else if (nest) hipLaunchKernelGGL((zf_trial_kernel<GI, true, false>), g, b, 0, s->stream, a);
-    else if (s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, false, true>), g, b, 0, s->stream, a);
-    else hipLaunchKernelGGL((zf_trial_kernel<GI, false, false>), g, b, 0, s->stream, a);
+    if (nest && s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, true, true, NT>), g, b, 0, s->stream, a);
+    else if (nest) hipLaunchKernelGGL((zf_trial_kernel<GI, true, false, NT>), g, b, 0, s->stream, a);
+    else if (s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, false, true, NT>), g, b, 0, s->stream, a);
+    else hipLaunchKernelGGL((zf_trial_kernel<GI, false, false, NT>), g, b, 0, s->stream, a);
+}
+template <bool GI>
+static void zf_launch_trial_t(zf_solver* s, const zf_step_args& a) {
+    if (s->nt) zf_launch_trial_t2<GI, true>(s, a);
+    else zf_launch_trial_t2<GI, false>(s, a);
 }
 
-static int zf_launch_trial(zf_solver* s) {
+static int zf_launch_trial(zf_solver* s, bool decide_in_launch) {
     const zf_problem_desc& d = s->desc;
     zf_step_args a;
     a.ctl = s->ctl;
@@ -258,7 +257,18 @@ static int zf_launch_trial(zf_solver* s) {
     a.lo = d.box_lo;
     a.hi = d.box_hi;
     a.n = d.n;
-    a.partials = s->partials;
+    a.ws = s->ws;
+    for (int k = 0; k < ZF_NPART; ++k) a.tail.scale[k] = 1.0;
+    a.tail.scale[3] = d.lam;        // g = lam * sum|x|
+    a.tail.pack = nullptr;
+    a.tail.ctl_rw = nullptr;
+    a.tail.trace = s->trace;
+    if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
+        a.tail.scale[0] = 0.5;      // f = 0.5 * sum(d (x-c)^2)
+        a.tail.scale[4] = 0.5;
+        a.tail.pack = s->pack_local;
+        if (d.world == 1 && decide_in_launch) a.tail.ctl_rw = s->ctl;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing) {
         if (s->ev_used == s->ev_pool.size()) {
@@ -314,28 +324,11 @@ static int zf_launch_trial(zf_solver* s) {
                                xr, s->sring, 1, m, n);
         hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1,
                            d.b, d.scale, m, s->ls_scal + 1);
+        hipLaunchKernelGGL(zf_ls_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->ws.totals, s->ls_scal,
+                           d.lam, s->pack_local, s->trace, (int)(d.world == 1 && decide_in_launch));
     }
     ZF_HIP(hipGetLastError());
     return ZF_OK;
-}
-
-static zf_fin_args zf_make_fin(zf_solver* s) {
-    zf_fin_args F;
-    F.partials = s->partials;
-    F.nblocks = s->grid;
-    for (int k = 0; k < ZF_NPART; ++k) F.scale[k] = 1.0;
-    F.scale[3] = s->desc.lam;   // g = lam * sum|x|
-    F.f_y_ext = nullptr;
-    F.f_x_ext = nullptr;
-    if (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
-        F.scale[0] = 0.5;       // f = 0.5 * sum(d (x-c)^2)
-        F.scale[4] = 0.5;
-    } else {
-        F.f_y_ext = s->ls_scal + 0;
-        F.f_x_ext = s->ls_scal + 1;
-    }
-    F.pack = s->pack_local;
-    return F;
 }
 
 extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
@@ -441,12 +434,7 @@ extern "C" int zf_solver_set_beta(zf_solver* s, int64_t first, const double* bet
 
 extern "C" int zf_solver_enqueue_trial(zf_solver* s) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_trial: solver not initialised");
-    int rc = zf_launch_trial(s);
-    if (rc) return rc;
-    zf_fin_args F = zf_make_fin(s);
-    hipLaunchKernelGGL(zf_finalize_kernel, dim3(1), dim3(ZF_FIN_BLOCK), 0, s->stream, F, s->ctl);
-    ZF_HIP(hipGetLastError());
-    return ZF_OK;
+    return zf_launch_trial(s, false);
 }
 
 extern "C" int zf_solver_enqueue_decide(zf_solver* s) {
@@ -460,14 +448,10 @@ extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_steps: solver not initialised");
     ZF_REQUIRE(s->desc.world == 1, "zf_solver_enqueue_steps: world > 1 needs trial/gather/decide");
     ZF_REQUIRE(steps >= 0 && steps <= ZF_RING, "zf_solver_enqueue_steps: steps must be in [0, ZF_RING]");
-    zf_fin_args F = zf_make_fin(s);
     for (int64_t k = 0; k < steps; ++k) {
-        int rc = zf_launch_trial(s);
+        int rc = zf_launch_trial(s, true);
         if (rc) return rc;
-        hipLaunchKernelGGL(zf_finalize_decide_kernel, dim3(1), dim3(ZF_FIN_BLOCK), 0, s->stream, F, s->ctl,
-                           s->trace);
     }
-    ZF_HIP(hipGetLastError());
     return ZF_OK;
 }
 
