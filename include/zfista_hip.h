@@ -198,6 +198,35 @@ int zf_host_diag_grad(double* out_host, const double* x_host, const double* d_de
 int zf_ls_eval(const double* A_dev, const double* b_dev, int64_t m_rows, int64_t n, double scale,
                const double* x_host, double* f_out, double* grad_out_host);
 
+/* ---- multi-objective trial (m >= 2), device side ---------------------------
+ * The dual of the scalarised subproblem is minimised on the host by SciPy exactly
+ * as the reference does (proximal_gradient.py:179-205); every O(n) expression runs
+ * on the GPU with x_k, x_{k-1}, y, x+ and J (m x n) resident in HBM.  g / prox are
+ * the shifted-l1 + box family of zfista/problems.py:101-138. */
+#define ZF_MO_GENERIC 0 /* f, jac_f are host callbacks; J is uploaded per trial     */
+#define ZF_MO_JOS1 1    /* zfista/problems.py:193-205  (m = 2)                      */
+#define ZF_MO_FDS 2     /* zfista/problems.py:309-328  (m = 3)                      */
+typedef struct zf_mo zf_mo;
+int zf_mo_create(zf_mo** out, int32_t kind, int32_t m, int64_t n, const double* l1_ratios_host,
+                 const double* l1_shifts_host, double box_lo, double box_hi, void* stream);
+int zf_mo_destroy(zf_mo* s);
+int zf_mo_set_x0(zf_mo* s, const double* x0_host);              /* :463-465 */
+/* point selector `which`: 0 = x_k, 1 = y, 2 = x+ (trial point), 3 = x_{k-1} */
+int zf_mo_eval_F(zf_mo* s, int32_t which, double* f_out /* m or NULL */, double* g_out /* m */); /* :279,:295 */
+int zf_mo_prepare(zf_mo* s, double* f_y_out /* m */);           /* J = jac_f(y), f(y)   :140,:142 */
+int zf_mo_set_jac(zf_mo* s, const double* J_host);              /* generic kind         :142 */
+/* out[0..m) = g_i(p), out[m] = |p-v|^2, out[m+1] = |w@J|^2, out[m+2..2m+2) = J_i.(p-y)   :162-173 */
+int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double* out);
+int zf_mo_recover(zf_mo* s, double lr, const double* w_host, double* err_out);   /* :206, :510 */
+int zf_mo_commit(zf_mo* s, double beta, int32_t nesterov);      /* :530-538 */
+int zf_mo_get(zf_mo* s, int32_t which, double* host);
+int zf_mo_put(zf_mo* s, int32_t which, const double* host);
+int zf_mo_get_jac(zf_mo* s, double* J_host);
+int zf_mo_prox_host(zf_mo* s, const double* weight_host, const double* x_host, double* out_host); /* problems.py:119-138 */
+/* generic kind, after the user's prox callback produced p (host):
+ * out[0..m) = J_i.(p - y), out[m] = |p - (y - lr w@J)|^2          proximal_gradient.py:168,173 */
+int zf_mo_post_terms(zf_mo* s, double lr, const double* w_host, const double* p_host, double* out);
+
 /* ---- device vector kernels (device pointers) ----------------------------- */
 int zf_eval_diag_l1(const double* x_dev, const double* d_dev, const double* c_dev, double lam,
                     int64_t n, double out2_host[2], void* stream); /* f(x), g(x) */

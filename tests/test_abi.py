@@ -15,7 +15,7 @@ from zfista_amd import _lib
 def _declared():
     src = open(os.path.join(ROOT, "include", "zfista_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(zf_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(zf_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 def test_library_loads_and_exports_every_declared_symbol():

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(CSRC, "libzfista_hip.so")
 ZF_OK = 0
 ZF_RUNNING, ZF_CONVERGED, ZF_MAXITER, ZF_BACKTRACK_FAILED = 0, 1, 2, 3
 ZF_PROBLEM_DIAG_QUAD_L1, ZF_PROBLEM_LEAST_SQUARES_L1 = 1, 2
+ZF_MO_GENERIC, ZF_MO_JOS1, ZF_MO_FDS = 0, 1, 2
 ZF_PACK_LEN, ZF_TRACE_COLS, ZF_RING = 8, 8, 1024
 TR_ERR, TR_F, TR_LR, TR_FUN, TR_TRIALS, TR_FX, TR_GX, TR_FY = range(8)
 PK_FY, PK_DOT, PK_SS, PK_GX, PK_FX, PK_ERR = range(6)
@@ -102,6 +103,20 @@ SIGNATURES = {
     "zf_host_prox_l1_box": (C.c_int, [_P, _P, C.c_double, C.c_double, C.c_double, C.c_int64]),
     "zf_host_asum": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_double)]),
     "zf_host_diag_grad": (C.c_int, [_P, _P, _P, _P, C.c_int64]),
+    "zf_mo_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, C.c_int64, _P, _P, C.c_double, C.c_double, _P]),
+    "zf_mo_destroy": (C.c_int, [_P]),
+    "zf_mo_set_x0": (C.c_int, [_P, _P]),
+    "zf_mo_eval_F": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "zf_mo_prepare": (C.c_int, [_P, _P]),
+    "zf_mo_set_jac": (C.c_int, [_P, _P]),
+    "zf_mo_dual_eval": (C.c_int, [_P, C.c_double, _P, _P]),
+    "zf_mo_recover": (C.c_int, [_P, C.c_double, _P, _P]),
+    "zf_mo_commit": (C.c_int, [_P, C.c_double, C.c_int32]),
+    "zf_mo_get": (C.c_int, [_P, C.c_int32, _P]),
+    "zf_mo_put": (C.c_int, [_P, C.c_int32, _P]),
+    "zf_mo_get_jac": (C.c_int, [_P, _P]),
+    "zf_mo_prox_host": (C.c_int, [_P, _P, _P, _P]),
+    "zf_mo_post_terms": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "zf_ls_eval": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_double, _P, C.POINTER(C.c_double), _P]),
 }
 

@@ -1,0 +1,541 @@
+// zf_multiobj.hip - device side of the multi-objective trial (m >= 2 objectives).
+//
+// The dual of the scalarised subproblem is minimised on the host by SciPy, as in
+// the reference (zfista/proximal_gradient.py:179-205); everything O(n) runs here:
+//   prepare   J = jac_f(y), f(y)                       problems.py:193-205 (JOS1), :312-328 (FDS)
+//   dual_eval v = y - lr (w @ J); p = prox(lr w, v);   proximal_gradient.py:162-173
+//             g_i(p), |p - v|^2, |w @ J|^2, J (p - y)  -> 2m+2 scalars, nothing written
+//   recover   x+ = prox(lr w*, y - lr w* @ J), max|x+ - y|       :206, :510
+//   eval_F    f(x), g(x)                               :279, :295   (g: problems.py:101-117)
+//   commit    x_old <- x_k <- x+ ; y = x_k + beta (x_k - x_old)  :534-538
+// g / prox are the shifted-l1 + box family shared by every reference problem
+// (problems.py:101-138), including the quirk that shift 0 is (net) ignored in the
+// prox (:129).  x, y, J stay resident in HBM between calls.
+#include <vector>
+
+#include "zf_common.h"
+
+namespace {
+
+constexpr int MO_MAX_M = 8;
+constexpr int MO_GRID_MAX = 1024;
+
+struct mo_g {             // g / prox descriptor, passed by value
+    int m;
+    int has_l1;
+    int has_box;
+    double ratio[MO_MAX_M];
+    double shift[MO_MAX_M];
+    double lo, hi;
+};
+
+// prox_wsum_g(weight, x), problems.py:126-138; coef = weight * l1_ratios
+__device__ __forceinline__ double mo_prox(const mo_g& G, const double* coef, double tail_sum, double x) {
+    if (G.has_l1) {
+        // stage 0: prox_lasso(x + sum(coef[1:]) - s0 + s0, coef[0])
+        x = zf_soft_threshold(x + tail_sum - G.shift[0] + G.shift[0], coef[0]);
+        for (int i = 1; i < G.m; ++i) x = zf_soft_threshold(x - coef[i] - G.shift[i], coef[i]) + G.shift[i];
+    }
+    if (G.has_box) x = zf_clip(x, G.lo, G.hi);
+    return x;
+}
+
+struct mo_w {
+    double w[MO_MAX_M];      // dual weights
+    double coef[MO_MAX_M];   // (lr * w) * l1_ratios
+    double tail_sum;         // sum(coef[1:])
+    double lr;
+};
+
+// ---- dual evaluation: reads J (m x n), y ; writes nothing --------------------------
+// partials (quantity-major): [0..m) sum|p - s_i|, [m] |p-v|^2, [m+1] |wJ|^2, [m+2 .. 2m+2) J_i.(p-y)
+template <int M>
+__global__ __launch_bounds__(ZF_BLOCK) void k_dual_eval(const double* __restrict__ J, const double* __restrict__ y,
+                                                        mo_g G, mo_w W, int64_t n, double* partials) {
+    constexpr int NQ = 2 * M + 2;
+    __shared__ double lds[ZF_WAVES * NQ];
+    double acc[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) acc[k] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        double Jc[M];
+        double wJ = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            Jc[i] = J[(int64_t)i * n + j];
+            wJ += W.w[i] * Jc[i];                       // weight @ jac_f_yk
+        }
+        const double yj = y[j];
+        const double v = yj - W.lr * wJ;
+        const double p = mo_prox(G, W.coef, W.tail_sum, v);
+#pragma unroll
+        for (int i = 0; i < M; ++i) acc[i] += fabs(p - G.shift[i]);
+        const double dv = p - v;
+        acc[M] += dv * dv;
+        acc[M + 1] += wJ * wJ;
+        const double dy = p - yj;
+#pragma unroll
+        for (int i = 0; i < M; ++i) acc[M + 2 + i] += Jc[i] * dy;
+    }
+    const double maxs[1] = {0.0};
+    double out = 0.0;
+    zf_block_reduce<NQ, 0, ZF_WAVES>(acc, maxs, lds, out);
+    if (threadIdx.x < NQ) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+}
+
+// ---- primal recovery: x+ = prox(lr w, y - lr w@J); partial: [0] max|x+ - y| ------------------
+template <int M>
+__global__ __launch_bounds__(ZF_BLOCK) void k_recover(const double* __restrict__ J, const double* __restrict__ y,
+                                                      double* __restrict__ xn, mo_g G, mo_w W, int64_t n,
+                                                      double* partials) {
+    __shared__ double lds[ZF_WAVES];
+    double mx = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        double wJ = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) wJ += W.w[i] * J[(int64_t)i * n + j];
+        const double yj = y[j];
+        const double p = mo_prox(G, W.coef, W.tail_sum, yj - W.lr * wJ);
+        xn[j] = p;
+        mx = fmax(mx, fabs(p - yj));
+    }
+    const double sums[1] = {0.0};
+    const double maxs[1] = {mx};
+    double out = 0.0;
+    zf_block_reduce<0 + 1, 1, ZF_WAVES>(sums, maxs, lds, out);   // [0] dummy sum, [1] max
+    if (threadIdx.x == 1) partials[blockIdx.x] = out;
+}
+
+// ---- g(x): partials [0..m) sum|x - s_i|, [m] box violations -----------------------------------
+template <int M>
+__global__ __launch_bounds__(ZF_BLOCK) void k_g_terms(const double* __restrict__ x, mo_g G, int64_t n,
+                                                      double* partials) {
+    __shared__ double lds[ZF_WAVES * (M + 1)];
+    double acc[M + 1];
+#pragma unroll
+    for (int k = 0; k <= M; ++k) acc[k] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        const double xv = x[j];
+#pragma unroll
+        for (int i = 0; i < M; ++i) acc[i] += fabs(xv - G.shift[i]);
+        if (G.has_box) acc[M] += (xv < G.lo || xv > G.hi) ? 1.0 : 0.0;
+    }
+    const double maxs[1] = {0.0};
+    double out = 0.0;
+    zf_block_reduce<M + 1, 0, ZF_WAVES>(acc, maxs, lds, out);
+    if (threadIdx.x <= M) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+}
+
+// ---- JOS1 (problems.py:193-205): sums [0] x^2, [1] (x-2)^2 ; J rows 2x/n, 2(x-2)/n -----------------
+__global__ __launch_bounds__(ZF_BLOCK) void k_jos1_sums(const double* __restrict__ x, int64_t n, double* partials) {
+    __shared__ double lds[ZF_WAVES * 2];
+    double acc[2] = {0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        const double xv = x[j], t = xv - 2;
+        acc[0] += xv * xv;
+        acc[1] += t * t;
+    }
+    const double maxs[1] = {0.0};
+    double out = 0.0;
+    zf_block_reduce<2, 0, ZF_WAVES>(acc, maxs, lds, out);
+    if (threadIdx.x < 2) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+}
+__global__ __launch_bounds__(ZF_BLOCK) void k_jos1_jac(const double* __restrict__ x, double* __restrict__ J, int64_t n) {
+    const double dn = (double)n;
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        const double xv = x[j];
+        J[j] = 2 * xv / dn;               // 2 * x / n
+        J[n + j] = 2 * (xv - 2) / dn;     // 2 * (x - 2) / n
+    }
+}
+
+// ---- FDS (problems.py:309-328): sums [0] i (x-i)^4, [1] x, [2] x^2, [3] i(n-i+1) e^{-x} -------------
+__global__ __launch_bounds__(ZF_BLOCK) void k_fds_sums(const double* __restrict__ x, int64_t n, double* partials) {
+    __shared__ double lds[ZF_WAVES * 4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        const double xv = x[j];
+        const double idx = (double)(j + 1);
+        const double conv = (double)((j + 1) * (n - j));   // one_to_n * one_to_n[::-1]
+        const double t = xv - idx, t2 = t * t;
+        acc[0] += idx * (t2 * t2);
+        acc[1] += xv;
+        acc[2] += xv * xv;
+        acc[3] += conv * exp(-xv);
+    }
+    const double maxs[1] = {0.0};
+    double out = 0.0;
+    zf_block_reduce<4, 0, ZF_WAVES>(acc, maxs, lds, out);
+    if (threadIdx.x < 4) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+}
+// e_mean = exp(sum(x)/n) read from totals[1] (device), so no host round trip between the two passes
+__global__ __launch_bounds__(ZF_BLOCK) void k_fds_jac(const double* __restrict__ x, double* __restrict__ J, int64_t n,
+                                                      const double* __restrict__ totals) {
+    const double dn = (double)n;
+    const double e_mean = exp(totals[1] / dn);
+    const double c1 = 4 / (dn * dn);            // 4 / n**2
+    const double den = dn * (dn + 1);           // n (n + 1)
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        const double xv = x[j];
+        const double idx = (double)(j + 1);
+        const double conv = (double)((j + 1) * (n - j));
+        const double t = xv - idx;
+        J[j] = c1 * idx * (t * t * t);                  // 4 / n**2 * idx * (x - idx)**3
+        J[n + j] = e_mean / dn + 2 * xv;                // exp(sum/n)/n + 2 x
+        J[2 * n + j] = -conv * exp(-xv) / den;          // -conv * exp(-x) / (n (n + 1))
+    }
+}
+
+__global__ __launch_bounds__(ZF_BLOCK) void k_prox_only(double* x, mo_g G, mo_w W, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride)
+        x[j] = mo_prox(G, W.coef, W.tail_sum, x[j]);
+}
+
+__global__ __launch_bounds__(ZF_BLOCK) void k_commit(double* __restrict__ y, const double* __restrict__ xk,
+                                                     const double* __restrict__ xo, double beta, int nesterov,
+                                                     int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride)
+        y[j] = nesterov ? xk[j] + beta * (xk[j] - xo[j]) : xk[j];
+}
+
+// one-block fixed-order reduce of `nq` quantities; quantity `max_index` (or -1) is a max
+__global__ __launch_bounds__(256) void k_mo_reduce(const double* __restrict__ partials, int nblocks, int nq,
+                                                   int max_index, double* out) {
+    __shared__ double lds[4 * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < nq; ++k) {
+        const bool is_max = (k == max_index);
+        double v = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) {
+            const double p = partials[(int64_t)k * nblocks + b];
+            v = is_max ? fmax(v, p) : v + p;
+        }
+        v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
+        if (lane == 0) lds[wave * 32 + k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nq) {
+        const int k = threadIdx.x;
+        double v = lds[k];
+        for (int w = 1; w < 4; ++w) v = (k == max_index) ? fmax(v, lds[w * 32 + k]) : v + lds[w * 32 + k];
+        out[k] = v;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+struct zf_mo {
+    int kind, m;
+    int64_t n;
+    mo_g G;
+    hipStream_t stream;
+    double* buf = nullptr;     // 3 x-buffers + y + J
+    double* xb[3] = {nullptr, nullptr, nullptr};
+    int cur = 0;               // xb[cur] = x_k, xb[(cur+2)%3] = x_{k-1}, xb[(cur+1)%3] = x+
+    double* y = nullptr;
+    double* J = nullptr;
+    double* partials = nullptr;
+    double* totals = nullptr;  // device, 32
+    int grid = 1;
+    double f_y[MO_MAX_M];
+};
+
+static int mo_reduce_to_host(zf_mo* s, int nq, int max_index, double* host) {
+    hipLaunchKernelGGL(k_mo_reduce, dim3(1), dim3(256), 0, s->stream, s->partials, s->grid, nq, max_index, s->totals);
+    ZF_HIP(hipGetLastError());
+    ZF_HIP(hipMemcpyAsync(host, s->totals, sizeof(double) * nq, hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return ZF_OK;
+}
+
+static double* mo_which(zf_mo* s, int which) {
+    switch (which) {
+        case 0: return s->xb[s->cur];
+        case 1: return s->y;
+        case 2: return s->xb[(s->cur + 1) % 3];
+        case 3: return s->xb[(s->cur + 2) % 3];
+        default: return nullptr;
+    }
+}
+
+static void mo_fill_w(const zf_mo* s, double lr, const double* w, mo_w* W) {
+    W->lr = lr;
+    W->tail_sum = 0.0;
+    for (int i = 0; i < MO_MAX_M; ++i) {
+        W->w[i] = i < s->m ? w[i] : 0.0;
+        // coef = weight * l1_ratios with weight = lr * w   (proximal_gradient.py:164, problems.py:127)
+        W->coef[i] = (i < s->m && s->G.has_l1) ? (lr * w[i]) * s->G.ratio[i] : 0.0;
+    }
+    for (int i = 1; i < s->m; ++i) W->tail_sum += W->coef[i];   // np.sum(coef[1:])
+}
+
+extern "C" int zf_mo_create(zf_mo** out, int32_t kind, int32_t m, int64_t n, const double* l1_ratios,
+                            const double* l1_shifts, double box_lo, double box_hi, void* stream) {
+    ZF_REQUIRE(out && n >= 1, "zf_mo_create: bad argument");
+    ZF_REQUIRE(m >= 2 && m <= 4, "zf_mo_create: 2 <= n_objectives <= 4 supported");
+    ZF_REQUIRE(kind == ZF_MO_GENERIC || (kind == ZF_MO_JOS1 && m == 2) || (kind == ZF_MO_FDS && m == 3),
+               "zf_mo_create: kind / n_objectives mismatch");
+    zf_mo* s = new (std::nothrow) zf_mo();
+    if (!s) return zf_fail(ZF_ERR_ARG, "zf_mo_create: out of host memory");
+    s->kind = kind;
+    s->m = m;
+    s->n = n;
+    s->stream = (hipStream_t)stream;
+    memset(&s->G, 0, sizeof(s->G));
+    s->G.m = m;
+    s->G.has_l1 = l1_ratios != nullptr;
+    for (int i = 0; i < m; ++i) {
+        s->G.ratio[i] = l1_ratios ? l1_ratios[i] : 0.0;
+        s->G.shift[i] = l1_shifts ? l1_shifts[i] : 0.0;
+    }
+    s->G.has_box = !(box_lo == -INFINITY && box_hi == INFINITY);
+    s->G.lo = box_lo;
+    s->G.hi = box_hi;
+    const int64_t n_pad = (n + 63) & ~int64_t(63);
+    hipError_t e = hipMalloc(&s->buf, sizeof(double) * n_pad * (4 + m));
+    if (e == hipSuccess) e = hipMalloc(&s->partials, sizeof(double) * 32 * MO_GRID_MAX);
+    if (e == hipSuccess) e = hipMalloc(&s->totals, sizeof(double) * 32);
+    if (e != hipSuccess) {
+        if (s->buf) (void)hipFree(s->buf);
+        if (s->partials) (void)hipFree(s->partials);
+        delete s;
+        return zf_fail(ZF_ERR_HIP, "zf_mo_create: %s", hipGetErrorString(e));
+    }
+    for (int k = 0; k < 3; ++k) s->xb[k] = s->buf + k * n_pad;
+    s->y = s->buf + 3 * n_pad;
+    s->J = s->buf + 4 * n_pad;   // rows are n apart (not n_pad): J[i*n + j]
+    int64_t g = (n + ZF_BLOCK - 1) / ZF_BLOCK;
+    s->grid = (int)(g > MO_GRID_MAX ? MO_GRID_MAX : (g < 1 ? 1 : g));
+    *out = s;
+    return ZF_OK;
+}
+
+extern "C" int zf_mo_destroy(zf_mo* s) {
+    if (!s) return ZF_OK;
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(s->buf);
+    (void)hipFree(s->partials);
+    (void)hipFree(s->totals);
+    delete s;
+    return ZF_OK;
+}
+
+// x_k = x_{k-1} = y = x0   (proximal_gradient.py:463-465)
+extern "C" int zf_mo_set_x0(zf_mo* s, const double* x0_host) {
+    ZF_REQUIRE(s && x0_host, "zf_mo_set_x0: null argument");
+    s->cur = 0;
+    const size_t bytes = sizeof(double) * s->n;
+    ZF_HIP(hipMemcpyAsync(s->xb[0], x0_host, bytes, hipMemcpyHostToDevice, s->stream));
+    ZF_HIP(hipMemcpyAsync(s->xb[2], s->xb[0], bytes, hipMemcpyDeviceToDevice, s->stream));
+    ZF_HIP(hipMemcpyAsync(s->y, s->xb[0], bytes, hipMemcpyDeviceToDevice, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return ZF_OK;
+}
+
+static int mo_builtin_f(zf_mo* s, const double* x, double* f_out) {
+    const double dn = (double)s->n;
+    double t[4];
+    if (s->kind == ZF_MO_JOS1) {
+        hipLaunchKernelGGL(k_jos1_sums, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->n, s->partials);
+        int rc = mo_reduce_to_host(s, 2, -1, t);
+        if (rc) return rc;
+        const double n0 = sqrt(t[0]), n1 = sqrt(t[1]);
+        f_out[0] = n0 * n0 / dn;   // np.linalg.norm(x) ** 2 / n
+        f_out[1] = n1 * n1 / dn;
+        return ZF_OK;
+    }
+    if (s->kind == ZF_MO_FDS) {
+        hipLaunchKernelGGL(k_fds_sums, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->n, s->partials);
+        int rc = mo_reduce_to_host(s, 4, -1, t);
+        if (rc) return rc;
+        const double nx = sqrt(t[2]);
+        f_out[0] = t[0] / (dn * dn);                    // inner(idx, (x-idx)**4) / n**2
+        f_out[1] = exp(t[1] / dn) + nx * nx;            // exp(x.sum()/n) + norm(x)**2
+        f_out[2] = t[3] / (dn * (dn + 1));              // inner(conv, exp(-x)) / (n (n+1))
+        return ZF_OK;
+    }
+    return zf_fail(ZF_ERR_STATE, "zf_mo: f is a host callback for this problem kind");
+}
+
+static int mo_g_values(zf_mo* s, const double* x, double* g_out) {
+    double t[MO_MAX_M + 1];
+    const int m = s->m;
+    if (m == 2) hipLaunchKernelGGL(k_g_terms<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->G, s->n, s->partials);
+    else if (m == 3) hipLaunchKernelGGL(k_g_terms<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->G, s->n, s->partials);
+    else hipLaunchKernelGGL(k_g_terms<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->G, s->n, s->partials);
+    int rc = mo_reduce_to_host(s, m + 1, -1, t);
+    if (rc) return rc;
+    for (int i = 0; i < m; ++i) {
+        if (s->G.has_box && t[m] > 0.0) g_out[i] = INFINITY;             // problems.py:104-106
+        else g_out[i] = s->G.has_l1 ? s->G.ratio[i] * t[i] : 0.0;         // :112-117
+    }
+    return ZF_OK;
+}
+
+// f(x), g(x) at which = 0: x_k, 1: y, 2: x+ ; f_out may be NULL (generic kind: host callback)
+extern "C" int zf_mo_eval_F(zf_mo* s, int32_t which, double* f_out, double* g_out) {
+    ZF_REQUIRE(s && g_out, "zf_mo_eval_F: null argument");
+    const double* x = mo_which(s, which);
+    ZF_REQUIRE(x, "zf_mo_eval_F: bad point selector");
+    if (f_out) {
+        int rc = mo_builtin_f(s, x, f_out);
+        if (rc) return rc;
+    }
+    return mo_g_values(s, x, g_out);
+}
+
+// J = jac_f(y), f_y = f(y) for the built-in problems
+extern "C" int zf_mo_prepare(zf_mo* s, double* f_y_out) {
+    ZF_REQUIRE(s && f_y_out, "zf_mo_prepare: null argument");
+    int rc = mo_builtin_f(s, s->y, f_y_out);   // leaves the raw sums in s->totals (FDS needs sum x)
+    if (rc) return rc;
+    if (s->kind == ZF_MO_JOS1)
+        hipLaunchKernelGGL(k_jos1_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n);
+    else
+        hipLaunchKernelGGL(k_fds_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n, s->totals);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+// generic kind: J (m x n, row-major) computed by a host callback
+extern "C" int zf_mo_set_jac(zf_mo* s, const double* J_host) {
+    ZF_REQUIRE(s && J_host, "zf_mo_set_jac: null argument");
+    ZF_HIP(hipMemcpyAsync(s->J, J_host, sizeof(double) * s->m * s->n, hipMemcpyHostToDevice, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return ZF_OK;
+}
+
+// out: [0..m) g_i(p)  [m] |p-v|^2  [m+1] |w@J|^2  [m+2 .. 2m+2) J_i . (p - y)
+extern "C" int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double* out) {
+    ZF_REQUIRE(s && w_host && out, "zf_mo_dual_eval: null argument");
+    mo_w W;
+    mo_fill_w(s, lr, w_host, &W);
+    const int m = s->m;
+    if (m == 2) hipLaunchKernelGGL(k_dual_eval<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials);
+    else if (m == 3) hipLaunchKernelGGL(k_dual_eval<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials);
+    else hipLaunchKernelGGL(k_dual_eval<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials);
+    int rc = mo_reduce_to_host(s, 2 * m + 2, -1, out);
+    if (rc) return rc;
+    for (int i = 0; i < m; ++i) out[i] = s->G.has_l1 ? s->G.ratio[i] * out[i] : 0.0;
+    return ZF_OK;
+}
+
+// x+ = prox(lr w, y - lr w@J) ; *err_out = max|x+ - y|
+extern "C" int zf_mo_recover(zf_mo* s, double lr, const double* w_host, double* err_out) {
+    ZF_REQUIRE(s && w_host && err_out, "zf_mo_recover: null argument");
+    mo_w W;
+    mo_fill_w(s, lr, w_host, &W);
+    double* xn = s->xb[(s->cur + 1) % 3];
+    const int m = s->m;
+    if (m == 2) hipLaunchKernelGGL(k_recover<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, xn, s->G, W, s->n, s->partials);
+    else if (m == 3) hipLaunchKernelGGL(k_recover<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, xn, s->G, W, s->n, s->partials);
+    else hipLaunchKernelGGL(k_recover<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, xn, s->G, W, s->n, s->partials);
+    return mo_reduce_to_host(s, 1, 0, err_out);
+}
+
+// accept x+: x_{k-1} <- x_k <- x+ ; y = x_k + beta (x_k - x_{k-1})  (or y = x_k)   :530-538
+extern "C" int zf_mo_commit(zf_mo* s, double beta, int32_t nesterov) {
+    ZF_REQUIRE(s, "zf_mo_commit: null argument");
+    s->cur = (s->cur + 1) % 3;
+    hipLaunchKernelGGL(k_commit, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->xb[s->cur],
+                       s->xb[(s->cur + 2) % 3], beta, (int)nesterov, s->n);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+// which = 0: x_k, 1: y, 2: x+, 3: x_{k-1}
+extern "C" int zf_mo_get(zf_mo* s, int32_t which, double* host) {
+    ZF_REQUIRE(s && host, "zf_mo_get: null argument");
+    const double* x = mo_which(s, which);
+    ZF_REQUIRE(x, "zf_mo_get: bad point selector");
+    ZF_HIP(hipMemcpyAsync(host, x, sizeof(double) * s->n, hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return ZF_OK;
+}
+
+extern "C" int zf_mo_get_jac(zf_mo* s, double* J_host) {
+    ZF_REQUIRE(s && J_host, "zf_mo_get_jac: null argument");
+    ZF_HIP(hipMemcpyAsync(J_host, s->J, sizeof(double) * s->m * s->n, hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return ZF_OK;
+}
+
+// upload a host point into slot which = 1 (y) or 2 (x+): used when a host callback produced it
+extern "C" int zf_mo_put(zf_mo* s, int32_t which, const double* host) {
+    ZF_REQUIRE(s && host && (which == 1 || which == 2 || which == 0), "zf_mo_put: bad argument");
+    ZF_HIP(hipMemcpyAsync(mo_which(s, which), host, sizeof(double) * s->n, hipMemcpyHostToDevice, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return ZF_OK;
+}
+
+// prox_wsum_g(weight, x) at a host point (callback contract of Problem.prox_wsum_g)
+extern "C" int zf_mo_prox_host(zf_mo* s, const double* weight_host, const double* x_host, double* out_host) {
+    ZF_REQUIRE(s && weight_host && x_host && out_host, "zf_mo_prox_host: null argument");
+    mo_w W;
+    mo_fill_w(s, 1.0, weight_host, &W);                  // coef = weight * l1_ratios
+    double* tmp_in = s->xb[(s->cur + 1) % 3];            // x+ slot is scratch between trials
+    ZF_HIP(hipMemcpyAsync(tmp_in, x_host, sizeof(double) * s->n, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_prox_only, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, tmp_in, s->G, W, s->n);
+    ZF_HIP(hipGetLastError());
+    ZF_HIP(hipMemcpyAsync(out_host, tmp_in, sizeof(double) * s->n, hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return ZF_OK;
+}
+
+// ---- generic kind: terms that follow a host prox callback ---------------------------------
+// p (host) = prox_wsum_g(lr w, v) was computed by the user's callback; returns
+// out[0..m) = J_i . (p - y)   and   out[m] = |p - (y - lr w@J)|^2   (proximal_gradient.py:168,173)
+namespace {
+template <int M>
+__global__ __launch_bounds__(ZF_BLOCK) void k_post_terms(const double* __restrict__ J, const double* __restrict__ y,
+                                                         const double* __restrict__ p, mo_w W, int64_t n,
+                                                         double* partials) {
+    __shared__ double lds[ZF_WAVES * (M + 1)];
+    double acc[M + 1];
+#pragma unroll
+    for (int k = 0; k <= M; ++k) acc[k] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        double Jc[M];
+        double wJ = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            Jc[i] = J[(int64_t)i * n + j];
+            wJ += W.w[i] * Jc[i];
+        }
+        const double yj = y[j], pj = p[j];
+        const double v = yj - W.lr * wJ;
+        const double dy = pj - yj, dv = pj - v;
+#pragma unroll
+        for (int i = 0; i < M; ++i) acc[i] += Jc[i] * dy;
+        acc[M] += dv * dv;
+    }
+    const double maxs[1] = {0.0};
+    double out = 0.0;
+    zf_block_reduce<M + 1, 0, ZF_WAVES>(acc, maxs, lds, out);
+    if (threadIdx.x <= M) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+}
+}  // namespace
+
+extern "C" int zf_mo_post_terms(zf_mo* s, double lr, const double* w_host, const double* p_host, double* out) {
+    ZF_REQUIRE(s && w_host && p_host && out, "zf_mo_post_terms: null argument");
+    mo_w W;
+    mo_fill_w(s, lr, w_host, &W);
+    double* pd = s->xb[(s->cur + 1) % 3];
+    ZF_HIP(hipMemcpyAsync(pd, p_host, sizeof(double) * s->n, hipMemcpyHostToDevice, s->stream));
+    const int m = s->m;
+    if (m == 2) hipLaunchKernelGGL(k_post_terms<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, pd, W, s->n, s->partials);
+    else if (m == 3) hipLaunchKernelGGL(k_post_terms<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, pd, W, s->n, s->partials);
+    else hipLaunchKernelGGL(k_post_terms<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, pd, W, s->n, s->partials);
+    return mo_reduce_to_host(s, m + 1, -1, out);
+}

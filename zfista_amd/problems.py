@@ -198,3 +198,124 @@ def match_native(f, g, jac_f, prox_wsum_g):
         if getattr(cb, "__func__", None) is not getattr(type(owner), name):
             return None
     return owner
+
+
+# ---------------------------------------------------------------------------
+# multi-objective problem family of zfista/problems.py (shifted l1 + box)
+# ---------------------------------------------------------------------------
+class Problem:
+    """Mirror of zfista.problems.Problem (problems.py:25-150): F_i = f_i + g_i with
+    g_i(x) = l1_ratios[i] * |x - l1_shifts[i]|_1 plus an optional box.
+
+    ``g`` and ``prox_wsum_g`` are NumPy-callable and evaluated on the GPU
+    (``zf_mo_eval_F`` / ``zf_mo_prox_host``).  Subclasses with a built-in device
+    ``f`` / ``jac_f`` (``JOS1``, ``FDS``) are run by ``minimize_proximal_gradient``
+    with everything but SciPy's dual search on the GPU.
+    """
+
+    _kind = _lib.ZF_MO_GENERIC
+
+    def __init__(self, n_features, n_objectives, l1_ratios=None, l1_shifts=None, bounds=None):
+        self.n_features = int(n_features)
+        self.n_objectives = int(n_objectives)
+        self.l1_ratios = None if l1_ratios is None else np.array(l1_ratios, dtype=np.float64)
+        self.l1_shifts = np.zeros(n_objectives) if l1_shifts is None else np.array(l1_shifts, dtype=np.float64)
+        self.bounds = bounds
+        if bounds is not None and (np.ndim(bounds[0]) or np.ndim(bounds[1])):
+            raise NotImplementedError("array-valued bounds are not supported by the device prox")
+        self.name = self._generate_name()
+        self._eng = None
+
+    def _generate_name(self):   # problems.py:81-91
+        parts = [type(self).__name__, f"n_{self.n_features}"]
+        if self.l1_ratios is not None:
+            parts.append("l1_ratios_" + "_".join(map(str, self.l1_ratios)))
+            parts.append("l1_shifts_" + "_".join(map(str, self.l1_shifts)))
+        if self.bounds is not None:
+            parts.append("bounds_" + "_".join(map(str, [self.bounds[0], self.bounds[1]])))
+        return "_".join(parts)
+
+    def _engine(self):
+        from .multiobjective import MoEngine
+
+        if self._eng is None or self._eng.h is None:
+            self._eng = MoEngine(self._kind, self.n_objectives, self.n_features, self.l1_ratios,
+                                 self.l1_shifts, self.bounds)
+        return self._eng
+
+    def _check_len(self, x):
+        if self.n_features != len(x):
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")   # problems.py:102-103
+
+    def g(self, x):
+        self._check_len(x)
+        eng = self._engine()
+        eng.put(2, x)
+        return eng.eval_F(2, builtin_f=False)[1]
+
+    def prox_wsum_g(self, weight, x):
+        self._check_len(x)
+        return self._engine().prox_host(weight, x)
+
+    def f(self, x):
+        raise NotImplementedError
+
+    def jac_f(self, x):
+        raise NotImplementedError
+
+    def callbacks(self):
+        return self.f, self.g, self.jac_f, self.prox_wsum_g
+
+    def minimize_proximal_gradient(self, x0, **kwargs):   # problems.py:140-150
+        from .proximal_gradient import minimize_proximal_gradient
+
+        return minimize_proximal_gradient(self.f, self.g, self.jac_f, self.prox_wsum_g, x0, **kwargs)
+
+
+class _BuiltinProblem(Problem):
+    def f(self, x):
+        self._check_len(x)
+        eng = self._engine()
+        eng.put(2, x)
+        return eng.eval_F(2)[0]
+
+    def jac_f(self, x):
+        self._check_len(x)
+        eng = self._engine()
+        saved = eng.get(1)
+        eng.put(1, x)
+        eng.prepare()
+        J = eng.get_jac()
+        eng.put(1, saved)
+        return J
+
+
+class JOS1(_BuiltinProblem):
+    """f_1 = |x|^2 / n, f_2 = |x - 2|^2 / n   (zfista/problems.py:153-205)."""
+
+    _kind = _lib.ZF_MO_JOS1
+
+    def __init__(self, n_features=5, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(n_features, 2, l1_ratios, l1_shifts, bounds)
+
+
+class FDS(_BuiltinProblem):
+    """Fliege-Drummond-Svaiter test problem, m = 3   (zfista/problems.py:267-328)."""
+
+    _kind = _lib.ZF_MO_FDS
+
+    def __init__(self, n_features=10, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(n_features, 3, l1_ratios, l1_shifts, bounds)
+
+
+def match_native_multi(f, g, jac_f, prox_wsum_g):
+    """The built-in multi-objective Problem whose four bound methods these are, else None."""
+    owner = getattr(f, "__self__", None)
+    if not isinstance(owner, _BuiltinProblem):
+        return None
+    for cb, name in zip((f, g, jac_f, prox_wsum_g), ("f", "g", "jac_f", "prox_wsum_g")):
+        if getattr(cb, "__self__", None) is not owner:
+            return None
+        if getattr(cb, "__func__", None) is not getattr(type(owner), name):
+            return None
+    return owner

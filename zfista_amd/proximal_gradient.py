@@ -24,7 +24,7 @@ from scipy.optimize import OptimizeResult
 
 from . import _lib
 from .engine import DeviceSolver, momentum_factors
-from .problems import match_native
+from .problems import match_native, match_native_multi
 
 _MSG_OK = "Optimization terminated successfully"   # proximal_gradient.py:527
 _MSG_MAXITER = "Maximum number of iterations reached"   # :541
@@ -71,8 +71,13 @@ def minimize_proximal_gradient(
         deprecated=deprecated,
     )
     native = match_native(f, g, jac_f, prox_wsum_g)
+    native_multi = match_native_multi(f, g, jac_f, prox_wsum_g)
     if native is not None:
         res, status = _solve_native(native, x0, opts)
+    elif native_multi is not None:
+        from . import multiobjective
+
+        res, status = multiobjective.solve_native(native_multi, x0, opts)
     else:
         res, status = _solve_generic(f, g, jac_f, prox_wsum_g, x0, opts)
     if status == _lib.ZF_MAXITER:
