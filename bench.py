@@ -42,6 +42,20 @@ def make_inputs(n, seed, device):
     return d, c
 
 
+def measured_traffic(n):
+    """HBM bytes per trial-kernel launch from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    runs of this same command, gfx950 corrections applied).  None when no profile
+    for this n is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            prof = json.load(fh)
+    except OSError:
+        return None
+    return prof["hbm_bytes_per_launch"] if prof.get("n") == n else None
+
+
 def cpu_baseline(d, c, sample_n=10**7, iters=5):
     """The oracle (NumPy restatement of the reference path) on the host cores,
     on a bounded sample of the same workload.  Reported, never a target."""
@@ -166,8 +180,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "zf_trial_kernel<grad inline, nesterov>",
+                "traffic": measured_traffic(n),
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                  "separate passes, bytes per launch)",
+                "kernel": "zf_trial_kernel<grad inline, nesterov, nt>",
                 "kernel_avg_ms": ker_ms,
                 "algorithmic_bytes_per_launch": ALG_BYTES_PER_ELEM * n,
             },
