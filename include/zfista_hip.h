@@ -158,6 +158,16 @@ int zf_solver_pack_ptrs(zf_solver* s, double** pack_local_dev, double** pack_all
 /* make the solver write / read caller-owned pack buffers instead (e.g. torch
  * tensors the collective runs on); sizes as above; must outlive the solver */
 int zf_solver_set_pack_buffers(zf_solver* s, double* pack_local_dev, double* pack_all_dev);
+/* sharded least squares (x and the columns of A split over ranks): the
+ * m-vector A_p x_p of every rank is exchanged once per trial.  Between
+ * zf_solver_enqueue_trial() and zf_solver_enqueue_trial_finish() (and between
+ * zf_solver_enqueue_init() and zf_solver_enqueue_init_finish()) the caller gathers
+ * s_part (m doubles) of all ranks into s_all (world x m, rank-major); the finish call
+ * adds the parts in rank order.  Both finish calls are no-ops for other problems. */
+int zf_solver_svec_ptrs(zf_solver* s, double** s_part_dev, double** s_all_dev);
+int zf_solver_set_svec_buffers(zf_solver* s, double* s_part_dev, double* s_all_dev);
+int zf_solver_enqueue_trial_finish(zf_solver* s);
+int zf_solver_enqueue_init_finish(zf_solver* s);
 /* synchronise the stream, copy out the control block and the trace ring */
 int zf_solver_poll(zf_solver* s, zf_control* ctl_host, double* trace_host /* ZF_RING*ZF_TRACE_COLS */);
 /* device address / host copy of the latest accepted iterate x_k (local shard) */

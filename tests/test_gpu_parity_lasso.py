@@ -85,6 +85,90 @@ def test_lasso_vs_oracle_shapes(shape):
     np.testing.assert_allclose(res.allfuns, exp.allfuns, rtol=TOL)
 
 
+def test_lasso_2048x8192_vs_oracle():
+    """A mid-size dense problem (128 MiB A: several row slices, many column panels) against
+    the oracle on the host; lr = 0.9/L so no trial is marginal."""
+    from oracle import cpu_ref, problems_ref as P
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.problems import LeastSquaresL1
+
+    m, n = 2048, 8192
+    A, b, lam = P.make_plasso(m, n, seed=9)
+    L = np.linalg.norm(A, 2) ** 2
+    kw = dict(lr=0.9 / L, nesterov=True, tol=0.0, max_iter=25, return_all=True)
+    prob, ref = LeastSquaresL1(A, b, lam), P.LeastSquaresL1Ref(A, b, lam)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize_proximal_gradient(*prob.callbacks(), np.zeros(n), **kw)
+        exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), np.zeros(n), **kw)
+    assert res.nit == exp.nit == 25
+    for k in (1, 5, 25):
+        assert rel_err(res.allvecs[k], exp.allvecs[k]) <= TOL
+    np.testing.assert_allclose(res.allfuns, exp.allfuns, rtol=TOL)
+    assert np.array_equal(np.asarray(exp.alltrials), np.ones(25, dtype=int))
+
+
+def test_lasso_cfg3_full_size_properties():
+    """BASELINE cfg3 size (A 16384 x 65536 fp64 = 8 GiB; an oracle run does not fit the time
+    budget): size-independent properties.  (1) the operator's f and grad f agree with an
+    independent fp64 evaluation (torch / rocBLAS GEMV) to 1e-12; (2) with lr = 0.9/L every
+    trial is accepted and F decreases monotonically under ISTA; (3) the FISTA iterate after K
+    steps equals a torch fp64 restatement of the same recursion to 1e-10."""
+    import torch
+
+    from zfista_amd import _lib
+    from zfista_amd.engine import momentum_factors
+    from zfista_amd.problems import LeastSquaresL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    m, n = 16384, 65536
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.randn(m, n, dtype=torch.float64, device="cuda", generator=gen)
+    xt = torch.zeros(n, dtype=torch.float64, device="cuda")
+    xt[:20] = torch.randn(20, dtype=torch.float64, device="cuda", generator=gen)
+    b = A @ xt + 0.01 * torch.randn(m, dtype=torch.float64, device="cuda", generator=gen)
+    lam = 0.1 * float(torch.max(torch.abs(A.T @ b)))
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=gen)
+    for _ in range(15):
+        v = A.T @ (A @ v)
+        v /= torch.linalg.norm(v)
+    L = float(torch.linalg.norm(A @ v)) ** 2
+    lr = 0.9 / L
+    prob = LeastSquaresL1(A, b, lam)
+    x = torch.randn(n, dtype=torch.float64, device="cuda", generator=gen) * 1e-3
+    r = A @ x - b
+    np.testing.assert_allclose(prob.f(x.cpu().numpy()), 0.5 * float(r @ r), rtol=1e-12)
+    g_ref = (A.T @ r).cpu().numpy()
+    g_got = prob.jac_f(x.cpu().numpy())
+    assert np.linalg.norm(g_got - g_ref) <= 1e-12 * np.linalg.norm(g_ref)
+
+    o = dict(lr=lr, tol=0.0, tol_internal=1e-12, max_iter=8, max_backtrack_iter=100, decay_rate=0.5,
+             nesterov=False, nesterov_ratio=(0, 0.25), deprecated=False)
+    run = NativeRun(prob, torch.zeros(n, dtype=torch.float64, device="cuda"), o)
+    rows = run.advance(8)
+    assert len(rows) == 8 and np.all(rows[:, _lib.TR_TRIALS] == 1)
+    F = np.concatenate([[run.F0], rows[:, _lib.TR_F]])
+    assert np.all(np.diff(F) < 0)
+    run.solver.close()
+
+    K = 6
+    o.update(nesterov=True, max_iter=K)
+    run = NativeRun(prob, torch.zeros(n, dtype=torch.float64, device="cuda"), o)
+    rows = run.advance(K)
+    xK = torch.from_numpy(run.solver.get_x()).cuda()
+    run.solver.close()
+    betas = np.concatenate([[0.0], momentum_factors(K, (0, 0.25))[0]])
+    xk = torch.zeros(n, dtype=torch.float64, device="cuda")
+    xo = xk.clone()
+    for k in range(K):
+        y = xk + betas[k] * (xk - xo)
+        grad = A.T @ (A @ y - b)
+        u = y - lr * grad
+        xn = torch.sign(u) * torch.clamp(torch.abs(u) - lam * lr, min=0.0)
+        xo, xk = xk, xn
+    assert float(torch.linalg.norm(xK - xk) / torch.linalg.norm(xk)) <= TOL
+
+
 def test_lasso_operator_callables():
     """f / g / jac_f / prox_wsum_g as plain callables (GPU-evaluated) match the oracle."""
     from oracle import problems_ref as P

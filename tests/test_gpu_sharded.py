@@ -14,6 +14,95 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("world,shape", [(2, (300, 1000)), (3, (129, 301)), (4, (64, 4096))])
+@pytest.mark.parametrize("nesterov", [False, True])
+def test_sharded_least_squares_lockstep(world, shape, nesterov):
+    """Column-sharded LASSO: rank p holds A_p, x_p; per trial the ranks
+    exchange the m-vector A_p x_p (C2) and the scalar pack (C1).  Two..four solver objects
+    in lockstep on one GPU, collectives emulated by D2D copies; compared with the oracle on
+    the unsharded problem (tolerance 1e-10: the row sums are added in a different order)."""
+    import torch
+
+    from conftest import rel_err
+    from oracle import cpu_ref, problems_ref as P
+    from zfista_amd import _lib
+    from zfista_amd.engine import DeviceSolver, momentum_factors
+
+    m, n = shape
+    A, b, lam = P.make_plasso(m, n, seed=6, n_informative=max(2, n // 10))
+    K = 40
+    kw = dict(lr=1.0, nesterov=nesterov, tol=0.0, max_iter=K)
+    opts = dict(lr=1.0, tol=0.0, tol_internal=1e-12, decay_rate=0.5, max_iter=K, max_backtrack_iter=100,
+                nesterov=int(nesterov), deprecated=0)
+    bounds = [r * n // world for r in range(world + 1)]
+    bd = torch.from_numpy(b).cuda()
+    solvers, keep = [], [bd]
+    for r in range(world):
+        Ap = torch.from_numpy(np.ascontiguousarray(A[:, bounds[r]:bounds[r + 1]])).cuda()
+        x0 = torch.zeros(Ap.shape[1], dtype=torch.float64, device="cuda")
+        keep += [Ap, x0]
+        fields = dict(kind=_lib.ZF_PROBLEM_LEAST_SQUARES_L1, world=world, rank=r, n=Ap.shape[1], m_rows=m,
+                      d=None, c=None, A=Ap.data_ptr(), b=bd.data_ptr(), scale=0.5, lam=lam,
+                      box_lo=-np.inf, box_hi=np.inf)
+        s = DeviceSolver(fields, opts, keepalive=(Ap, bd))
+        s.init_begin(x0.data_ptr())
+        solvers.append(s)
+
+    def exchange_svec():
+        allp = torch.cat([s._s_part for s in solvers])
+        for s in solvers:
+            s._s_all.copy_(allp)
+
+    def exchange_pack():
+        allp = torch.cat([s._pack_local for s in solvers])
+        for s in solvers:
+            s._pack_all.copy_(allp)
+
+    exchange_svec()
+    for s in solvers:
+        s.init_finish()
+    exchange_pack()
+    for s in solvers:
+        s.init_commit()
+    betas = np.concatenate([[0.0], momentum_factors(K, (0, 0.25))[0]])
+    if nesterov:
+        for s in solvers:
+            s.set_beta(0, betas[:K + 1])
+    funs, lrs = [], []
+    status, seen, guard = _lib.ZF_RUNNING, 0, 0
+    while status == _lib.ZF_RUNNING and guard < 50:
+        guard += 1
+        for _ in range(16):
+            for s in solvers:
+                s.enqueue_trial()
+            exchange_svec()
+            for s in solvers:
+                s.trial_finish()
+            exchange_pack()
+            for s in solvers:
+                s.enqueue_decide()
+        ctls = [s.poll() for s in solvers]
+        c0, t0 = ctls[0]
+        for ck, tk in ctls[1:]:
+            assert (ck.nit, ck.status, ck.lr, ck.cur) == (c0.nit, c0.status, c0.lr, c0.cur)
+            assert np.array_equal(tk, t0)
+        rows = t0[np.arange(seen, c0.nit) % _lib.ZF_RING]
+        funs += list(rows[:, _lib.TR_F])
+        lrs += list(rows[:, _lib.TR_LR])
+        seen, status = int(c0.nit), int(c0.status)
+    x = np.concatenate([s.get_x() for s in solvers])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*P.LeastSquaresL1Ref(A, b, lam).callbacks(), np.zeros(n),
+                                                 return_all=True, **kw)
+    assert seen == exp.nit == K
+    assert np.array_equal(np.asarray(lrs), np.asarray(exp.alllrs))
+    assert rel_err(x, exp.x) <= 1e-10
+    np.testing.assert_allclose(funs, exp.allfuns[1:], rtol=1e-10)
+    for s in solvers:
+        s.close()
+
+
 @pytest.mark.parametrize("kw", [
     dict(lr=0.45, nesterov=True, tol=0.0, max_iter=40),
     dict(lr=4.0, nesterov=True, tol=1e-6, max_iter=300),

@@ -91,6 +91,10 @@ SIGNATURES = {
     "zf_solver_enqueue_decide": (C.c_int, [_P]),
     "zf_solver_pack_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "zf_solver_set_pack_buffers": (C.c_int, [_P, _P, _P]),
+    "zf_solver_svec_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "zf_solver_set_svec_buffers": (C.c_int, [_P, _P, _P]),
+    "zf_solver_enqueue_trial_finish": (C.c_int, [_P]),
+    "zf_solver_enqueue_init_finish": (C.c_int, [_P]),
     "zf_solver_poll": (C.c_int, [_P, C.POINTER(Control), _P]),
     "zf_solver_x_dev": (C.c_int, [_P, C.POINTER(_P)]),
     "zf_solver_get_x": (C.c_int, [_P, _P]),

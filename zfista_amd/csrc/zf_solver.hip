@@ -21,15 +21,32 @@ thread_local char zf_errbuf[512] = "";
 // ---------------------------------------------------------------------------
 // least squares: the trial kernel leaves the raw totals; f(y), f(x+) come from the
 // GEMV side.  One thread builds the pack and (unsharded) runs the decide step.
+// s_out = sum over ranks (rank order) of the gathered parts A_p x_p; slot as in zf_gemv_rows_kernel
+__global__ __launch_bounds__(ZF_BLOCK) void zf_sum_parts_kernel(const zf_control* ctl, const double* __restrict__ s_all,
+                                                                int world, int64_t m, zf_ring3 sr, int slot) {
+    int idx = 0;
+    if (slot >= 0) {
+        if (ctl->status != ZF_RUNNING) return;
+        idx = (ctl->cur + slot) % 3;
+    }
+    double* __restrict__ out = sr.p[idx];
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; i < m; i += stride) {
+        double t = s_all[i];
+        for (int r = 1; r < world; ++r) t += s_all[(int64_t)r * m + i];
+        out[i] = t;
+    }
+}
+
 __global__ void zf_ls_pack_kernel(zf_control* ctl, const double* totals, const double* ls_scal, double lam,
-                                  double* pack, double* trace, int decide) {
+                                  double* pack, double* trace, int decide, int contribute_f) {
     if (threadIdx.x || blockIdx.x) return;
     if (ctl->status != ZF_RUNNING) return;
-    pack[ZF_PK_FY] = ls_scal[0];
+    pack[ZF_PK_FY] = contribute_f ? ls_scal[0] : 0.0;
     pack[ZF_PK_DOT] = totals[1];
     pack[ZF_PK_SS] = totals[2];
     pack[ZF_PK_GX] = lam * totals[3];
-    pack[ZF_PK_FX] = ls_scal[1];
+    pack[ZF_PK_FX] = contribute_f ? ls_scal[1] : 0.0;
     pack[ZF_PK_ERR] = totals[5];
     pack[6] = 0.0;
     pack[7] = 0.0;
@@ -104,6 +121,9 @@ struct zf_solver {
     double* resid = nullptr;      // m_rows
     double* slab = nullptr;       // slices * n
     double* ls_scal = nullptr;    // [0] f(y) [1] f(x+)
+    double* s_part = nullptr;     // sharded: this rank's A_p x_p (m)
+    double* s_all = nullptr;      // sharded: gathered parts (world x m, rank-major)
+    bool own_svec = true;
     int slices = 1;
     int64_t rows_per_slice = 0;
     bool initialised = false;
@@ -119,7 +139,8 @@ struct zf_solver {
 static int zf_solver_free_all(zf_solver* s) {
     void* ptrs[] = {s->ws.blk_part, s->ws.grp_part, s->counters, s->ws.totals, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
-                    s->grad, s->sbuf, s->resid, s->slab, s->ls_scal};
+                    s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
+                    s->own_svec ? s->s_part : nullptr, s->own_svec ? s->s_all : nullptr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : s->ev_pool) {
@@ -146,7 +167,6 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     } else if (desc->kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
         ZF_REQUIRE(desc->A && desc->b && desc->m_rows >= 1, "zf_solver_create: A, b, m_rows required");
         ZF_REQUIRE(zf_aligned16(desc->A), "zf_solver_create: A must be 16-byte aligned");
-        ZF_REQUIRE(desc->world == 1, "zf_solver_create: sharded least squares is not built yet");
     } else {
         return zf_fail(ZF_ERR_ARG, "zf_solver_create: unknown problem kind");
     }
@@ -217,6 +237,10 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         ZF_TRY(hipMalloc(&s->resid, sizeof(double) * m_pad));
         ZF_TRY(hipMalloc(&s->slab, sizeof(double) * s->slices * n));
         ZF_TRY(hipMalloc(&s->ls_scal, sizeof(double) * 8));
+        if (desc->world > 1) {
+            ZF_TRY(hipMalloc(&s->s_part, sizeof(double) * m_pad));
+            ZF_TRY(hipMalloc(&s->s_all, sizeof(double) * m * desc->world));
+        }
     }
 #undef ZF_TRY
     *out = s;
@@ -312,22 +336,96 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch) {
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
         zf_launch_trial_t<false>(s, a);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
-        // (3) s+ = A x+ ; f(x+)
+        // (3) s+ = A x+ ; f(x+).  Sharded x (column blocks): this rank's A_p x_p+ goes to
+        // s_part; the caller gathers the parts and zf_solver_enqueue_trial_finish() adds them.
         zf_ring3 xr = {{s->xb[0], s->xb[1], s->xb[2]}};
+        zf_ring3 sout = s->sring;
+        if (d.world > 1) sout = {{s->s_part, s->s_part, s->s_part}};
         int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
         if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
         if (V == 2)
             hipLaunchKernelGGL(zf_gemv_rows_kernel<2>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, s->ctl, d.A,
-                               xr, s->sring, 1, m, n);
+                               xr, sout, 1, m, n);
         else
             hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, s->ctl, d.A,
-                               xr, s->sring, 1, m, n);
-        hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1,
-                           d.b, d.scale, m, s->ls_scal + 1);
-        hipLaunchKernelGGL(zf_ls_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->ws.totals, s->ls_scal,
-                           d.lam, s->pack_local, s->trace, (int)(d.world == 1 && decide_in_launch));
+                               xr, sout, 1, m, n);
+        if (d.world == 1) {
+            hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1,
+                               d.b, d.scale, m, s->ls_scal + 1);
+            hipLaunchKernelGGL(zf_ls_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->ws.totals,
+                               s->ls_scal, d.lam, s->pack_local, s->trace, (int)decide_in_launch, 1);
+        }
     }
     ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+// sharded least squares, second half of a trial: s+ = sum over ranks of A_p x_p+ (rank
+// order), f(x+), local pack (f values contributed by rank 0 only: they are replicated)
+extern "C" int zf_solver_enqueue_trial_finish(zf_solver* s) {
+    ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_trial_finish: solver not initialised");
+    const zf_problem_desc& d = s->desc;
+    if (d.kind != ZF_PROBLEM_LEAST_SQUARES_L1 || d.world == 1) return ZF_OK;
+    const int64_t m = d.m_rows;
+    hipLaunchKernelGGL(zf_sum_parts_kernel, dim3(zf_grid_for(m)), dim3(ZF_BLOCK), 0, s->stream, s->ctl, s->s_all,
+                       (int)d.world, m, s->sring, 1);
+    hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1, d.b,
+                       d.scale, m, s->ls_scal + 1);
+    hipLaunchKernelGGL(zf_ls_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->ws.totals, s->ls_scal, d.lam,
+                       s->pack_local, s->trace, 0, (int)(d.rank == 0));
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+// least squares: with s0 = A x0 in sring[0], finish F(x0): A x_{-1} = A x0, f(x0), g(x0), init pack
+static int zf_init_ls_tail(zf_solver* s) {
+    const zf_problem_desc& d = s->desc;
+    const int64_t n = d.n, m = d.m_rows;
+    zf_ring3 s0 = {{s->sring.p[0], s->sring.p[0], s->sring.p[0]}};
+    ZF_HIP(hipMemcpyAsync(s->sring.p[2], s->sring.p[0], sizeof(double) * m, hipMemcpyDeviceToDevice, s->stream));
+    hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, nullptr, s0, -1, d.b, d.scale,
+                       m, s->ls_scal + 1);
+    const int g = zf_grid_for(n);
+    if (s->box)
+        hipLaunchKernelGGL((zf_eval_kernel<false, true>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0], nullptr,
+                           nullptr, d.box_lo, d.box_hi, n, s->partials);
+    else
+        hipLaunchKernelGGL((zf_eval_kernel<false, false>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0], nullptr,
+                           nullptr, d.box_lo, d.box_hi, n, s->partials);
+    zf_init_args I;
+    I.partials = s->partials;
+    I.nblocks = g;
+    I.f_scale = 0.0;
+    I.lam = d.lam;
+    I.f_ext = s->ls_scal + 1;
+    I.pack = s->pack_local;
+    hipLaunchKernelGGL(zf_init_finalize_kernel, dim3(1), dim3(ZF_FIN_BLOCK), 0, s->stream, I);
+    ZF_HIP(hipGetLastError());
+    if (d.world == 1)
+        ZF_HIP(hipMemcpyAsync(s->pack_all, s->pack_local, sizeof(double) * ZF_PACK_LEN, hipMemcpyDeviceToDevice,
+                              s->stream));
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_svec_ptrs(zf_solver* s, double** s_part_dev, double** s_all_dev) {
+    ZF_REQUIRE(s && s_part_dev && s_all_dev, "zf_solver_svec_ptrs: null argument");
+    *s_part_dev = s->s_part;
+    *s_all_dev = s->s_all;
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_set_svec_buffers(zf_solver* s, double* s_part_dev, double* s_all_dev) {
+    ZF_REQUIRE(s && s_part_dev && s_all_dev, "zf_solver_set_svec_buffers: null argument");
+    ZF_REQUIRE(!s->initialised, "zf_solver_set_svec_buffers: call before zf_solver_enqueue_init");
+    ZF_REQUIRE(s->desc.kind == ZF_PROBLEM_LEAST_SQUARES_L1 && s->desc.world > 1,
+               "zf_solver_set_svec_buffers: only for sharded least squares");
+    if (s->own_svec) {
+        if (s->s_part) (void)hipFree(s->s_part);
+        if (s->s_all) (void)hipFree(s->s_all);
+    }
+    s->own_svec = false;
+    s->s_part = s_part_dev;
+    s->s_all = s_all_dev;
     return ZF_OK;
 }
 
@@ -370,12 +468,13 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
             hipLaunchKernelGGL((zf_eval_kernel<true, false>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0],
                                d.d, d.c, d.box_lo, d.box_hi, n, s->partials);
     } else {
-        I.f_scale = 0.0;
-        I.f_ext = s->ls_scal + 1;
+        // s0 = A x0 (sharded: this rank's A_p x0_p into s_part; zf_solver_enqueue_init_finish()
+        // continues after the caller gathered the parts)
         const int64_t m = d.m_rows;
         const int V = (n % 2 == 0) ? 2 : 1;
         zf_ring3 xr = {{s->xb[0], s->xb[0], s->xb[0]}};
-        zf_ring3 s0 = {{s->sring.p[0], s->sring.p[0], s->sring.p[0]}};
+        double* dst = (d.world > 1) ? s->s_part : s->sring.p[0];
+        zf_ring3 s0 = {{dst, dst, dst}};
         int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
         if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
         if (V == 2)
@@ -384,19 +483,9 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
         else
             hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
                                s0, -1, m, n);
-        // A x_{-1} = A x0 as well
-        const int64_t m_pad = (m + 63) & ~int64_t(63);
-        (void)m_pad;
-        ZF_HIP(hipMemcpyAsync(s->sring.p[2], s->sring.p[0], sizeof(double) * m, hipMemcpyDeviceToDevice,
-                              s->stream));
-        hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, nullptr, s0, -1, d.b,
-                           d.scale, m, s->ls_scal + 1);
-        if (s->box)
-            hipLaunchKernelGGL((zf_eval_kernel<false, true>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0],
-                               nullptr, nullptr, d.box_lo, d.box_hi, n, s->partials);
-        else
-            hipLaunchKernelGGL((zf_eval_kernel<false, false>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0],
-                               nullptr, nullptr, d.box_lo, d.box_hi, n, s->partials);
+        ZF_HIP(hipGetLastError());
+        if (d.world > 1) return ZF_OK;
+        return zf_init_ls_tail(s);
     }
     hipLaunchKernelGGL(zf_init_finalize_kernel, dim3(1), dim3(ZF_FIN_BLOCK), 0, s->stream, I);
     ZF_HIP(hipGetLastError());
@@ -404,6 +493,18 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
         ZF_HIP(hipMemcpyAsync(s->pack_all, s->pack_local, sizeof(double) * ZF_PACK_LEN,
                               hipMemcpyDeviceToDevice, s->stream));
     return ZF_OK;
+}
+
+// sharded least squares, second half of the initialisation: s0 = sum of the gathered parts
+extern "C" int zf_solver_enqueue_init_finish(zf_solver* s) {
+    ZF_REQUIRE(s, "zf_solver_enqueue_init_finish: null solver");
+    const zf_problem_desc& d = s->desc;
+    if (d.kind != ZF_PROBLEM_LEAST_SQUARES_L1 || d.world == 1) return ZF_OK;
+    zf_ring3 s0 = {{s->sring.p[0], s->sring.p[0], s->sring.p[0]}};
+    hipLaunchKernelGGL(zf_sum_parts_kernel, dim3(zf_grid_for(d.m_rows)), dim3(ZF_BLOCK), 0, s->stream, nullptr,
+                       s->s_all, (int)d.world, d.m_rows, s0, -1);
+    ZF_HIP(hipGetLastError());
+    return zf_init_ls_tail(s);
 }
 
 extern "C" int zf_solver_enqueue_init_commit(zf_solver* s) {

@@ -61,6 +61,8 @@ class DeviceSolver:
         self.world = int(desc_fields.get("world", 1))
         self.rank = int(desc_fields.get("rank", 0))
         self.n = int(desc_fields["n"])
+        self.kind = int(desc_fields["kind"])
+        self.m_rows = int(desc_fields.get("m_rows", 0) or 0)
         if stream is None:
             import torch
 
@@ -95,9 +97,26 @@ class DeviceSolver:
         self._pack_all = torch.zeros(_lib.ZF_PACK_LEN * self.world, dtype=torch.float64, device="cuda")
         _lib.check(self.lib.zf_solver_set_pack_buffers(
             self.handle, C.c_void_p(self._pack_local.data_ptr()), C.c_void_p(self._pack_all.data_ptr())))
+        self._s_part = self._s_all = None
+        if self.kind == _lib.ZF_PROBLEM_LEAST_SQUARES_L1:
+            # C2: the m-vector A_p x_p of every rank, gathered once per trial
+            self._s_part = torch.zeros(self.m_rows, dtype=torch.float64, device="cuda")
+            self._s_all = torch.zeros(self.m_rows * self.world, dtype=torch.float64, device="cuda")
+            _lib.check(self.lib.zf_solver_set_svec_buffers(
+                self.handle, C.c_void_p(self._s_part.data_ptr()), C.c_void_p(self._s_all.data_ptr())))
 
     def _gather(self):
         gather_packs(self._pack_all, self._pack_local, self.group)
+
+    def _gather_svec(self):
+        if self._s_part is not None:
+            gather_packs(self._s_all, self._s_part, self.group)   # same rank-major all-gather
+
+    def trial_finish(self):
+        _lib.check(self.lib.zf_solver_enqueue_trial_finish(self.handle), "enqueue_trial_finish")
+
+    def init_finish(self):
+        _lib.check(self.lib.zf_solver_enqueue_init_finish(self.handle), "enqueue_init_finish")
 
     # the two halves of a sharded step, and of the sharded initialisation; the
     # caller runs the exchange between them (enqueue()/init() do exactly that)
@@ -117,6 +136,8 @@ class DeviceSolver:
     def init(self, x0_dev_ptr: int):
         self.init_begin(x0_dev_ptr)
         if self.world > 1:
+            self._gather_svec()
+            self.init_finish()
             self._gather()
         self.init_commit()
 
@@ -132,6 +153,8 @@ class DeviceSolver:
             return
         for _ in range(steps):
             self.enqueue_trial()
+            self._gather_svec()
+            self.trial_finish()
             self._gather()
             self.enqueue_decide()
 

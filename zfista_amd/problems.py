@@ -144,7 +144,11 @@ class LeastSquaresL1(NativeProblem):
 
     kind = _lib.ZF_PROBLEM_LEAST_SQUARES_L1
 
-    def __init__(self, A, b, lam, scale=0.5, bounds=None):
+    def __init__(self, A, b, lam, scale=0.5, bounds=None, group=None):
+        """With ``group`` set, ``A`` is this rank's column block A_p (m x n_p, row-major) of a
+        matrix whose columns - and the decision vector - are partitioned over the ranks of
+        that process group; ``b`` is replicated.  ``f`` / ``jac_f`` as plain callables then
+        refer to the local block only; the solve exchanges A_p x_p once per trial."""
         self.A = _to_device(A, "A")
         self.b = _to_device(b, "b")
         if self.A.ndim != 2 or self.b.ndim != 1 or self.A.shape[0] != self.b.shape[0]:
@@ -152,7 +156,7 @@ class LeastSquaresL1(NativeProblem):
         self.lam, self.scale = float(lam), float(scale)
         self.box = (-np.inf, np.inf) if bounds is None else (float(bounds[0]), float(bounds[1]))
         self.m_rows, self.n_features = int(self.A.shape[0]), int(self.A.shape[1])
-        self.group = None
+        self.group = group
 
     def _ls(self, x, want_grad):
         x = _as_host(x)
@@ -180,7 +184,11 @@ class LeastSquaresL1(NativeProblem):
         return None, np.float64(self.lam * s.value)
 
     def _descriptor(self):
-        fields = dict(kind=self.kind, world=1, rank=0, n=self.n_features, m_rows=self.m_rows,
+        import torch.distributed as dist
+
+        world = dist.get_world_size(self.group) if self.group is not None else 1
+        rank = dist.get_rank(self.group) if self.group is not None else 0
+        fields = dict(kind=self.kind, world=world, rank=rank, n=self.n_features, m_rows=self.m_rows,
                       d=None, c=None, A=self.A.data_ptr(), b=self.b.data_ptr(),
                       scale=self.scale, lam=self.lam, box_lo=self.box[0], box_hi=self.box[1])
         return fields, (self.A, self.b)
