@@ -93,6 +93,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Only the JSON line may reach stdout: libraries (RCCL prints "Hostname : ..." banners at
+    # communicator creation) are pointed at stderr for the whole run.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -103,7 +109,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     group = None
-    if world > 1:
+    use_pg = world > 1 or (os.environ.get("ZF_FORCE_SPLIT") == "1" and "RANK" in os.environ)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         group = dist.group.WORLD
@@ -190,9 +197,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, c)
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     run.solver.close()
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

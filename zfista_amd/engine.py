@@ -9,6 +9,7 @@ solver arithmetic happens in the library's HIP kernels.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -84,7 +85,10 @@ class DeviceSolver:
         self._pack_local = self._pack_all = None
         if timing:
             _lib.check(self.lib.zf_solver_set_timing(self.handle, 1))
-        if self.world > 1:
+        # ZF_FORCE_SPLIT=1 runs the sharded step sequence (trial -> all-gather -> decide) even
+        # for one rank: lets a 1-GPU box exercise the RCCL path end to end
+        self.split = self.world > 1 or os.environ.get("ZF_FORCE_SPLIT") == "1"
+        if self.split:
             self._wrap_packs()
 
     # -- sharded x: the per-trial exchange -------------------------------------
@@ -98,7 +102,7 @@ class DeviceSolver:
         _lib.check(self.lib.zf_solver_set_pack_buffers(
             self.handle, C.c_void_p(self._pack_local.data_ptr()), C.c_void_p(self._pack_all.data_ptr())))
         self._s_part = self._s_all = None
-        if self.kind == _lib.ZF_PROBLEM_LEAST_SQUARES_L1:
+        if self.kind == _lib.ZF_PROBLEM_LEAST_SQUARES_L1 and self.world > 1:
             # C2: the m-vector A_p x_p of every rank, gathered once per trial
             self._s_part = torch.zeros(self.m_rows, dtype=torch.float64, device="cuda")
             self._s_all = torch.zeros(self.m_rows * self.world, dtype=torch.float64, device="cuda")
@@ -135,7 +139,7 @@ class DeviceSolver:
     # -- life cycle ---------------------------------------------------------------
     def init(self, x0_dev_ptr: int):
         self.init_begin(x0_dev_ptr)
-        if self.world > 1:
+        if self.split:
             self._gather_svec()
             self.init_finish()
             self._gather()
@@ -148,7 +152,7 @@ class DeviceSolver:
 
     def enqueue(self, steps: int):
         """Enqueue ``steps`` line-search trials; no host synchronisation."""
-        if self.world == 1:
+        if not self.split:
             _lib.check(self.lib.zf_solver_enqueue_steps(self.handle, steps), "enqueue_steps")
             return
         for _ in range(steps):
