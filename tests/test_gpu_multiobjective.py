@@ -198,6 +198,27 @@ def test_generic_multiobjective_golden(m, golden):
             np.testing.assert_allclose(np.concatenate(res.allvecs), G(f"{tag}.vecs").ravel(), rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("tag", ["jos1_n1000_l1", "fds_n10_l1", "fds_n100_l1", "fds_n10_pos"])
+def test_native_dual_solver_full_solve(tag, golden, monkeypatch):
+    """Opt-in native dual solver: same outer iteration count as the
+    reference run and iterates within the accuracy of the reference's own dual solves."""
+    from zfista_amd import minimize_proximal_gradient
+
+    G = golden("g4_multiobjective.npz")
+    make, _, kw = _cases()[tag]
+    p = make()
+    monkeypatch.setenv("ZF_DUAL_SOLVER", "native")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize_proximal_gradient(*p.callbacks(), G(f"{tag}.x0"), nesterov=True, tol=1e-5, max_iter=12,
+                                         return_all=True, **kw)
+    assert res.nit == int(G(f"{tag}.fista.nit"))
+    for a, b in zip(res.allvecs, G(f"{tag}.fista.vecs")):
+        assert rel_err(a, b) <= 2e-5
+    np.testing.assert_allclose(np.stack(res.allfuns), G(f"{tag}.fista.allfuns"), rtol=1e-5)
+    assert p._engine().n_dual_evals <= 60 * res.nit
+
+
 def test_fds_1e6_dual_eval_consistency():
     """BASELINE cfg4 size (n = 10^6, m = 3): one dual evaluation against the oracle's
     NumPy expressions on the same J, y, w (no SciPy in the loop)."""
@@ -225,5 +246,8 @@ def test_fds_1e6_dual_eval_consistency():
     for w in (np.ones(3) / 3, np.array([0.7, 0.2, 0.1]), np.array([0.0, 0.5, 0.5])):
         fun, jac = device_dual(eng, lr, f_y, f0 + g0, False)(w)
         efun, ejac = cpu_ref.dual_value_and_grad(w, r.g, r.prox_wsum_g, lr, y, J, r.f(y), r.f(x0) + r.g(x0))
-        np.testing.assert_allclose(fun, efun, rtol=1e-9, atol=1e-9)
-        np.testing.assert_allclose(jac, ejac, rtol=1e-9, atol=1e-9)
+        # fun and jac contain F(x_old) - f(y): at n = 1e6 FDS's f_1 is ~1e23, so that difference
+        # carries ~1e-16 * 1e23 of cancellation noise whatever the summation order
+        noise = 4e-16 * np.max(np.abs(f_y)) * 8
+        np.testing.assert_allclose(fun, efun, rtol=1e-9, atol=noise)
+        np.testing.assert_allclose(jac, ejac, rtol=1e-9, atol=noise)

@@ -208,27 +208,22 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_commit(double* __restrict__ y, con
 }
 
 // one-block fixed-order reduce of `nq` quantities; quantity `max_index` (or -1) is a max
-__global__ __launch_bounds__(256) void k_mo_reduce(const double* __restrict__ partials, int nblocks, int nq,
-                                                   int max_index, double* out) {
-    __shared__ double lds[4 * 32];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = 0; k < nq; ++k) {
-        const bool is_max = (k == max_index);
-        double v = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += 256) {
-            const double p = partials[(int64_t)k * nblocks + b];
-            v = is_max ? fmax(v, p) : v + p;
-        }
-        v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
-        if (lane == 0) lds[wave * 32 + k] = v;
+// One wave per quantity (nq <= 16 waves): every lane's loads are independent, so the whole
+// reduce is one memory round trip instead of nq dependent ones (it sits on the host's
+// critical path once per dual evaluation).
+constexpr int MO_RED_WAVES = 16;
+__global__ __launch_bounds__(64 * MO_RED_WAVES) void k_mo_reduce(const double* __restrict__ partials, int nblocks,
+                                                                 int nq, int max_index, double* out) {
+    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    if (k >= nq) return;
+    const bool is_max = (k == max_index);
+    double v = 0.0;
+    for (int b = lane; b < nblocks; b += 64) {
+        const double p = partials[(int64_t)k * nblocks + b];
+        v = is_max ? fmax(v, p) : v + p;
     }
-    __syncthreads();
-    if (threadIdx.x < nq) {
-        const int k = threadIdx.x;
-        double v = lds[k];
-        for (int w = 1; w < 4; ++w) v = (k == max_index) ? fmax(v, lds[w * 32 + k]) : v + lds[w * 32 + k];
-        out[k] = v;
-    }
+    v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
+    if (lane == 0) out[k] = v;
 }
 
 }  // namespace
@@ -246,15 +241,18 @@ struct zf_mo {
     double* J = nullptr;
     double* partials = nullptr;
     double* totals = nullptr;  // device, 32
+    double* h_totals = nullptr;  // pinned host mirror of totals (DMA target, no staging copy)
     int grid = 1;
     double f_y[MO_MAX_M];
 };
 
 static int mo_reduce_to_host(zf_mo* s, int nq, int max_index, double* host) {
-    hipLaunchKernelGGL(k_mo_reduce, dim3(1), dim3(256), 0, s->stream, s->partials, s->grid, nq, max_index, s->totals);
+    hipLaunchKernelGGL(k_mo_reduce, dim3(1), dim3(64 * MO_RED_WAVES), 0, s->stream, s->partials, s->grid, nq, max_index,
+                       s->totals);
     ZF_HIP(hipGetLastError());
-    ZF_HIP(hipMemcpyAsync(host, s->totals, sizeof(double) * nq, hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipMemcpyAsync(s->h_totals, s->totals, sizeof(double) * nq, hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
+    memcpy(host, s->h_totals, sizeof(double) * nq);
     return ZF_OK;
 }
 
@@ -305,6 +303,7 @@ extern "C" int zf_mo_create(zf_mo** out, int32_t kind, int32_t m, int64_t n, con
     hipError_t e = hipMalloc(&s->buf, sizeof(double) * n_pad * (4 + m));
     if (e == hipSuccess) e = hipMalloc(&s->partials, sizeof(double) * 32 * MO_GRID_MAX);
     if (e == hipSuccess) e = hipMalloc(&s->totals, sizeof(double) * 32);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_totals, sizeof(double) * 32, hipHostMallocDefault);
     if (e != hipSuccess) {
         if (s->buf) (void)hipFree(s->buf);
         if (s->partials) (void)hipFree(s->partials);
@@ -326,6 +325,7 @@ extern "C" int zf_mo_destroy(zf_mo* s) {
     (void)hipFree(s->buf);
     (void)hipFree(s->partials);
     (void)hipFree(s->totals);
+    (void)hipHostFree(s->h_totals);
     delete s;
     return ZF_OK;
 }

@@ -142,6 +142,12 @@ class MoEngine:
 
 def solve_dual(dual, m, w0, tol, max_iter):
     """The reference's two SciPy calls (:179-205).  Returns (weight, fun, nit)."""
+    import os
+
+    if os.environ.get("ZF_DUAL_SOLVER", DUAL_SOLVER) == "native":
+        out = solve_dual_native(dual, m, w0, tol, max_iter)
+        if out is not None:
+            return out
     if m == 2:
         sol = minimize_scalar(lambda s: dual(np.array([s, 1 - s]))[0], bounds=(0, 1),
                               options={"maxiter": max_iter, "xatol": tol})
@@ -154,6 +160,151 @@ def solve_dual(dual, m, w0, tol, max_iter):
     if not sol.success:
         warn(sol.message, stacklevel=2)
     return sol.x, sol.fun, sol.nit
+
+
+# ---------------------------------------------------------------------------
+# native dual solver: opt-in replacement of the two SciPy calls
+# ---------------------------------------------------------------------------
+DUAL_SOLVER = "scipy"   # "scipy" = the reference's calls (parity default); "native" = simplex Newton
+
+
+def _simplex_qp(q, Q):
+    """argmin_{w in simplex} q.w + 1/2 w'Qw for tiny m by enumerating supports (KKT check)."""
+    m = q.size
+    best, best_val = None, np.inf
+    for mask in range(1, 1 << m):
+        S = [i for i in range(m) if mask >> i & 1]
+        k = len(S)
+        K = np.zeros((k + 1, k + 1))
+        K[:k, :k] = Q[np.ix_(S, S)]
+        K[:k, k] = 1.0
+        K[k, :k] = 1.0
+        rhs = np.concatenate([-q[S], [1.0]])
+        try:
+            sol = np.linalg.solve(K, rhs)
+        except np.linalg.LinAlgError:
+            sol = np.linalg.lstsq(K, rhs, rcond=None)[0]
+        wS, mu = sol[:k], sol[k]
+        if np.any(wS < -1e-14):
+            continue
+        w = np.zeros(m)
+        w[S] = np.maximum(wS, 0.0)
+        w /= w.sum()
+        red = q + Q @ w + mu          # reduced costs; must be >= 0 off the support
+        if np.any(red[[i for i in range(m) if i not in S]] < -1e-10 * (1 + np.abs(red).max())):
+            continue
+        val = q @ w + 0.5 * w @ Q @ w
+        if val < best_val:
+            best, best_val = w, val
+    if best is None:                  # numerically degenerate: fall back to the best vertex
+        v = np.argmin(q + 0.5 * np.diag(Q))
+        best = np.zeros(m)
+        best[v] = 1.0
+    return best
+
+
+def _solve_dual_1d(dual, tol, max_iter):
+    """m = 2: the dual restricted to w = (s, 1 - s) is convex C^1 on [0, 1]; its derivative
+    phi(s) = dD/dw_0 - dD/dw_1 is monotone and piecewise linear, so a bracketing root finder
+    (Illinois-modified regula falsi, exact on a linear piece) places the minimiser to `tol`
+    in s - something a comparison-based search on D itself (minimize_scalar) cannot do below
+    sqrt(eps)."""
+
+    def phi(s):
+        f, g = dual(np.array([s, 1.0 - s]))
+        return f, g[0] - g[1]
+
+    fa, pa = phi(0.0)
+    if pa >= 0.0:
+        return np.array([0.0, 1.0]), fa, 1
+    fb, pb = phi(1.0)
+    if pb <= 0.0:
+        return np.array([1.0, 0.0]), fb, 2
+    a, b = 0.0, 1.0
+    side = 0
+    s, fs = 0.5, None
+    nit = 2
+    for nit in range(3, int(max_iter) + 3):
+        s = (a * pb - b * pa) / (pb - pa)          # secant point of the bracket
+        if not (a < s < b):
+            s = 0.5 * (a + b)
+        fs, ps = phi(s)
+        if ps == 0.0 or (b - a) <= tol:
+            break
+        if ps < 0.0:
+            a, pa = s, ps
+            if side == -1:
+                pb *= 0.5                            # Illinois: halve the stale end
+            side = -1
+        else:
+            b, pb = s, ps
+            if side == 1:
+                pa *= 0.5
+            side = 1
+        if (b - a) <= tol:
+            s = 0.5 * (a + b)
+            fs, _ = phi(s)
+            break
+    return np.array([s, 1.0 - s]), fs, nit
+
+
+def solve_dual_native(dual, m, w0, tol, max_iter):
+    """Minimise the convex C^1 (piecewise quadratic for the l1 + box family) dual over the
+    unit simplex by a projected Newton method: gradient from one fused evaluation,
+    curvature from m further gradient evaluations along the feasible directions e_i - w,
+    the m-variable QP on the simplex solved exactly, Armijo backtracking.  Typically
+    (m + 2) evaluations per iteration and 3-8 iterations, against 30 - 1e5 evaluations of
+    trust-constr at the same tolerance.  Returns (weight, fun, n_iterations)."""
+    w = np.ones(m) / m if w0 is None else np.clip(np.asarray(w0, float), 0, None)
+    w = w / w.sum()
+    fun, grad = dual(w)
+    if not (np.isfinite(fun) and np.all(np.isfinite(grad))):
+        return None   # e.g. F(x_k) = inf (x_k outside the box): leave it to the reference's calls
+    if m == 2:
+        return _solve_dual_1d(dual, tol, max_iter)
+    nit = 0
+    h = 1e-5
+    for nit in range(1, int(max_iter) + 1):
+        # curvature on the tangent space: (grad(w + h (e_i - w)) - grad(w)) / h = H (e_i - w)
+        T = np.eye(m) - w[:, None]                  # column i = e_i - w
+        HT = np.empty((m, m))
+        for i in range(m):
+            _, gi = dual(w + h * T[:, i])
+            HT[:, i] = (gi - grad) / h
+        Q = T.T @ HT
+        Q = 0.5 * (Q + Q.T)
+        ev = np.linalg.eigvalsh(Q)
+        if ev.min() < 0:                            # keep the model convex against FD noise
+            Q = Q + (1e-12 - ev.min()) * np.eye(m)
+        # model in w' (sum w' = 1, w' - w = T w'):  grad.T w' + 1/2 w'Qw'
+        w_new = _simplex_qp(T.T @ grad, Q)
+        d = w_new - w
+        step = np.max(np.abs(d))
+        slope = grad @ d
+        # stop at `tol` in w, or when the model predicts no decrease resolvable in double
+        # precision (the reductions behind `fun` carry ~1e-16 relative noise)
+        if step <= tol or slope >= -4e-16 * max(1.0, abs(fun)):
+            break
+        t = 1.0
+        while True:
+            f_try, g_try = dual(w + t * d)
+            if f_try <= fun + 1e-4 * t * slope + 1e-15 * abs(fun) or t < 1e-10:
+                break
+            t *= 0.5
+        w_prev = w
+        w = w + t * d
+        w = np.clip(w, 0.0, None)
+        w /= w.sum()
+        if t < 1.0 or not np.array_equal(w, w_prev + t * d):
+            fun, grad = dual(w)
+        else:
+            fun, grad = f_try, g_try
+        if t * step <= tol:
+            break
+        # finite-difference step follows the Newton step so the curvature is that of the
+        # quadratic piece the iterate sits in (the dual is piecewise quadratic)
+        h = float(np.clip(0.1 * t * step, 1e-7, 1e-5))
+    return w, fun, nit
 
 
 def device_dual(eng, lr, f_y, F_old, deprecated):
