@@ -63,9 +63,11 @@ def test_lasso_lr_sequence(golden):
     run.solver.close()
 
 
-@pytest.mark.parametrize("shape", [(3, 1), (7, 5), (64, 33), (33, 64), (129, 1000), (1000, 130)])
+@pytest.mark.parametrize("shape", [(3, 1), (7, 5), (64, 33), (33, 64), (129, 1000), (1000, 130),
+                                   (7, 32), (16, 128), (100, 96), (257, 2048)])
 def test_lasso_vs_oracle_shapes(shape):
-    """Odd / even n (scalar and 16-B kernels), tall and wide A."""
+    """Odd / even n (scalar and 16-B VALU kernels), n % 32 == 0 (MFMA A^T r kernel, with
+    row counts that are / are not multiples of its 16-row step), tall and wide A."""
     from oracle import cpu_ref, problems_ref as P
     from zfista_amd import minimize_proximal_gradient
     from zfista_amd.problems import LeastSquaresL1

@@ -33,7 +33,28 @@ template <> __device__ __forceinline__ double zf_dot_v<2>(double2 a, double2 b) 
 // re-read by every workgroup from L2 / Infinity Cache.
 // slot: -1 -> x_in = xr.p[0], s_out = sr.p[0] (plain call)
 //       >=0 -> relative ring slot: index (ctl->cur + slot) % 3 on both rings.
-constexpr int GEMV_ROWS = 4;
+// Measured on 16384 x 65536 (rocprofv3, one sweep = 8.59 GB): 2 rows per workgroup 1.390 ms,
+// 4: 1.418, 8: 1.415, 16: 1.484 (rocBLAS gemv on the same matrix: 1.672 ms).
+#ifndef ZF_GEMV_ROWS
+#define ZF_GEMV_ROWS 2
+#endif
+#ifndef ZF_GEMV_NT
+#define ZF_GEMV_NT 1   // A is read once per sweep: nontemporal loads keep x / r cache-resident
+#endif
+constexpr int GEMV_ROWS = ZF_GEMV_ROWS;
+template <typename T> __device__ __forceinline__ T zf_ld_stream(const T* p) {
+#if ZF_GEMV_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+typedef double zf_row2 __attribute__((ext_vector_type(2)));
+template <int V> struct zf_rowvec;
+template <> struct zf_rowvec<1> { using type = double; };
+template <> struct zf_rowvec<2> { using type = zf_row2; };
+__device__ __forceinline__ double zf_dot_row(double a, double b) { return a * b; }
+__device__ __forceinline__ double zf_dot_row(zf_row2 a, double2 b) { return a.x * b.x + a.y * b.y; }
 template <int V>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_gemv_rows_kernel(const zf_control* ctl,
                                                                 const double* __restrict__ A,
@@ -60,8 +81,9 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_gemv_rows_kernel(const zf_control
 #pragma unroll
             for (int r = 0; r < GEMV_ROWS; ++r) {
                 if (row0 + r < m_rows) {
-                    const VT a = reinterpret_cast<const VT*>(A + (row0 + r) * n)[j];
-                    acc[r] += zf_dot_v<V>(a, xj);
+                    using RT = typename zf_rowvec<V>::type;
+                    const RT a = zf_ld_stream(reinterpret_cast<const RT*>(A + (row0 + r) * n) + j);
+                    acc[r] += zf_dot_row(a, xj);
                 }
             }
         }
@@ -182,6 +204,65 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_gemvT_partial_kernel(const zf_con
     double* out = slab + (int64_t)blockIdx.y * n + colv * V;
 #pragma unroll
     for (int v = 0; v < V; ++v) out[v] = acc[v];
+}
+
+// ---- the same column sweep on the matrix cores (v_mfma_f64_16x16x4_f64) ---------------------
+// A wave owns a 32-column panel and takes 4 rows per step.  B operand: lane l holds
+// B[k = l>>4][col = l&15]; with one 16-B load a lane fetches columns 2c, 2c+1 (c = l&15) of row
+// i0 + (l>>4), which feeds two MFMAs (even / odd columns of the panel).  A operand: lane l holds
+// A[row = l&15][k = l>>4] = r[i0 + (l>>4)] (all 16 rows identical, so every row of D is the
+// wanted 16-column strip).  C/D: col = l&15, row = (l>>4) + 4*reg -> row 0 is lanes 0..15,
+// register 0.  Each matrix element is used once, so an MFMA consumes exactly the 64 elements a
+// v_fma_f64 wave instruction does: measured 6.27 TB/s against 6.26 TB/s for the VALU form on
+// 16384 x 65536 (tools/tune_gemv.hip) - both at the HBM roof, the matrix pipe ~2 % busy.
+typedef double zf_f64x2 __attribute__((ext_vector_type(2)));
+typedef double zf_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int GEMVT_MFMA_UNROLL = 4;
+constexpr int GEMVT_MFMA_COLS = 128;   // columns per workgroup: 4 waves x 32
+__global__ __launch_bounds__(ZF_BLOCK) void zf_gemvT_partial_mfma_kernel(const zf_control* ctl,
+                                                                         const double* __restrict__ A,
+                                                                         const double* __restrict__ r,
+                                                                         double* __restrict__ slab,
+                                                                         int64_t m_rows, int64_t n,
+                                                                         int64_t rows_per_slice) {
+    if (ctl && (ctl->status != ZF_RUNNING || !ctl->need_grad)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j0 = ((int64_t)blockIdx.x * ZF_WAVES + wave) * 32;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
+    int64_t r1 = r0 + rows_per_slice;
+    if (r1 > m_rows) r1 = m_rows;
+    if (j0 >= n) return;
+    const int kq = lane >> 4, c = lane & 15;
+    const double* __restrict__ Ap = A + j0 + 2 * c;
+    zf_f64x4 acc_e = {0.0, 0.0, 0.0, 0.0}, acc_o = {0.0, 0.0, 0.0, 0.0};
+    int64_t i = r0;
+    for (; i + 4 * GEMVT_MFMA_UNROLL <= r1; i += 4 * GEMVT_MFMA_UNROLL) {
+        zf_f64x2 b[GEMVT_MFMA_UNROLL];
+        double rv[GEMVT_MFMA_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GEMVT_MFMA_UNROLL; ++u) {
+            b[u] = zf_ld_stream(reinterpret_cast<const zf_f64x2*>(Ap + (i + 4 * u + kq) * n));
+            rv[u] = r[i + 4 * u + kq];
+        }
+#pragma unroll
+        for (int u = 0; u < GEMVT_MFMA_UNROLL; ++u) {
+            acc_e = __builtin_amdgcn_mfma_f64_16x16x4f64(rv[u], b[u].x, acc_e, 0, 0, 0);
+            acc_o = __builtin_amdgcn_mfma_f64_16x16x4f64(rv[u], b[u].y, acc_o, 0, 0, 0);
+        }
+    }
+    if (kq == 0) {
+        double te = acc_e[0], to = acc_o[0];
+        for (; i < r1; ++i) {   // fewer than 16 rows left in the slice
+            const zf_f64x2 a = *reinterpret_cast<const zf_f64x2*>(Ap + i * n);
+            const double x = r[i];
+            te += a.x * x;
+            to += a.y * x;
+        }
+        zf_f64x2 o;
+        o.x = te;
+        o.y = to;
+        *reinterpret_cast<zf_f64x2*>(slab + (int64_t)blockIdx.y * n + j0 + 2 * c) = o;
+    }
 }
 
 __global__ __launch_bounds__(ZF_BLOCK) void zf_gemvT_combine_kernel(const zf_control* ctl,

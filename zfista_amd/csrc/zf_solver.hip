@@ -128,6 +128,7 @@ struct zf_solver {
     int64_t rows_per_slice = 0;
     bool initialised = false;
     bool own_packs = true;
+    bool gemv_mfma = false;       // A^T r on v_mfma_f64_16x16x4 (n % 32 == 0; ZF_GEMV_MFMA=0 disables)
     // trial-kernel timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -231,6 +232,8 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         if (slices > 64) slices = 64;
         s->rows_per_slice = (m + slices - 1) / slices;
         s->slices = (int)((m + s->rows_per_slice - 1) / s->rows_per_slice);
+        const char* mf = getenv("ZF_GEMV_MFMA");
+        s->gemv_mfma = (n % 32 == 0) && !(mf && atoi(mf) == 0);
         ZF_TRY(hipMalloc(&s->grad, sizeof(double) * n_pad));
         ZF_TRY(hipMalloc(&s->sbuf, sizeof(double) * 3 * m_pad));
         for (int k = 0; k < 3; ++k) s->sring.p[k] = s->sbuf + k * m_pad;
@@ -320,7 +323,11 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch) {
                            (int)s->opt.nesterov);
         const int64_t nv = n / V;
         dim3 gT((unsigned)((nv + ZF_BLOCK - 1) / ZF_BLOCK), (unsigned)s->slices);
-        if (nv > 0) {
+        if (s->gemv_mfma) {
+            dim3 gM((unsigned)((n + GEMVT_MFMA_COLS - 1) / GEMVT_MFMA_COLS), (unsigned)s->slices);
+            hipLaunchKernelGGL(zf_gemvT_partial_mfma_kernel, gM, dim3(ZF_BLOCK), 0, s->stream, s->ctl, d.A,
+                               s->resid, s->slab, m, n, s->rows_per_slice);
+        } else if (nv > 0) {
             if (V == 2)
                 hipLaunchKernelGGL(zf_gemvT_partial_kernel<2>, gT, dim3(ZF_BLOCK), 0, s->stream, s->ctl,
                                    d.A, s->resid, s->slab, m, n, s->rows_per_slice);
