@@ -178,6 +178,7 @@ def main():
                 "n_total": n * world,
                 "iters_per_sec_full_problem": K / dt,
                 "trials_per_iteration": trials_per_iter,
+                "tiles_per_workgroup_autotuned": getattr(run.solver, "tiles_per_wg", None),
                 "parallelism": f"x sharded over {world} GPU(s); per-trial scalar pack all-gather"
                                if world > 1 else "single GPU",
             },

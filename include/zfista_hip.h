@@ -74,7 +74,10 @@ typedef struct zf_control {
     int32_t deprecated;   /* deprecated acceptance test (:300-302)                    */
     int32_t need_grad;    /* least squares: gradient at y_k must be (re)computed      */
     int32_t world;        /* ranks whose packs are summed by the decide step          */
-    int32_t reserved[2];
+    double beta_next;     /* momentum factor of the next trial (:533), resolved from the
+                             momentum ring by the decide step so that a trial kernel needs
+                             ONE dependent scalar load (this block) before its first
+                             vector load                                               */
 } zf_control;
 
 typedef struct zf_problem_desc {
@@ -149,6 +152,10 @@ int zf_solver_enqueue_init_commit(zf_solver* s);
 int zf_solver_set_beta(zf_solver* s, int64_t first, const double* beta_host, int64_t count);
 /* world == 1: enqueue `steps` complete steps (trial+finalize+decide), no host sync */
 int zf_solver_enqueue_steps(zf_solver* s, int64_t steps);
+/* after initialisation: time the trial kernel with 1, 2, 4 interleaved tiles per workgroup on
+ * this device (dry runs: no control-block or iterate is modified) and keep the fastest; the
+ * ranking is device-dependent.  ZF_TILES_PER_WG=<n> in the environment pins it instead. */
+int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles);
 /* world > 1: the two halves of a step; the caller gathers pack_local -> pack_all between them */
 int zf_solver_enqueue_trial(zf_solver* s);
 int zf_solver_enqueue_decide(zf_solver* s);

@@ -149,10 +149,11 @@ def test_sharded_lockstep_matches_oracle(kw, world):
     seen = 0
     while status == _lib.ZF_RUNNING:
         chunk = 50
-        if kw["nesterov"] and seen + chunk > filled:
+        # factors for accepted counts <= seen + chunk: the last decide resolves the next trial's
+        if kw["nesterov"] and seen + chunk + 1 > filled:
             for s in solvers:
-                s.set_beta(filled, betas[filled:seen + chunk])
-            filled = seen + chunk
+                s.set_beta(filled, betas[filled:seen + chunk + 1])
+            filled = min(seen + chunk + 1, betas.size)
         for _ in range(chunk):
             for s in solvers:
                 s.enqueue_trial()

@@ -211,9 +211,10 @@ template <int U, int BS, int MASK> void run_c(const Bufs& B) {
     printf("contig U=%d BS=%4d mask=%2d grid=%6d : %7.3f ms  %7.1f GB/s\n", U, BS, MASK, grid, ms, 40.0 * B.n / ms / 1e6);
 }
 // the library's kernel itself (control block, in-launch reduction tail, rotating ring)
-template <bool NT> void run_lib(const Bufs& B, bool decide) {
+template <bool NT> void run_lib(const Bufs& B, bool decide, int T = 1) {
     const int64_t n2 = B.n / 2;
-    int grid = (int)((n2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS);
+    const int64_t nt_all = (n2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
+    int grid = (int)((nt_all + T - 1) / T);
     int ngroups = (grid + ZF_GROUP - 1) / ZF_GROUP;
     zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.world = 1; h.max_iter = 1 << 30;
     h.max_backtrack = 100; h.decay_rate = 0.5; h.tol_internal = 1e300; h.F_old = 1e300; h.nesterov = 1;
@@ -224,12 +225,140 @@ template <bool NT> void run_lib(const Bufs& B, bool decide) {
     CK(hipMalloc(&A.ws.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&A.ws.grp_part, 8 * ZF_NPART * ngroups));
     CK(hipMalloc(&A.ws.totals, 64)); A.ws.grp_cnt = cnt; A.ws.top_cnt = cnt + ngroups;
     A.ctl = ctl; A.beta_ring = beta; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c;
-    A.lam = 0.1; A.lo = 0; A.hi = 0; A.n = B.n;
+    A.lam = 0.1; A.lo = 0; A.hi = 0; A.n = B.n; A.tiles_per_wg = T;
     for (int k = 0; k < ZF_NPART; ++k) A.tail.scale[k] = 1.0;
     A.tail.pack = pack; A.tail.ctl_rw = decide ? ctl : nullptr; A.tail.trace = trace;
     double ms = time_ms([&] { hipLaunchKernelGGL((zf_trial_kernel<true, true, false, NT>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A); });
-    printf("LIB kernel nt=%d decide(rotating ring)=%d grid=%6d : %7.3f ms  %7.1f GB/s\n", (int)NT, (int)decide, grid, ms,
+    printf("LIB kernel nt=%d decide=%d T=%d grid=%6d : %7.3f ms  %7.1f GB/s\n", (int)NT, (int)decide, T, grid, ms,
            40.0 * B.n / ms / 1e6);
+}
+// staged copies of the library kernel's per-workgroup overheads (where do the 4-6 % go?)
+//   LEVEL 0: control-block scalar loads + ring selection, plain partial stores
+//   LEVEL 1: + wave 0 publishes sc1 and drains vmcnt before storing its x+ tile
+//   LEVEL 2: + returning ticket on the group counter, LDS flag, workgroup barrier
+template <int LEVEL>
+__global__ __launch_bounds__(ZF_BLOCK) void trial_dbg(zf_step_args A) {
+    __shared__ double lds[ZF_WAVES * 8 + 8];
+    __shared__ int s_flag;
+    if (A.ctl->status != ZF_RUNNING) return;
+    const int cur = A.ctl->cur;
+    const double lr = A.ctl->lr, beta = A.ctl->beta_next, tau = A.lam * lr;
+    const zf_d2* xk2 = (const zf_d2*)A.xb[cur]; const zf_d2* xo2 = (const zf_d2*)A.xb[(cur + 2) % 3];
+    zf_d2* xn2 = (zf_d2*)A.xb[(cur + 1) % 3];
+    const zf_d2* p02 = (const zf_d2*)A.p0; const zf_d2* p12 = (const zf_d2*)A.p1;
+    zf_elem_acc acc = {0, 0, 0, 0, 0, 0};
+    const int64_t base = (int64_t)blockIdx.x * ZF_TILE_UNITS + threadIdx.x;
+    zf_d2 a[4], o[4], q[4], cc[4], r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int64_t i = base + u * ZF_BLOCK; a[u] = xk2[i]; o[u] = xo2[i];
+        q[u] = zf_ld2<true>(p02 + i); cc[u] = zf_ld2<true>(p12 + i); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        r[u].x = zf_elem_diag<true, false>(a[u].x, o[u].x, q[u].x, cc[u].x, beta, lr, tau, 0, 0, acc);
+        r[u].y = zf_elem_diag<true, false>(a[u].y, o[u].y, q[u].y, cc[u].y, beta, lr, tau, 0, 0, acc);
+    }
+    const double sums[5] = {acc.fy, acc.dot, acc.ss, acc.l1, acc.fx};
+    const double maxs[1] = {acc.mx};
+    double mine = 0.0;
+    zf_block_reduce<5, 1, ZF_WAVES>(sums, maxs, lds, mine);
+    if (LEVEL == 0) {
+        if (threadIdx.x < ZF_NPART) A.ws.blk_part[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = mine;
+    } else if (threadIdx.x < 64) {
+        if (threadIdx.x < ZF_NPART) zf_publish(A.ws.blk_part + (int64_t)threadIdx.x * gridDim.x + blockIdx.x, mine);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (LEVEL >= 2 && threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(A.ws.grp_cnt + blockIdx.x / ZF_GROUP, 1u, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+            s_flag = (t == 0xffffffffu);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) zf_st2<true>(xn2 + base + u * ZF_BLOCK, r[u]);
+    if (LEVEL >= 2) {
+        __syncthreads();
+        if (s_flag) A.ws.totals[0] = 1.0;
+    }
+}
+// LEVEL 2 structure, but a workgroup owns T tiles (consecutive when INTERLEAVE = 0, else b, b+G, ...)
+// and takes ONE ticket after the last tile
+template <int T, int INTERLEAVE>
+__global__ __launch_bounds__(ZF_BLOCK) void trial_multi(zf_step_args A, int64_t ntiles) {
+    __shared__ double lds[ZF_WAVES * 8 + 8];
+    __shared__ int s_flag;
+    if (A.ctl->status != ZF_RUNNING) return;
+    const int cur = A.ctl->cur;
+    const double lr = A.ctl->lr, beta = A.ctl->beta_next, tau = A.lam * lr;
+    const zf_d2* xk2 = (const zf_d2*)A.xb[cur]; const zf_d2* xo2 = (const zf_d2*)A.xb[(cur + 2) % 3];
+    zf_d2* xn2 = (zf_d2*)A.xb[(cur + 1) % 3];
+    const zf_d2* p02 = (const zf_d2*)A.p0; const zf_d2* p12 = (const zf_d2*)A.p1;
+    zf_elem_acc acc = {0, 0, 0, 0, 0, 0};
+    zf_d2 r[4];
+    int64_t last_base = -1;
+    for (int t = 0; t < T; ++t) {
+        const int64_t tile = INTERLEAVE ? ((int64_t)t * gridDim.x + blockIdx.x) : ((int64_t)blockIdx.x * T + t);
+        if (tile >= ntiles) break;
+        if (last_base >= 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) zf_st2<true>(xn2 + last_base + u * ZF_BLOCK, r[u]);
+        }
+        const int64_t base = tile * ZF_TILE_UNITS + threadIdx.x;
+        zf_d2 a[4], o[4], q[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int64_t i = base + u * ZF_BLOCK; a[u] = xk2[i]; o[u] = xo2[i];
+            q[u] = zf_ld2<true>(p02 + i); cc[u] = zf_ld2<true>(p12 + i); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            r[u].x = zf_elem_diag<true, false>(a[u].x, o[u].x, q[u].x, cc[u].x, beta, lr, tau, 0, 0, acc);
+            r[u].y = zf_elem_diag<true, false>(a[u].y, o[u].y, q[u].y, cc[u].y, beta, lr, tau, 0, 0, acc);
+        }
+        last_base = base;
+    }
+    const double sums[5] = {acc.fy, acc.dot, acc.ss, acc.l1, acc.fx};
+    const double maxs[1] = {acc.mx};
+    double mine = 0.0;
+    zf_block_reduce<5, 1, ZF_WAVES>(sums, maxs, lds, mine);
+    if (threadIdx.x < 64) {
+        if (threadIdx.x < ZF_NPART) zf_publish(A.ws.blk_part + (int64_t)threadIdx.x * gridDim.x + blockIdx.x, mine);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(A.ws.grp_cnt + blockIdx.x / ZF_GROUP, 1u, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+            s_flag = (t == 0xffffffffu);
+        }
+    }
+    if (last_base >= 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) zf_st2<true>(xn2 + last_base + u * ZF_BLOCK, r[u]);
+    }
+    __syncthreads();
+    if (s_flag) A.ws.totals[0] = 1.0;
+}
+template <int T, int INTERLEAVE> void run_multi(const Bufs& B) {
+    const int64_t ntiles = (B.n / 2) / ZF_TILE_UNITS;
+    int grid = (int)((ntiles + T - 1) / T);
+    int ngroups = (grid + ZF_GROUP - 1) / ZF_GROUP;
+    zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.beta_next = 0.3;
+    zf_control* ctl; CK(hipMalloc(&ctl, sizeof(h))); CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+    unsigned* cnt; zf_step_args A;
+    CK(hipMalloc(&cnt, 4 * (ngroups + 16))); CK(hipMemset(cnt, 0, 4 * (ngroups + 16)));
+    CK(hipMalloc(&A.ws.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&A.ws.totals, 64)); A.ws.grp_cnt = cnt;
+    A.ctl = ctl; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c; A.lam = 0.1; A.n = B.n;
+    double ms = time_ms([&] { hipLaunchKernelGGL((trial_multi<T, INTERLEAVE>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A, ntiles); });
+    printf("multi-tile T=%d interleave=%d grid=%6d : %7.3f ms  %7.1f GB/s\n", T, INTERLEAVE, grid, ms, 40.0 * B.n / ms / 1e6);
+}
+template <int LEVEL> void run_dbg(const Bufs& B) {
+    const int64_t n2 = B.n / 2;
+    int grid = (int)(n2 / ZF_TILE_UNITS);   // full tiles only
+    int ngroups = (grid + ZF_GROUP - 1) / ZF_GROUP;
+    zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.beta_next = 0.3;
+    zf_control* ctl; CK(hipMalloc(&ctl, sizeof(h))); CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+    unsigned* cnt; zf_step_args A;
+    CK(hipMalloc(&cnt, 4 * (ngroups + 16))); CK(hipMemset(cnt, 0, 4 * (ngroups + 16)));
+    CK(hipMalloc(&A.ws.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&A.ws.totals, 64)); A.ws.grp_cnt = cnt;
+    A.ctl = ctl; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c; A.lam = 0.1; A.n = B.n; A.tiles_per_wg = 1;
+    double ms = time_ms([&] { hipLaunchKernelGGL((trial_dbg<LEVEL>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A); });
+    printf("staged LEVEL %d grid=%6d : %7.3f ms  %7.1f GB/s\n", LEVEL, grid, ms, 40.0 * B.n / ms / 1e6);
 }
 template <int U, int BS, int MASK, bool PF> void run_p(const Bufs& B, int grid) {
     double ms = time_ms([&] { hipLaunchKernelGGL((trial_p<U, BS, MASK, PF>), dim3(grid), dim3(BS), 0, 0, B.xk, B.xo, B.d, B.c,
@@ -260,9 +389,12 @@ int main(int argc, char** argv) {
     const int64_t n2 = B.n / 2;
     auto full = [&](int U, int BS) { return (int)((n2 + (int64_t)U * BS - 1) / ((int64_t)U * BS)); };
     printf("n = %lld\n", (long long)B.n);
-    run_c<4, 256, 9>(B);
-    run_lib<true>(B, true); run_lib<true>(B, false); run_lib<false>(B, true);
-    run_c<4, 256, 9>(B);
-    run_lib<true>(B, true);
+    for (int rep = 0; rep < 2; ++rep) {
+        run_c<4, 256, 9>(B);
+        run_dbg<0>(B); run_dbg<2>(B);
+        run_multi<1, 0>(B); run_multi<2, 0>(B); run_multi<4, 0>(B); run_multi<8, 0>(B);
+        run_multi<2, 1>(B); run_multi<4, 1>(B); run_multi<8, 1>(B);
+        run_lib<true>(B, true, 1); run_lib<true>(B, true, 2); run_lib<true>(B, true, 4);
+    }
     return 0;
 }

@@ -44,7 +44,7 @@ class Control(C.Structure):
         ("max_backtrack", C.c_int64), ("total_trials", C.c_int64),
         ("status", C.c_int32), ("cur", C.c_int32), ("nesterov", C.c_int32),
         ("deprecated", C.c_int32), ("need_grad", C.c_int32), ("world", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("beta_next", C.c_double),
     ]
 
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "zf_solver_enqueue_init_commit": (C.c_int, [_P]),
     "zf_solver_set_beta": (C.c_int, [_P, C.c_int64, _P, C.c_int64]),
     "zf_solver_enqueue_steps": (C.c_int, [_P, C.c_int64]),
+    "zf_solver_autotune": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "zf_solver_enqueue_trial": (C.c_int, [_P]),
     "zf_solver_enqueue_decide": (C.c_int, [_P]),
     "zf_solver_pack_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),

@@ -42,7 +42,10 @@ ZF_HD inline void zf_reduce_packs(const double* packs, int world, double* out) {
     }
 }
 
-ZF_HD inline void zf_decide_step(zf_control* c, const double* packs, double* trace) {
+// beta_ring (may be NULL on the host): momentum ring indexed by the accepted-iteration count;
+// on acceptance the factor of the NEXT trial is copied into the control block.
+ZF_HD inline void zf_decide_step(zf_control* c, const double* packs, double* trace,
+                                 const double* beta_ring = nullptr) {
     if (c->status != ZF_RUNNING) return;
     double pk[ZF_PACK_LEN];
     zf_reduce_packs(packs, c->world, pk);
@@ -89,6 +92,7 @@ ZF_HD inline void zf_decide_step(zf_control* c, const double* packs, double* tra
     c->trial = 0;
     c->cur = (c->cur + 1) % 3;   // x+ becomes x_k; old x_k becomes x_{k-1} (:538)
     c->need_grad = 1;
+    if (beta_ring) c->beta_next = beta_ring[nit % ZF_RING];   // y_{k+1} = x_k + beta (x_k - x_{k-1})  :533-534
     if (err < c->tol) c->status = ZF_CONVERGED;               // :525
     else if (nit >= c->max_iter) c->status = ZF_MAXITER;      // :539
 }

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(RESID_BLOCK) void zf_resid_y_kernel(const zf_contro
     __shared__ double lds[RESID_BLOCK / 64];
     if (ctl->status != ZF_RUNNING || !ctl->need_grad) return;
     const int cur = ctl->cur;
-    const double beta = nesterov ? beta_ring[ctl->nit % ZF_RING] : 0.0;
+    const double beta = nesterov ? ctl->beta_next : 0.0;
+    (void)beta_ring;
     const double* __restrict__ sk = sr.p[cur];
     const double* __restrict__ so = sr.p[(cur + 2) % 3];
     double acc = 0.0;

@@ -96,7 +96,8 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
 // device-dependent, up to 9 % slower than one workgroup per tile.
 // ---------------------------------------------------------------------------
 constexpr int ZF_TILE_U = 4;
-constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per workgroup
+constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per tile
+constexpr int ZF_MAX_TILES_PER_WG = 8;                // upper bound of zf_step_args.tiles_per_wg
 constexpr int ZF_GROUP = 64;                          // workgroups per reduction group
 
 typedef double zf_d2 __attribute__((ext_vector_type(2)));
@@ -139,6 +140,7 @@ struct zf_step_args {
     const double* p1;         // diag: c        vec: unused
     double lam, lo, hi;
     int64_t n;
+    int tiles_per_wg;         // interleaved tiles per workgroup (1 .. ZF_MAX_TILES_PER_WG)
     zf_reduce_ws ws;
     zf_tail_args tail;
 };
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     if (status != ZF_RUNNING) return;
     const int cur = A.ctl->cur;
     const double lr = A.ctl->lr;
-    const double beta = NESTEROV ? A.beta_ring[A.ctl->nit % ZF_RING] : 0.0;
+    const double beta = NESTEROV ? A.ctl->beta_next : 0.0;   // same cache line as status / cur / lr
     const double tau = A.lam * lr;   // oracle: soft_threshold(x, lam * weight)
     const double* __restrict__ xk = A.xb[cur];
     const double* __restrict__ xo = A.xb[(cur + 2) % 3];
@@ -264,54 +266,75 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     const zf_d2* __restrict__ p12 = reinterpret_cast<const zf_d2*>(p1);
     zf_d2* __restrict__ xn2 = reinterpret_cast<zf_d2*>(xn);
 
-    const int64_t base = (int64_t)blockIdx.x * ZF_TILE_UNITS + threadIdx.x;
-    const bool full_tile = base - threadIdx.x + ZF_TILE_UNITS <= n2;   // workgroup-uniform
+    // Workgroup b owns tiles b, b + G, b + 2G, ... (G = gridDim.x, A.tiles_per_wg of them):
+    // interleaved, so that at any time the resident workgroups still cover one contiguous window
+    // of every stream (consecutive tiles per workgroup measured 4-8 % slower), while the
+    // per-workgroup costs - block reduction, publish, ticket - are paid once per T tiles.
+    // Which T wins is device-dependent (T = 4: -1 % on some MI355X boxes, +7 % on others, against
+    // T = 1), so the solver measures it once at initialisation (zf_solver_autotune).
+    const int64_t ntiles = (n2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
+    const int64_t G = gridDim.x;
     zf_d2 r[ZF_TILE_U];
-    if (full_tile) {
-        zf_d2 a[ZF_TILE_U], o[ZF_TILE_U], q[ZF_TILE_U], cc[ZF_TILE_U];
+    int64_t deferred_base = -1;   // the last full tile's x+ stays in registers until after the ticket
+    for (int t = 0; t < A.tiles_per_wg; ++t) {
+        const int64_t tile = (int64_t)t * G + blockIdx.x;
+        if (tile >= ntiles) break;
+        if (deferred_base >= 0) {
 #pragma unroll
-        for (int u = 0; u < ZF_TILE_U; ++u) {
-            const int64_t i = base + u * ZF_BLOCK;
-            a[u] = xk2[i];
-            o[u] = a[u];
-            if (NESTEROV) o[u] = xo2[i];
-            q[u] = zf_ld2<NT>(p02 + i);
-            cc[u] = q[u];
-            if (GRAD_INLINE) cc[u] = zf_ld2<NT>(p12 + i);
+            for (int u = 0; u < ZF_TILE_U; ++u) zf_st2<NT>(xn2 + deferred_base + u * ZF_BLOCK, r[u]);
+            deferred_base = -1;
         }
+        const int64_t base = tile * ZF_TILE_UNITS + threadIdx.x;
+        if ((tile + 1) * ZF_TILE_UNITS <= n2) {   // full tile (workgroup-uniform)
+            zf_d2 a[ZF_TILE_U], o[ZF_TILE_U], q[ZF_TILE_U], cc[ZF_TILE_U];
 #pragma unroll
-        for (int u = 0; u < ZF_TILE_U; ++u) {
-            if (GRAD_INLINE) {
-                r[u].x = zf_elem_diag<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, cc[u].x, beta, lr, tau, A.lo, A.hi, acc);
-                r[u].y = zf_elem_diag<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, cc[u].y, beta, lr, tau, A.lo, A.hi, acc);
-            } else {
-                r[u].x = zf_elem_vec<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, beta, lr, tau, A.lo, A.hi, acc);
-                r[u].y = zf_elem_vec<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, beta, lr, tau, A.lo, A.hi, acc);
+            for (int u = 0; u < ZF_TILE_U; ++u) {
+                const int64_t i = base + u * ZF_BLOCK;
+                a[u] = xk2[i];
+                o[u] = a[u];
+                if (NESTEROV) o[u] = xo2[i];
+                q[u] = zf_ld2<NT>(p02 + i);
+                cc[u] = q[u];
+                if (GRAD_INLINE) cc[u] = zf_ld2<NT>(p12 + i);
             }
-        }
-    } else {
-        // ragged last tile: stored at once (at most one workgroup per launch)
-        for (int u = 0; u < ZF_TILE_U; ++u) {
-            const int64_t i = base + u * ZF_BLOCK;
-            if (i < n2) {
-                const zf_d2 a0 = xk2[i];
-                const zf_d2 o0 = NESTEROV ? xo2[i] : a0;
-                const zf_d2 q0 = p02[i];
-                const zf_d2 c0 = GRAD_INLINE ? p12[i] : q0;
-                zf_d2 r0;
+            // keep all 16 loads of the tile in flight: without this fence the scheduler sinks the
+            // last four below the first arithmetic to save registers
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < ZF_TILE_U; ++u) {
                 if (GRAD_INLINE) {
-                    r0.x = zf_elem_diag<NESTEROV, BOX>(a0.x, o0.x, q0.x, c0.x, beta, lr, tau, A.lo, A.hi, acc);
-                    r0.y = zf_elem_diag<NESTEROV, BOX>(a0.y, o0.y, q0.y, c0.y, beta, lr, tau, A.lo, A.hi, acc);
+                    r[u].x = zf_elem_diag<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, cc[u].x, beta, lr, tau, A.lo, A.hi, acc);
+                    r[u].y = zf_elem_diag<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, cc[u].y, beta, lr, tau, A.lo, A.hi, acc);
                 } else {
-                    r0.x = zf_elem_vec<NESTEROV, BOX>(a0.x, o0.x, q0.x, beta, lr, tau, A.lo, A.hi, acc);
-                    r0.y = zf_elem_vec<NESTEROV, BOX>(a0.y, o0.y, q0.y, beta, lr, tau, A.lo, A.hi, acc);
+                    r[u].x = zf_elem_vec<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, beta, lr, tau, A.lo, A.hi, acc);
+                    r[u].y = zf_elem_vec<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, beta, lr, tau, A.lo, A.hi, acc);
                 }
-                xn2[i] = r0;
+            }
+            deferred_base = base;
+        } else {
+            // ragged last tile of the vector: stored at once (one workgroup per launch)
+            for (int u = 0; u < ZF_TILE_U; ++u) {
+                const int64_t i = base + u * ZF_BLOCK;
+                if (i < n2) {
+                    const zf_d2 a0 = xk2[i];
+                    const zf_d2 o0 = NESTEROV ? xo2[i] : a0;
+                    const zf_d2 q0 = p02[i];
+                    const zf_d2 c0 = GRAD_INLINE ? p12[i] : q0;
+                    zf_d2 r0;
+                    if (GRAD_INLINE) {
+                        r0.x = zf_elem_diag<NESTEROV, BOX>(a0.x, o0.x, q0.x, c0.x, beta, lr, tau, A.lo, A.hi, acc);
+                        r0.y = zf_elem_diag<NESTEROV, BOX>(a0.y, o0.y, q0.y, c0.y, beta, lr, tau, A.lo, A.hi, acc);
+                    } else {
+                        r0.x = zf_elem_vec<NESTEROV, BOX>(a0.x, o0.x, q0.x, beta, lr, tau, A.lo, A.hi, acc);
+                        r0.y = zf_elem_vec<NESTEROV, BOX>(a0.y, o0.y, q0.y, beta, lr, tau, A.lo, A.hi, acc);
+                    }
+                    xn2[i] = r0;
+                }
             }
         }
     }
-    // odd trailing element (n odd): last workgroup
-    if ((n & 1) && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    // odd trailing element (n odd): workgroup 0
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t t = n - 1;
         const double xo_t = NESTEROV ? xo[t] : xk[t];
         if (GRAD_INLINE)
@@ -324,12 +347,12 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     const double maxs[1] = {acc.mx};
     double mine = 0.0;
     zf_block_reduce<5, 1, ZF_WAVES>(sums, maxs, lds, mine);
-    // wave 0 publishes the partials and takes the ticket while its x+ tile is still in
-    // registers; waves 1-3 stream their x+ out meanwhile
+    // wave 0 publishes the partials and takes the ticket while its last x+ tile is still in
+    // registers; waves 1-3 stream theirs out meanwhile
     if (threadIdx.x < 64) zf_publish_and_ticket(A.ws, mine, &s_flag);
-    if (full_tile) {
+    if (deferred_base >= 0) {
 #pragma unroll
-        for (int u = 0; u < ZF_TILE_U; ++u) zf_st2<NT>(xn2 + base + u * ZF_BLOCK, r[u]);
+        for (int u = 0; u < ZF_TILE_U; ++u) zf_st2<NT>(xn2 + deferred_base + u * ZF_BLOCK, r[u]);
     }
     __syncthreads();
     if (!s_flag) return;
@@ -345,7 +368,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
         pack[ZF_PK_ERR] = totals[5];
         pack[6] = 0.0;
         pack[7] = 0.0;
-        if (A.tail.ctl_rw) zf_decide_step(A.tail.ctl_rw, pack, A.tail.trace);
+        if (A.tail.ctl_rw) zf_decide_step(A.tail.ctl_rw, pack, A.tail.trace, A.beta_ring);
     }
 }
 

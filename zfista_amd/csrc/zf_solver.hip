@@ -39,7 +39,8 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_sum_parts_kernel(const zf_control
 }
 
 __global__ void zf_ls_pack_kernel(zf_control* ctl, const double* totals, const double* ls_scal, double lam,
-                                  double* pack, double* trace, int decide, int contribute_f) {
+                                  double* pack, double* trace, int decide, int contribute_f,
+                                  const double* beta_ring) {
     if (threadIdx.x || blockIdx.x) return;
     if (ctl->status != ZF_RUNNING) return;
     pack[ZF_PK_FY] = contribute_f ? ls_scal[0] : 0.0;
@@ -50,11 +51,16 @@ __global__ void zf_ls_pack_kernel(zf_control* ctl, const double* totals, const d
     pack[ZF_PK_ERR] = totals[5];
     pack[6] = 0.0;
     pack[7] = 0.0;
-    if (decide) zf_decide_step(ctl, pack, trace);
+    if (decide) zf_decide_step(ctl, pack, trace, beta_ring);
 }
 
-__global__ void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) zf_decide_step(ctl, packs, trace);
+__global__ void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace, const double* beta_ring) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) zf_decide_step(ctl, packs, trace, beta_ring);
+}
+
+// after the host refilled the momentum ring: re-resolve the factor of the pending trial
+__global__ void zf_refresh_beta_kernel(zf_control* ctl, const double* beta_ring) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctl->beta_next = beta_ring[ctl->nit % ZF_RING];
 }
 
 // initial F(x0): partials [f raw, |x|_1, violations] -> init pack [f, g, 0...]
@@ -129,6 +135,9 @@ struct zf_solver {
     bool initialised = false;
     bool own_packs = true;
     bool gemv_mfma = false;       // A^T r on v_mfma_f64_16x16x4 (n % 32 == 0; ZF_GEMV_MFMA=0 disables)
+    int64_t ntiles = 1;           // 16 KiB tiles of the trial kernel
+    int tiles = 1;                // interleaved tiles per workgroup (zf_solver_autotune picks it)
+    int max_grid = 1;
     // trial-kernel timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -180,13 +189,15 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     const int64_t n = desc->n;
     const int64_t n_pad = (n + 63) & ~int64_t(63);   // keep every ring buffer 512-B aligned
     {   // one workgroup per tile of ZF_TILE_UNITS 16-byte units (zf_kernels_step.h)
-        int64_t nb = (n / 2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
-        if (nb < 1) nb = 1;
-        if (nb > 0x7fffffff) {
+        int64_t ntiles = (n / 2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
+        if (ntiles < 1) ntiles = 1;
+        if (ntiles > 0x7fffffff) {
             delete s;
             return zf_fail(ZF_ERR_ARG, "zf_solver_create: n too large for one rank");
         }
-        s->grid = (int)nb;
+        s->ntiles = ntiles;
+        s->grid = (int)ntiles;            // tiles_per_wg = 1: the largest grid; buffers are sized for it
+        s->max_grid = s->grid;
     }
     const char* nt_env = getenv("ZF_NT");
     if (nt_env) s->nt = atoi(nt_env) != 0;
@@ -274,7 +285,7 @@ static void zf_launch_trial_t(zf_solver* s, const zf_step_args& a) {
     else zf_launch_trial_t2<GI, false>(s, a);
 }
 
-static int zf_launch_trial(zf_solver* s, bool decide_in_launch) {
+static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false) {
     const zf_problem_desc& d = s->desc;
     zf_step_args a;
     a.ctl = s->ctl;
@@ -284,6 +295,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch) {
     a.lo = d.box_lo;
     a.hi = d.box_hi;
     a.n = d.n;
+    a.tiles_per_wg = s->tiles;
     a.ws = s->ws;
     for (int k = 0; k < ZF_NPART; ++k) a.tail.scale[k] = 1.0;
     a.tail.scale[3] = d.lam;        // g = lam * sum|x|
@@ -293,8 +305,8 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch) {
     if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
         a.tail.scale[0] = 0.5;      // f = 0.5 * sum(d (x-c)^2)
         a.tail.scale[4] = 0.5;
-        a.tail.pack = s->pack_local;
-        if (d.world == 1 && decide_in_launch) a.tail.ctl_rw = s->ctl;
+        if (!dry) a.tail.pack = s->pack_local;   // dry (autotune probe): totals only, no pack, no decide
+        if (!dry && d.world == 1 && decide_in_launch) a.tail.ctl_rw = s->ctl;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing) {
@@ -360,7 +372,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch) {
             hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1,
                                d.b, d.scale, m, s->ls_scal + 1);
             hipLaunchKernelGGL(zf_ls_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->ws.totals,
-                               s->ls_scal, d.lam, s->pack_local, s->trace, (int)decide_in_launch, 1);
+                               s->ls_scal, d.lam, s->pack_local, s->trace, (int)decide_in_launch, 1, s->beta_ring);
         }
     }
     ZF_HIP(hipGetLastError());
@@ -379,7 +391,7 @@ extern "C" int zf_solver_enqueue_trial_finish(zf_solver* s) {
     hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1, d.b,
                        d.scale, m, s->ls_scal + 1);
     hipLaunchKernelGGL(zf_ls_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->ws.totals, s->ls_scal, d.lam,
-                       s->pack_local, s->trace, 0, (int)(d.rank == 0));
+                       s->pack_local, s->trace, 0, (int)(d.rank == 0), s->beta_ring);
     ZF_HIP(hipGetLastError());
     return ZF_OK;
 }
@@ -536,6 +548,8 @@ extern "C" int zf_solver_set_beta(zf_solver* s, int64_t first, const double* bet
                               hipMemcpyHostToDevice, s->stream));
         done += len;
     }
+    hipLaunchKernelGGL(zf_refresh_beta_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->beta_ring);
+    ZF_HIP(hipGetLastError());
     ZF_HIP(hipStreamSynchronize(s->stream));   // beta_host may be reused by the caller
     return ZF_OK;
 }
@@ -547,7 +561,8 @@ extern "C" int zf_solver_enqueue_trial(zf_solver* s) {
 
 extern "C" int zf_solver_enqueue_decide(zf_solver* s) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_decide: solver not initialised");
-    hipLaunchKernelGGL(zf_decide_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, s->trace);
+    hipLaunchKernelGGL(zf_decide_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, s->trace,
+                       s->beta_ring);
     ZF_HIP(hipGetLastError());
     return ZF_OK;
 }
@@ -560,6 +575,62 @@ extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
         int rc = zf_launch_trial(s, true);
         if (rc) return rc;
     }
+    return ZF_OK;
+}
+
+static void zf_set_tiles(zf_solver* s, int tiles) {
+    if (tiles < 1) tiles = 1;
+    if (tiles > ZF_MAX_TILES_PER_WG) tiles = ZF_MAX_TILES_PER_WG;
+    s->tiles = tiles;
+    s->grid = (int)((s->ntiles + tiles - 1) / tiles);
+}
+
+// Measure the trial kernel with 1, 2 and 4 interleaved tiles per workgroup on THIS device and
+// keep the fastest: the ranking differs between MI355X boxes (tools/tune_trial.hip: T = 4 is
+// 1 % faster than T = 1 on some, 7 % slower on others).  The probe launches are dry runs of the
+// pending trial: they write only the scratch x+ buffer and the reduction workspace (re-armed by
+// the kernel itself), never the control block.  Synchronises the stream.
+extern "C" int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles) {
+    ZF_REQUIRE(s && s->initialised, "zf_solver_autotune: solver not initialised");
+    const char* env = getenv("ZF_TILES_PER_WG");
+    if (env) {
+        zf_set_tiles(s, atoi(env));
+    } else if (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->ntiles >= 4096) {
+        // (below ~64 MB per stream the launch is latency-, not bandwidth-bound: keep T = 1)
+        const int cand[3] = {1, 2, 4};
+        double best = 1e300;
+        int best_t = 1;
+        hipEvent_t e0, e1;
+        ZF_HIP(hipEventCreate(&e0));
+        ZF_HIP(hipEventCreate(&e1));
+        const bool timing = s->timing;
+        s->timing = false;
+        for (int c = 0; c < 3; ++c) {
+            zf_set_tiles(s, cand[c]);
+            double t_min = 1e300;
+            for (int rep = 0; rep < 7; ++rep) {   // first repetition warms up
+                ZF_HIP(hipEventRecord(e0, s->stream));
+                int rc = zf_launch_trial(s, false, /*dry=*/true);
+                if (rc) return rc;
+                ZF_HIP(hipEventRecord(e1, s->stream));
+                ZF_HIP(hipEventSynchronize(e1));
+                float ms = 0.f;
+                ZF_HIP(hipEventElapsedTime(&ms, e0, e1));
+                if (rep > 0 && ms < t_min) t_min = ms;
+            }
+            if (getenv("ZF_AUTOTUNE_VERBOSE"))
+                fprintf(stderr, "[zf autotune] tiles_per_wg=%d  trial kernel %.4f ms\n", cand[c], t_min);
+            if (t_min < best * 0.995) {   // prefer the smaller T unless clearly faster
+                best = t_min;
+                best_t = cand[c];
+            }
+        }
+        s->timing = timing;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        zf_set_tiles(s, best_t);
+    }
+    if (chosen_tiles) *chosen_tiles = s->tiles;
     return ZF_OK;
 }
 

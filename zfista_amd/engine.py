@@ -144,6 +144,11 @@ class DeviceSolver:
             self.init_finish()
             self._gather()
         self.init_commit()
+        self.tiles_per_wg = 1
+        if os.environ.get("ZF_AUTOTUNE", "1") != "0":
+            t = C.c_int32(1)
+            _lib.check(self.lib.zf_solver_autotune(self.handle, C.byref(t)), "autotune")
+            self.tiles_per_wg = int(t.value)
 
     def set_beta(self, first: int, betas: np.ndarray):
         betas = np.ascontiguousarray(betas, dtype=np.float64)

@@ -146,14 +146,15 @@ class NativeRun:
     def advance(self, steps):
         """Enqueue ``steps`` trials, then synchronise.  Returns the trace rows of
         the iterations accepted meanwhile (array [k, ZF_TRACE_COLS])."""
-        steps = int(min(steps, _lib.ZF_RING))
-        self._fill_beta(self.nit_seen + steps)
+        steps = int(min(steps, _lib.ZF_RING - 1))
+        # + 1: the decide step of the last trial resolves the factor of the trial after it
+        self._fill_beta(self.nit_seen + steps + 1)
         self.solver.enqueue(steps)
         return self.collect()
 
     def enqueue_only(self, steps):
-        steps = int(min(steps, _lib.ZF_RING))
-        self._fill_beta(self.nit_seen + steps)
+        steps = int(min(steps, _lib.ZF_RING - 1))
+        self._fill_beta(self.nit_seen + steps + 1)
         self.solver.enqueue(steps)
 
     def collect(self):
