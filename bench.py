@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=N_PER_GPU, help="elements per GPU (default 1e8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket every trial kernel with HIP events (roofline becomes null); "
+                         "shows what the per-kernel timing itself costs")
     args = ap.parse_args()
 
     # Only the JSON line may reach stdout: libraries (RCCL prints "Hostname : ..." banners at
@@ -125,7 +128,7 @@ def main():
     prob = DiagQuadL1(d, c, LAM, group=group)
     opts = dict(lr=LR, tol=0.0, tol_internal=1e-12, max_iter=K + W, max_backtrack_iter=100, decay_rate=0.5,
                 nesterov=True, nesterov_ratio=(0, 0.25), deprecated=False)
-    run = NativeRun(prob, torch.zeros(n, dtype=torch.float64, device="cuda"), opts, timing=True)
+    run = NativeRun(prob, torch.zeros(n, dtype=torch.float64, device="cuda"), opts, timing=not args.no_kernel_events)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -148,8 +151,10 @@ def main():
     dt = time.perf_counter() - t0
     assert run.nit_seen - nit0 == K, f"expected {K} accepted iterations, got {run.nit_seen - nit0}"
     ker_ms, ker_n = run.solver.trial_kernel_ms()
+    if args.no_kernel_events:
+        ker_ms, ker_n = float("nan"), int(run.solver.ctl.total_trials)
     assert ker_n >= K
-    trials_per_iter = ker_n / K
+    trials_per_iter = None if args.no_kernel_events else ker_n / K
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")

@@ -10,6 +10,20 @@
 #include "../zfista_amd/csrc/zf_kernels_step.h"
 
 thread_local char zf_errbuf[512] = "";
+
+// argument block of the experiment kernels below (the library's zf_step_args only carries
+// what the shipped kernel needs)
+constexpr int ZF_GROUP = 64;   // (experiments) workgroups per ticket group
+struct tune_ws { double* blk_part; unsigned* grp_cnt; double* totals; };
+struct tune_args {
+    const zf_control* ctl;
+    double* xb[3];
+    const double* p0;
+    const double* p1;
+    double lam;
+    int64_t n;
+    tune_ws ws;
+};
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
 template <bool NT> __device__ __forceinline__ double2 ld2(const double2* p) {
@@ -210,34 +224,12 @@ template <int U, int BS, int MASK> void run_c(const Bufs& B) {
                                                  B.xn, 0.3, 0.45, 0.1, B.n, B.partials); });
     printf("contig U=%d BS=%4d mask=%2d grid=%6d : %7.3f ms  %7.1f GB/s\n", U, BS, MASK, grid, ms, 40.0 * B.n / ms / 1e6);
 }
-// the library's kernel itself (control block, in-launch reduction tail, rotating ring)
-template <bool NT> void run_lib(const Bufs& B, bool decide, int T = 1) {
-    const int64_t n2 = B.n / 2;
-    const int64_t nt_all = (n2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
-    int grid = (int)((nt_all + T - 1) / T);
-    int ngroups = (grid + ZF_GROUP - 1) / ZF_GROUP;
-    zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.world = 1; h.max_iter = 1 << 30;
-    h.max_backtrack = 100; h.decay_rate = 0.5; h.tol_internal = 1e300; h.F_old = 1e300; h.nesterov = 1;
-    zf_control* ctl; CK(hipMalloc(&ctl, sizeof(h))); CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
-    double *beta, *trace, *pack; unsigned* cnt; zf_step_args A;
-    CK(hipMalloc(&beta, 8 * ZF_RING)); CK(hipMemset(beta, 0, 8 * ZF_RING)); CK(hipMalloc(&trace, 8 * ZF_RING * 8));
-    CK(hipMalloc(&pack, 64)); CK(hipMalloc(&cnt, 4 * (ngroups + 16))); CK(hipMemset(cnt, 0, 4 * (ngroups + 16)));
-    CK(hipMalloc(&A.ws.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&A.ws.grp_part, 8 * ZF_NPART * ngroups));
-    CK(hipMalloc(&A.ws.totals, 64)); A.ws.grp_cnt = cnt; A.ws.top_cnt = cnt + ngroups;
-    A.ctl = ctl; A.beta_ring = beta; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c;
-    A.lam = 0.1; A.lo = 0; A.hi = 0; A.n = B.n; A.tiles_per_wg = T;
-    for (int k = 0; k < ZF_NPART; ++k) A.tail.scale[k] = 1.0;
-    A.tail.pack = pack; A.tail.ctl_rw = decide ? ctl : nullptr; A.tail.trace = trace;
-    double ms = time_ms([&] { hipLaunchKernelGGL((zf_trial_kernel<true, true, false, NT>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A); });
-    printf("LIB kernel nt=%d decide=%d T=%d grid=%6d : %7.3f ms  %7.1f GB/s\n", (int)NT, (int)decide, T, grid, ms,
-           40.0 * B.n / ms / 1e6);
-}
 // staged copies of the library kernel's per-workgroup overheads (where do the 4-6 % go?)
 //   LEVEL 0: control-block scalar loads + ring selection, plain partial stores
 //   LEVEL 1: + wave 0 publishes sc1 and drains vmcnt before storing its x+ tile
 //   LEVEL 2: + returning ticket on the group counter, LDS flag, workgroup barrier
 template <int LEVEL>
-__global__ __launch_bounds__(ZF_BLOCK) void trial_dbg(zf_step_args A) {
+__global__ __launch_bounds__(ZF_BLOCK) void trial_dbg(tune_args A) {
     __shared__ double lds[ZF_WAVES * 8 + 8];
     __shared__ int s_flag;
     if (A.ctl->status != ZF_RUNNING) return;
@@ -282,7 +274,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void trial_dbg(zf_step_args A) {
 // LEVEL 2 structure, but a workgroup owns T tiles (consecutive when INTERLEAVE = 0, else b, b+G, ...)
 // and takes ONE ticket after the last tile
 template <int T, int INTERLEAVE>
-__global__ __launch_bounds__(ZF_BLOCK) void trial_multi(zf_step_args A, int64_t ntiles) {
+__global__ __launch_bounds__(ZF_BLOCK) void trial_multi(tune_args A, int64_t ntiles) {
     __shared__ double lds[ZF_WAVES * 8 + 8];
     __shared__ int s_flag;
     if (A.ctl->status != ZF_RUNNING) return;
@@ -340,12 +332,116 @@ template <int T, int INTERLEAVE> void run_multi(const Bufs& B) {
     int ngroups = (grid + ZF_GROUP - 1) / ZF_GROUP;
     zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.beta_next = 0.3;
     zf_control* ctl; CK(hipMalloc(&ctl, sizeof(h))); CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
-    unsigned* cnt; zf_step_args A;
+    unsigned* cnt; tune_args A;
     CK(hipMalloc(&cnt, 4 * (ngroups + 16))); CK(hipMemset(cnt, 0, 4 * (ngroups + 16)));
     CK(hipMalloc(&A.ws.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&A.ws.totals, 64)); A.ws.grp_cnt = cnt;
     A.ctl = ctl; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c; A.lam = 0.1; A.n = B.n;
     double ms = time_ms([&] { hipLaunchKernelGGL((trial_multi<T, INTERLEAVE>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A, ntiles); });
     printf("multi-tile T=%d interleave=%d grid=%6d : %7.3f ms  %7.1f GB/s\n", T, INTERLEAVE, grid, ms, 40.0 * B.n / ms / 1e6);
+}
+// ---- alternative: plain partial stores + a separate fast finalize/decide kernel --------------------
+// FB workgroups of 1024 threads each reduce a slice of the per-workgroup partials with all loads
+// independent; the last arriver (one ticket per finalize workgroup) adds the slices and decides.
+template <int FB>
+__global__ __launch_bounds__(1024) void finalize_fast(const double* __restrict__ partials, int nblocks, double* slice_part,
+                                                      unsigned* cnt, zf_control* ctl, double* trace, double* pack) {
+    __shared__ double lds[16 * 8];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = (nblocks + FB - 1) / FB;
+    const int b0 = blockIdx.x * per;
+    int b1 = b0 + per; if (b1 > nblocks) b1 = nblocks;
+    double v[ZF_NPART];
+#pragma unroll
+    for (int k = 0; k < ZF_NPART; ++k) v[k] = 0.0;
+    for (int b = b0 + threadIdx.x; b < b1; b += 1024) {
+        double p[ZF_NPART];
+#pragma unroll
+        for (int k = 0; k < ZF_NPART; ++k) p[k] = partials[(int64_t)k * nblocks + b];
+#pragma unroll
+        for (int k = 0; k < ZF_NPART - 1; ++k) v[k] += p[k];
+        v[ZF_NPART - 1] = fmax(v[ZF_NPART - 1], p[ZF_NPART - 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < ZF_NPART; ++k) {
+        const double r = (k == ZF_NPART - 1) ? zf_wave_max(v[k]) : zf_wave_sum(v[k]);
+        if (lane == 0) lds[wave * 8 + k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        if (threadIdx.x < ZF_NPART) {
+            const int k = threadIdx.x;
+            double r = lds[k];
+            for (int w = 1; w < 16; ++w) r = (k == ZF_NPART - 1) ? fmax(r, lds[w * 8 + k]) : r + lds[w * 8 + k];
+            if (FB == 1) lds[k] = r; else zf_publish(slice_part + (int64_t)k * FB + blockIdx.x, r);
+        }
+        if (FB > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) {
+                const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (t == FB - 1);
+                if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+    }
+    __syncthreads();
+    if (FB > 1 && !s_last) return;
+    if (threadIdx.x == 0) {
+        double tot[ZF_NPART];
+        for (int k = 0; k < ZF_NPART; ++k) {
+            if (FB == 1) tot[k] = lds[k];
+            else {
+                double r = zf_consume(slice_part + (int64_t)k * FB);
+                for (int q = 1; q < FB; ++q) { const double p = zf_consume(slice_part + (int64_t)k * FB + q); r = (k == ZF_NPART - 1) ? fmax(r, p) : r + p; }
+                tot[k] = r;
+            }
+        }
+        pack[0] = 0.5 * tot[0]; pack[1] = tot[1]; pack[2] = tot[2]; pack[3] = 0.1 * tot[3]; pack[4] = 0.5 * tot[4]; pack[5] = tot[5];
+        pack[6] = pack[7] = 0.0;
+        zf_decide_step(ctl, pack, trace, nullptr);
+    }
+}
+
+template <int FB> void run_split(const Bufs& B) {
+    const int64_t n2 = B.n / 2;
+    int grid = (int)(n2 / ZF_TILE_UNITS);
+    zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.world = 1; h.max_iter = 1 << 30;
+    h.max_backtrack = 100; h.decay_rate = 0.5; h.tol_internal = 1e300; h.F_old = 1e300; h.nesterov = 1; h.beta_next = 0.3;
+    zf_control* ctl; CK(hipMalloc(&ctl, sizeof(h))); CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+    double *trace, *pack, *slice; unsigned* cnt; tune_args A;
+    CK(hipMalloc(&trace, 8 * ZF_RING * 8)); CK(hipMalloc(&pack, 64)); CK(hipMalloc(&slice, 8 * ZF_NPART * 64));
+    CK(hipMalloc(&cnt, 64)); CK(hipMemset(cnt, 0, 64));
+    CK(hipMalloc(&A.ws.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&A.ws.totals, 64));
+    A.ctl = ctl; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c; A.lam = 0.1; A.n = B.n; 
+    const int K = 20;
+    double ms = time_ms([&] { for (int k = 0; k < K; ++k) {
+        hipLaunchKernelGGL((trial_dbg<0>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A);
+        hipLaunchKernelGGL((finalize_fast<FB>), dim3(FB), dim3(1024), 0, 0, A.ws.blk_part, grid, slice, cnt, ctl, trace, pack); } }, 5);
+    printf("SPLIT  streaming + finalize_fast<%2d> : %7.3f ms per step (loop of %d)\n", FB, ms / K, K);
+}
+// the shipped pair: library trial kernel (plain partial stores) + library finalize/decide kernel
+template <bool NT> void run_lib_loop(const Bufs& B, int T) {
+    const int64_t n2 = B.n / 2;
+    const int64_t nt_all = (n2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
+    int grid = (int)((nt_all + T - 1) / T);
+    zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.world = 1; h.max_iter = 1 << 30;
+    h.max_backtrack = 100; h.decay_rate = 0.5; h.tol_internal = 1e300; h.F_old = 1e300; h.nesterov = 1;
+    zf_control* ctl; CK(hipMalloc(&ctl, sizeof(h))); CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+    double *beta, *trace, *pack; zf_step_args A; zf_finalize_args F;
+    CK(hipMalloc(&beta, 8 * ZF_RING)); CK(hipMemset(beta, 0, 8 * ZF_RING)); CK(hipMalloc(&trace, 8 * ZF_RING * 8));
+    CK(hipMalloc(&pack, 64)); CK(hipMalloc(&F.cnt, 64)); CK(hipMemset(F.cnt, 0, 64));
+    CK(hipMalloc(&A.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&F.slice_part, 8 * ZF_NPART * ZF_FIN_WGS));
+    A.ctl = ctl; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c;
+    A.lam = 0.1; A.lo = 0; A.hi = 0; A.n = B.n; A.tiles_per_wg = T;
+    F.blk_part = A.blk_part; F.nblocks = grid; for (int k = 0; k < ZF_NPART; ++k) F.scale[k] = 1.0;
+    F.f_y_ext = F.f_x_ext = nullptr; F.contribute_f = 1; F.pack = pack; F.ctl = ctl; F.decide = 1; F.trace = trace; F.beta_ring = beta;
+    int wgs = (grid + ZF_FIN_THREADS - 1) / ZF_FIN_THREADS; if (wgs > ZF_FIN_WGS) wgs = ZF_FIN_WGS; if (wgs < 1) wgs = 1;
+    const int K = 20;
+    double ms = time_ms([&] { for (int k = 0; k < K; ++k) {
+        hipLaunchKernelGGL((zf_trial_kernel<true, true, false, NT>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A);
+        hipLaunchKernelGGL(zf_finalize_kernel, dim3(wgs), dim3(ZF_FIN_THREADS), 0, 0, F); } }, 5);
+    printf("LIBRARY trial + finalize  T=%d nt=%d : %7.3f ms per step (loop of %d)\n", T, (int)NT, ms / K, K);
 }
 template <int LEVEL> void run_dbg(const Bufs& B) {
     const int64_t n2 = B.n / 2;
@@ -353,10 +449,10 @@ template <int LEVEL> void run_dbg(const Bufs& B) {
     int ngroups = (grid + ZF_GROUP - 1) / ZF_GROUP;
     zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.beta_next = 0.3;
     zf_control* ctl; CK(hipMalloc(&ctl, sizeof(h))); CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
-    unsigned* cnt; zf_step_args A;
+    unsigned* cnt; tune_args A;
     CK(hipMalloc(&cnt, 4 * (ngroups + 16))); CK(hipMemset(cnt, 0, 4 * (ngroups + 16)));
     CK(hipMalloc(&A.ws.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&A.ws.totals, 64)); A.ws.grp_cnt = cnt;
-    A.ctl = ctl; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c; A.lam = 0.1; A.n = B.n; A.tiles_per_wg = 1;
+    A.ctl = ctl; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c; A.lam = 0.1; A.n = B.n;
     double ms = time_ms([&] { hipLaunchKernelGGL((trial_dbg<LEVEL>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A); });
     printf("staged LEVEL %d grid=%6d : %7.3f ms  %7.1f GB/s\n", LEVEL, grid, ms, 40.0 * B.n / ms / 1e6);
 }
@@ -391,10 +487,8 @@ int main(int argc, char** argv) {
     printf("n = %lld\n", (long long)B.n);
     for (int rep = 0; rep < 2; ++rep) {
         run_c<4, 256, 9>(B);
-        run_dbg<0>(B); run_dbg<2>(B);
-        run_multi<1, 0>(B); run_multi<2, 0>(B); run_multi<4, 0>(B); run_multi<8, 0>(B);
-        run_multi<2, 1>(B); run_multi<4, 1>(B); run_multi<8, 1>(B);
-        run_lib<true>(B, true, 1); run_lib<true>(B, true, 2); run_lib<true>(B, true, 4);
+        run_split<16>(B);
+        run_lib_loop<true>(B, 1); run_lib_loop<true>(B, 2); run_lib_loop<true>(B, 4); run_lib_loop<false>(B, 1);
     }
     return 0;
 }

@@ -75,30 +75,22 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
 //   * all 16 loads of a thread are issued before the first use;
 //   * d, c are read once per trial and x+ is written once: nontemporal (nt)
 //     loads / stores keep them from displacing x_k in the caches (+8 %).
-// The reduction is finished inside the same launch (no finalize kernel, no
-// extra launch boundary): every workgroup publishes its six partials
-// write-through (sc1) and takes a ticket on its group's counter; the group's
-// last arriver adds the members' partials (fixed shuffle tree = index order),
-// publishes the group partial and takes a ticket on the launch counter; the
-// launch's last arriver adds the group partials in group order, builds the scalar
-// pack and (unsharded x) runs the decide step.  Wave 0 does the publish/ticket
-// BEFORE it stores its own x+ tile: `s_waitcnt vmcnt(0)` waits for every earlier
-// store of the wave in issue order, and the 8-byte publishes complete in ~1 us
-// while HBM stores take several.  Hand-off protocol: guide section 6
-// Guideline 16 (R1, counter form) / MI355X_MICROARCH "Valid forms": sc1 stores,
-// the storing wave drains vmcnt, one relaxed agent-scope add per workgroup, the
-// reducer takes one agent-scope acquire and reads with sc1 loads.  Sums are
-// added in workgroup / group index order, never arrival order: deterministic.
-// Alternatives measured and rejected (tools/tune_trial.hip, n = 1e8 / 1e7):
-// separate one-workgroup finalize kernel +21 us +2 launch gaps; reducer
-// workgroups appended to the grid that poll the counters: same at 1e8, +10 us
-// at 1e7 (they are dispatched last and start late); persistent tile walk:
-// device-dependent, up to 9 % slower than one workgroup per tile.
+// Reduction: every workgroup stores its six partials with plain stores and retires
+// (no per-workgroup hand-off); a second, tiny launch - zf_finalize_kernel, ZF_FIN_WGS
+// workgroups of 1024 threads, every load independent - adds them in index order, its
+// last-arriving workgroup (one ticket per finalize workgroup, guide Guideline 16 R1
+// counter form) builds the scalar pack and runs the decide step.  Measured per step in
+// loops of 20 launches (tools/tune_trial.hip, one box): streaming + finalize 0.675 ms
+// (n = 1e8) / 0.069 ms (1e7); a fused single launch with per-workgroup tickets and a
+// two-level in-launch reduction 0.686 / 0.078 ms at one tile per workgroup, and
+// device-dependent (0.66 - 0.71) with several tiles per workgroup; the first version's
+// single-workgroup finalize with dependent load rounds 0.849 / 0.098 ms.
 // ---------------------------------------------------------------------------
 constexpr int ZF_TILE_U = 4;
 constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per tile
 constexpr int ZF_MAX_TILES_PER_WG = 8;                // upper bound of zf_step_args.tiles_per_wg
-constexpr int ZF_GROUP = 64;                          // workgroups per reduction group
+constexpr int ZF_FIN_WGS = 48;                        // workgroups of the finalize kernel
+constexpr int ZF_FIN_THREADS = 1024;
 
 typedef double zf_d2 __attribute__((ext_vector_type(2)));
 
@@ -117,103 +109,57 @@ __device__ __forceinline__ double zf_consume(const double* p) {     // sc1 load,
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-struct zf_reduce_ws {
-    double* blk_part;     // ZF_NPART x nblocks, quantity-major
-    double* grp_part;     // ZF_NPART x ngroups
-    unsigned* grp_cnt;    // ngroups arrival counters (zero between launches)
-    unsigned* top_cnt;    // 1
-    double* totals;       // ZF_NPART launch totals (raw sums / max)
-};
-
-struct zf_tail_args {
-    double scale[ZF_NPART];   // pack[k] = scale[k] * total[k]
-    double* pack;             // local pack out (ZF_PACK_LEN), may be NULL
-    zf_control* ctl_rw;       // decide in-launch when non-NULL (unsharded separable problem)
-    double* trace;
-};
-
 struct zf_step_args {
     const zf_control* ctl;
-    const double* beta_ring;  // ZF_RING momentum factors, indexed by accepted count
     double* xb[3];            // x ring
     const double* p0;         // diag: d        vec: grad
     const double* p1;         // diag: c        vec: unused
     double lam, lo, hi;
     int64_t n;
     int tiles_per_wg;         // interleaved tiles per workgroup (1 .. ZF_MAX_TILES_PER_WG)
-    zf_reduce_ws ws;
-    zf_tail_args tail;
+    double* blk_part;         // ZF_NPART x gridDim.x per-workgroup partials, quantity-major
 };
 
-// Elect-and-reduce tail, part 1 (wave 0 only; `mine` = this workgroup's total of
-// quantity threadIdx.x, threads < ZF_NPART): publish, drain, ticket.  Sets *s_flag
-// (LDS) to 1 in the workgroup whose ticket is the group's last.  Must run BEFORE
-// the wave issues its x+ stores.
-__device__ __forceinline__ void zf_publish_and_ticket(const zf_reduce_ws& W, double mine, int* s_flag) {
-    const int nblocks = gridDim.x;
-    const int b = blockIdx.x;
-    const int g = b / ZF_GROUP;
-    const int g0 = g * ZF_GROUP;
-    const int gsize = (nblocks - g0 < ZF_GROUP) ? (nblocks - g0) : ZF_GROUP;
-    if (threadIdx.x < ZF_NPART) zf_publish(W.blk_part + (int64_t)threadIdx.x * nblocks + b, mine);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(W.grp_cnt + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == (unsigned)(gsize - 1));
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *s_flag = last;
-    }
-}
+struct zf_finalize_args {
+    const double* blk_part;   // ZF_NPART x nblocks (written by the trial kernel)
+    int nblocks;
+    double* slice_part;       // ZF_NPART x ZF_FIN_WGS
+    unsigned* cnt;            // arrival counter of the finalize workgroups (zero between launches)
+    double scale[ZF_NPART];   // pack[k] = scale[k] * total[k]
+    const double* f_y_ext;    // least squares: f(y), f(x+) come from the GEMV side (else NULL)
+    const double* f_x_ext;
+    int contribute_f;         // sharded least squares: only rank 0 contributes the replicated f values
+    double* pack;             // local pack out (ZF_PACK_LEN)
+    zf_control* ctl;          // read for the early exit; written when `decide`
+    int decide;               // unsharded x: run the decide step here
+    double* trace;
+    const double* beta_ring;
+};
 
-// part 2 (whole workgroup, after a barrier that follows part 1; only the group's
-// last workgroup calls it).  Returns true in every thread of the launch's last
-// workgroup, with totals[] (LDS) filled.
-__device__ __forceinline__ bool zf_group_and_launch_reduce(const zf_reduce_ws& W, double* lds /* >= 40 */,
-                                                           double* totals /* LDS, 8 */, int* s_flag) {
-    const int nblocks = gridDim.x;
-    const int g = blockIdx.x / ZF_GROUP;
-    const int ngroups = (nblocks + ZF_GROUP - 1) / ZF_GROUP;
-    const int g0 = g * ZF_GROUP;
-    const int gsize = (nblocks - g0 < ZF_GROUP) ? (nblocks - g0) : ZF_GROUP;
+// Second launch of a step.  Every workgroup adds its slice of the per-workgroup partials
+// (thread t takes workgroups t, t+1024, ... of the slice: index order; six independent loads per
+// index), publishes the slice totals write-through and takes a ticket; the last arriver adds
+// the ZF_FIN_WGS slices in slice order, builds the pack and (decide) runs the decide step:
+// model value, acceptance, lr decay, failure, termination, buffer rotation, trace row
+// (proximal_gradient.py:149-155,:298-307,:510,:525,:539).  Deterministic: no float atomics,
+// sums in index order.
+__global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize_args F) {
+    __shared__ double lds[(ZF_FIN_THREADS / 64) * 8];
+    __shared__ int s_last;
+    if (F.ctl->status != ZF_RUNNING) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // group reducer: lane l holds workgroup g0+l; fixed shuffle tree = index order.
-    // wave w reduces quantities w and w+4 (both loads in flight before the first use)
-    {
-        const int k0 = wave, k1 = wave + ZF_WAVES;
-        double v0 = 0.0, v1 = 0.0;
-        if (lane < gsize) {
-            v0 = zf_consume(W.blk_part + (int64_t)k0 * nblocks + g0 + lane);
-            if (k1 < ZF_NPART) v1 = zf_consume(W.blk_part + (int64_t)k1 * nblocks + g0 + lane);
-        }
-        v0 = zf_wave_sum(v0);                                            // k0 < 4: always a sum
-        v1 = (k1 == ZF_NPART - 1) ? zf_wave_max(v1) : zf_wave_sum(v1);
-        if (lane == 0) {
-            zf_publish(W.grp_part + (int64_t)k0 * ngroups + g, v0);
-            if (k1 < ZF_NPART) zf_publish(W.grp_part + (int64_t)k1 * ngroups + g, v1);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(W.grp_cnt + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-        const unsigned t = __hip_atomic_fetch_add(W.top_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == (unsigned)(ngroups - 1));
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *s_flag = last;
-    }
-    __syncthreads();
-    if (!*s_flag) return false;
-    // last workgroup of the launch: add the group partials in group order; the six
-    // loads of one group index are independent and issued together
+    constexpr int NW = ZF_FIN_THREADS / 64;
+    const int per = (F.nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = blockIdx.x * per;
+    int b1 = b0 + per;
+    if (b1 > F.nblocks) b1 = F.nblocks;
     double v[ZF_NPART];
 #pragma unroll
     for (int k = 0; k < ZF_NPART; ++k) v[k] = 0.0;
-    for (int q = threadIdx.x; q < ngroups; q += ZF_BLOCK) {
+    for (int b = b0 + threadIdx.x; b < b1; b += ZF_FIN_THREADS) {
         double p[ZF_NPART];
 #pragma unroll
-        for (int k = 0; k < ZF_NPART; ++k) p[k] = zf_consume(W.grp_part + (int64_t)k * ngroups + q);
+        for (int k = 0; k < ZF_NPART; ++k) p[k] = F.blk_part[(int64_t)k * F.nblocks + b];
 #pragma unroll
         for (int k = 0; k < ZF_NPART - 1; ++k) v[k] += p[k];
         v[ZF_NPART - 1] = fmax(v[ZF_NPART - 1], p[ZF_NPART - 1]);
@@ -224,16 +170,46 @@ __device__ __forceinline__ bool zf_group_and_launch_reduce(const zf_reduce_ws& W
         if (lane == 0) lds[wave * 8 + k] = r;
     }
     __syncthreads();
-    if (threadIdx.x < ZF_NPART) {
-        const int k = threadIdx.x;
-        double r = lds[k];
-        for (int w = 1; w < ZF_WAVES; ++w) r = (k == ZF_NPART - 1) ? fmax(r, lds[w * 8 + k]) : r + lds[w * 8 + k];
-        totals[k] = r;
-        W.totals[k] = r;
+    if (threadIdx.x < 64) {
+        if (threadIdx.x < ZF_NPART) {
+            const int k = threadIdx.x;
+            double r = lds[k];
+            for (int w = 1; w < NW; ++w) r = (k == ZF_NPART - 1) ? fmax(r, lds[w * 8 + k]) : r + lds[w * 8 + k];
+            zf_publish(F.slice_part + (int64_t)k * ZF_FIN_WGS + blockIdx.x, r);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(F.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == (unsigned)(gridDim.x - 1));
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(F.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = last;
+        }
     }
-    if (threadIdx.x == 0) __hip_atomic_store(W.top_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    return true;
+    if (!s_last || wave != 0) return;
+    // last arriver, wave 0: lane q holds slice q (six independent sc1 loads: one round trip),
+    // then the fixed shuffle tree adds the slices in slice order
+    double tot[ZF_NPART];
+#pragma unroll
+    for (int k = 0; k < ZF_NPART; ++k)
+        tot[k] = (lane < (int)gridDim.x) ? zf_consume(F.slice_part + (int64_t)k * ZF_FIN_WGS + lane) : 0.0;
+#pragma unroll
+    for (int k = 0; k < ZF_NPART; ++k) tot[k] = (k == ZF_NPART - 1) ? zf_wave_max(tot[k]) : zf_wave_sum(tot[k]);
+    if (lane != 0) return;
+    double* pack = F.pack;
+    pack[ZF_PK_FY] = F.f_y_ext ? (F.contribute_f ? *F.f_y_ext : 0.0) : F.scale[0] * tot[0];
+    pack[ZF_PK_DOT] = tot[1];
+    pack[ZF_PK_SS] = tot[2];
+    pack[ZF_PK_GX] = F.scale[3] * tot[3];
+    pack[ZF_PK_FX] = F.f_x_ext ? (F.contribute_f ? *F.f_x_ext : 0.0) : F.scale[4] * tot[4];
+    pack[ZF_PK_ERR] = tot[5];
+    pack[6] = 0.0;
+    pack[7] = 0.0;
+    if (F.decide) zf_decide_step(F.ctl, pack, F.trace, F.beta_ring);
 }
 
 // GRAD_INLINE: true  -> separable quadratic, gradient computed from d, c
@@ -242,8 +218,6 @@ __device__ __forceinline__ bool zf_group_and_launch_reduce(const zf_reduce_ws& W
 template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     __shared__ double lds[ZF_WAVES * 8 + 8];
-    __shared__ double totals[8];
-    __shared__ int s_flag;
     // wave-uniform control reads (scalar loads); written by the previous launch's decide step
     const int status = A.ctl->status;
     if (status != ZF_RUNNING) return;
@@ -269,21 +243,15 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     // Workgroup b owns tiles b, b + G, b + 2G, ... (G = gridDim.x, A.tiles_per_wg of them):
     // interleaved, so that at any time the resident workgroups still cover one contiguous window
     // of every stream (consecutive tiles per workgroup measured 4-8 % slower), while the
-    // per-workgroup costs - block reduction, publish, ticket - are paid once per T tiles.
-    // Which T wins is device-dependent (T = 4: -1 % on some MI355X boxes, +7 % on others, against
-    // T = 1), so the solver measures it once at initialisation (zf_solver_autotune).
+    // per-workgroup costs (block reduction, partial stores) are paid once per T tiles.  Which T
+    // wins is device-dependent (T = 4: -1 % on some MI355X boxes, +7 % on others, against T = 1),
+    // so the solver measures it once at initialisation (zf_solver_autotune); T = 1 otherwise.
     const int64_t ntiles = (n2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
     const int64_t G = gridDim.x;
     zf_d2 r[ZF_TILE_U];
-    int64_t deferred_base = -1;   // the last full tile's x+ stays in registers until after the ticket
     for (int t = 0; t < A.tiles_per_wg; ++t) {
         const int64_t tile = (int64_t)t * G + blockIdx.x;
         if (tile >= ntiles) break;
-        if (deferred_base >= 0) {
-#pragma unroll
-            for (int u = 0; u < ZF_TILE_U; ++u) zf_st2<NT>(xn2 + deferred_base + u * ZF_BLOCK, r[u]);
-            deferred_base = -1;
-        }
         const int64_t base = tile * ZF_TILE_UNITS + threadIdx.x;
         if ((tile + 1) * ZF_TILE_UNITS <= n2) {   // full tile (workgroup-uniform)
             zf_d2 a[ZF_TILE_U], o[ZF_TILE_U], q[ZF_TILE_U], cc[ZF_TILE_U];
@@ -310,7 +278,8 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
                     r[u].y = zf_elem_vec<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, beta, lr, tau, A.lo, A.hi, acc);
                 }
             }
-            deferred_base = base;
+#pragma unroll
+            for (int u = 0; u < ZF_TILE_U; ++u) zf_st2<NT>(xn2 + base + u * ZF_BLOCK, r[u]);
         } else {
             // ragged last tile of the vector: stored at once (one workgroup per launch)
             for (int u = 0; u < ZF_TILE_U; ++u) {
@@ -347,29 +316,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     const double maxs[1] = {acc.mx};
     double mine = 0.0;
     zf_block_reduce<5, 1, ZF_WAVES>(sums, maxs, lds, mine);
-    // wave 0 publishes the partials and takes the ticket while its last x+ tile is still in
-    // registers; waves 1-3 stream theirs out meanwhile
-    if (threadIdx.x < 64) zf_publish_and_ticket(A.ws, mine, &s_flag);
-    if (deferred_base >= 0) {
-#pragma unroll
-        for (int u = 0; u < ZF_TILE_U; ++u) zf_st2<NT>(xn2 + deferred_base + u * ZF_BLOCK, r[u]);
-    }
-    __syncthreads();
-    if (!s_flag) return;
-    if (!zf_group_and_launch_reduce(A.ws, lds, totals, &s_flag)) return;
-    // last workgroup of the launch
-    if (threadIdx.x == 0 && A.tail.pack) {
-        double* pack = A.tail.pack;
-        pack[ZF_PK_FY] = A.tail.scale[0] * totals[0];
-        pack[ZF_PK_DOT] = totals[1];
-        pack[ZF_PK_SS] = totals[2];
-        pack[ZF_PK_GX] = A.tail.scale[3] * totals[3];
-        pack[ZF_PK_FX] = A.tail.scale[4] * totals[4];
-        pack[ZF_PK_ERR] = totals[5];
-        pack[6] = 0.0;
-        pack[7] = 0.0;
-        if (A.tail.ctl_rw) zf_decide_step(A.tail.ctl_rw, pack, A.tail.trace, A.beta_ring);
-    }
+    if (threadIdx.x < ZF_NPART) A.blk_part[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = mine;
 }
 
 // --- f(x), g(x) at a point (initial F(x0), proximal_gradient.py:466,472) -------

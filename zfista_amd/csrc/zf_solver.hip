@@ -19,8 +19,6 @@ thread_local char zf_errbuf[512] = "";
 // ---------------------------------------------------------------------------
 // finalize / decide kernels
 // ---------------------------------------------------------------------------
-// least squares: the trial kernel leaves the raw totals; f(y), f(x+) come from the
-// GEMV side.  One thread builds the pack and (unsharded) runs the decide step.
 // s_out = sum over ranks (rank order) of the gathered parts A_p x_p; slot as in zf_gemv_rows_kernel
 __global__ __launch_bounds__(ZF_BLOCK) void zf_sum_parts_kernel(const zf_control* ctl, const double* __restrict__ s_all,
                                                                 int world, int64_t m, zf_ring3 sr, int slot) {
@@ -36,22 +34,6 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_sum_parts_kernel(const zf_control
         for (int r = 1; r < world; ++r) t += s_all[(int64_t)r * m + i];
         out[i] = t;
     }
-}
-
-__global__ void zf_ls_pack_kernel(zf_control* ctl, const double* totals, const double* ls_scal, double lam,
-                                  double* pack, double* trace, int decide, int contribute_f,
-                                  const double* beta_ring) {
-    if (threadIdx.x || blockIdx.x) return;
-    if (ctl->status != ZF_RUNNING) return;
-    pack[ZF_PK_FY] = contribute_f ? ls_scal[0] : 0.0;
-    pack[ZF_PK_DOT] = totals[1];
-    pack[ZF_PK_SS] = totals[2];
-    pack[ZF_PK_GX] = lam * totals[3];
-    pack[ZF_PK_FX] = contribute_f ? ls_scal[1] : 0.0;
-    pack[ZF_PK_ERR] = totals[5];
-    pack[6] = 0.0;
-    pack[7] = 0.0;
-    if (decide) zf_decide_step(ctl, pack, trace, beta_ring);
 }
 
 __global__ void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace, const double* beta_ring) {
@@ -112,8 +94,9 @@ struct zf_solver {
     double* xbuf = nullptr;   // 3 * n_pad
     double* xb[3] = {nullptr, nullptr, nullptr};
     double* partials = nullptr;   // init-time evaluation partials
-    zf_reduce_ws ws = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    unsigned* counters = nullptr; // ngroups + 1 arrival counters
+    double* blk_part = nullptr;   // ZF_NPART x max_grid per-workgroup partials of the trial kernel
+    double* slice_part = nullptr; // ZF_NPART x ZF_FIN_WGS
+    unsigned* fin_cnt = nullptr;  // arrival counter of the finalize workgroups
     bool nt = true;               // nontemporal policy for once-touched streams
     zf_control* ctl = nullptr;
     double* trace = nullptr;      // ZF_RING * ZF_TRACE_COLS
@@ -147,7 +130,7 @@ struct zf_solver {
 };
 
 static int zf_solver_free_all(zf_solver* s) {
-    void* ptrs[] = {s->ws.blk_part, s->ws.grp_part, s->counters, s->ws.totals, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
+    void* ptrs[] = {s->blk_part, s->slice_part, s->fin_cnt, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
                     s->own_svec ? s->s_part : nullptr, s->own_svec ? s->s_all : nullptr};
@@ -213,16 +196,10 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * 3 * n_pad));
     for (int k = 0; k < 3; ++k) s->xb[k] = s->xbuf + k * n_pad;
     ZF_TRY(hipMalloc(&s->partials, sizeof(double) * ZF_NPART * ZF_MAX_GRID));
-    {
-        const int ngroups = (s->grid + ZF_GROUP - 1) / ZF_GROUP;
-        ZF_TRY(hipMalloc(&s->ws.blk_part, sizeof(double) * ZF_NPART * s->grid));
-        ZF_TRY(hipMalloc(&s->ws.grp_part, sizeof(double) * ZF_NPART * ngroups));
-        ZF_TRY(hipMalloc(&s->counters, sizeof(unsigned) * (ngroups + 16)));
-        ZF_TRY(hipMalloc(&s->ws.totals, sizeof(double) * 8));
-        ZF_TRY(hipMemsetAsync(s->counters, 0, sizeof(unsigned) * (ngroups + 16), s->stream));
-        s->ws.grp_cnt = s->counters;
-        s->ws.top_cnt = s->counters + ngroups;
-    }
+    ZF_TRY(hipMalloc(&s->blk_part, sizeof(double) * ZF_NPART * s->max_grid));
+    ZF_TRY(hipMalloc(&s->slice_part, sizeof(double) * ZF_NPART * ZF_FIN_WGS));
+    ZF_TRY(hipMalloc(&s->fin_cnt, 64));
+    ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, 64, s->stream));
     ZF_TRY(hipMalloc(&s->ctl, sizeof(zf_control)));
     ZF_TRY(hipMalloc(&s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS));
     ZF_TRY(hipMalloc(&s->beta_ring, sizeof(double) * ZF_RING));
@@ -285,29 +262,49 @@ static void zf_launch_trial_t(zf_solver* s, const zf_step_args& a) {
     else zf_launch_trial_t2<GI, false>(s, a);
 }
 
+// second launch of a step: partials -> pack (+ decide when x is unsharded)
+static void zf_launch_finalize(zf_solver* s, bool decide) {
+    const zf_problem_desc& d = s->desc;
+    zf_finalize_args F;
+    F.blk_part = s->blk_part;
+    F.nblocks = s->grid;
+    F.slice_part = s->slice_part;
+    F.cnt = s->fin_cnt;
+    for (int k = 0; k < ZF_NPART; ++k) F.scale[k] = 1.0;
+    F.scale[3] = d.lam;               // g = lam * sum|x|
+    F.f_y_ext = nullptr;
+    F.f_x_ext = nullptr;
+    F.contribute_f = 1;
+    if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
+        F.scale[0] = 0.5;             // f = 0.5 * sum(d (x-c)^2)
+        F.scale[4] = 0.5;
+    } else {
+        F.f_y_ext = s->ls_scal + 0;   // f(y), f(x+) come from the GEMV side and are replicated
+        F.f_x_ext = s->ls_scal + 1;
+        F.contribute_f = (d.world == 1 || d.rank == 0) ? 1 : 0;
+    }
+    F.pack = s->pack_local;
+    F.ctl = s->ctl;
+    F.decide = decide ? 1 : 0;
+    F.trace = s->trace;
+    F.beta_ring = s->beta_ring;
+    int wgs = (s->grid + ZF_FIN_THREADS - 1) / ZF_FIN_THREADS;   // no more workgroups than slices of work
+    if (wgs > ZF_FIN_WGS) wgs = ZF_FIN_WGS;
+    if (wgs < 1) wgs = 1;
+    hipLaunchKernelGGL(zf_finalize_kernel, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
+}
+
 static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false) {
     const zf_problem_desc& d = s->desc;
     zf_step_args a;
     a.ctl = s->ctl;
-    a.beta_ring = s->beta_ring;
     for (int k = 0; k < 3; ++k) a.xb[k] = s->xb[k];
     a.lam = d.lam;
     a.lo = d.box_lo;
     a.hi = d.box_hi;
     a.n = d.n;
     a.tiles_per_wg = s->tiles;
-    a.ws = s->ws;
-    for (int k = 0; k < ZF_NPART; ++k) a.tail.scale[k] = 1.0;
-    a.tail.scale[3] = d.lam;        // g = lam * sum|x|
-    a.tail.pack = nullptr;
-    a.tail.ctl_rw = nullptr;
-    a.tail.trace = s->trace;
-    if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
-        a.tail.scale[0] = 0.5;      // f = 0.5 * sum(d (x-c)^2)
-        a.tail.scale[4] = 0.5;
-        if (!dry) a.tail.pack = s->pack_local;   // dry (autotune probe): totals only, no pack, no decide
-        if (!dry && d.world == 1 && decide_in_launch) a.tail.ctl_rw = s->ctl;
-    }
+    a.blk_part = s->blk_part;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing) {
         if (s->ev_used == s->ev_pool.size()) {
@@ -326,6 +323,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
         zf_launch_trial_t<true>(s, a);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+        if (!dry) zf_launch_finalize(s, d.world == 1 && decide_in_launch);
     } else {
         const int64_t n = d.n, m = d.m_rows;
         const int V = (n % 2 == 0) ? 2 : 1;
@@ -371,8 +369,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         if (d.world == 1) {
             hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1,
                                d.b, d.scale, m, s->ls_scal + 1);
-            hipLaunchKernelGGL(zf_ls_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->ws.totals,
-                               s->ls_scal, d.lam, s->pack_local, s->trace, (int)decide_in_launch, 1, s->beta_ring);
+            zf_launch_finalize(s, decide_in_launch);
         }
     }
     ZF_HIP(hipGetLastError());
@@ -390,8 +387,7 @@ extern "C" int zf_solver_enqueue_trial_finish(zf_solver* s) {
                        (int)d.world, m, s->sring, 1);
     hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1, d.b,
                        d.scale, m, s->ls_scal + 1);
-    hipLaunchKernelGGL(zf_ls_pack_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->ws.totals, s->ls_scal, d.lam,
-                       s->pack_local, s->trace, 0, (int)(d.rank == 0), s->beta_ring);
+    zf_launch_finalize(s, false);
     ZF_HIP(hipGetLastError());
     return ZF_OK;
 }
