@@ -45,6 +45,7 @@ extern "C" {
 #define ZF_PROBLEM_LEAST_SQUARES_L1 2 /* f = scale |Ax-b|^2,          g = lam |x|_1 (+box) */
 
 #define ZF_PACK_LEN 8    /* doubles in one per-trial scalar pack */
+#define ZF_MAX_SUB_ITERS 8 /* packs per pass: a rank's pack buffer holds sub_iters x ZF_PACK_LEN doubles */
 #define ZF_TRACE_COLS 8  /* doubles per accepted iteration in the trace ring */
 #define ZF_RING 1024     /* capacity (iterations) of the trace and momentum rings */
 
@@ -69,7 +70,7 @@ typedef struct zf_control {
     int64_t max_backtrack;
     int64_t total_trials; /* over the whole run                                       */
     int32_t status;       /* ZF_RUNNING ...                                           */
-    int32_t cur;          /* which of the three x buffers holds x_k                   */
+    int32_t cur;          /* which x buffer holds x_k                                 */
     int32_t nesterov;
     int32_t deprecated;   /* deprecated acceptance test (:300-302)                    */
     int32_t need_grad;    /* least squares: gradient at y_k must be (re)computed      */
@@ -78,6 +79,15 @@ typedef struct zf_control {
                              momentum ring by the decide step so that a trial kernel needs
                              ONE dependent scalar load (this block) before its first
                              vector load                                               */
+    int32_t ring_size;    /* x buffers: 3 (one iteration per pass) or 4                */
+    int32_t sub_iters;    /* S: trials one pass chains in registers (temporal blocking) */
+    int32_t prev;         /* which x buffer holds x_{k-1}                             */
+    /* plan of the next pass (written by the decide step, read by the trial kernel):
+     * plan_n trials chained on acceptance; from trial index cut_at on (cut_at >= 0) the step
+     * size is lr * decay_rate^ncuts - ncuts rejections already observed at that position */
+    int32_t plan_n;
+    int32_t cut_at;
+    int32_t ncuts;
 } zf_control;
 
 typedef struct zf_problem_desc {
@@ -106,6 +116,10 @@ typedef struct zf_options {  /* keyword arguments of proximal_gradient.py:317-33
     int64_t max_backtrack_iter;
     int32_t nesterov;
     int32_t deprecated;
+    int32_t sub_iters;   /* S iterations per pass over the data for separable problems (temporal
+                            blocking): 0 = library default (ZF_SUB_ITERS in the environment, else 4),
+                            1..4 explicit.  Results do not depend on it.                            */
+    int32_t reserved;
 } zf_options;
 
 typedef struct zf_solver zf_solver; /* opaque; owns x ring, partials, control, rings */
@@ -159,8 +173,12 @@ int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles);
 /* world > 1: the two halves of a step; the caller gathers pack_local -> pack_all between them */
 int zf_solver_enqueue_trial(zf_solver* s);
 int zf_solver_enqueue_decide(zf_solver* s);
-/* device addresses of this rank's pack (ZF_PACK_LEN doubles) and of the gathered
- * packs (world x ZF_PACK_LEN doubles, rank-major) */
+/* device addresses of this rank's packs (sub_iters x ZF_PACK_LEN doubles) and of the gathered
+ * packs (world x sub_iters x ZF_PACK_LEN doubles, rank-major); zf_solver_sub_iters() tells S */
+int zf_solver_sub_iters(zf_solver* s, int32_t* sub_iters);
+/* change max_iter of a live solve (stream-ordered); a solve stopped by ZF_MAXITER resumes when
+ * the new bound is above nit - how a caller continues `res.nit < max_iter` runs (:539) */
+int zf_solver_set_max_iter(zf_solver* s, int64_t max_iter);
 int zf_solver_pack_ptrs(zf_solver* s, double** pack_local_dev, double** pack_all_dev);
 /* make the solver write / read caller-owned pack buffers instead (e.g. torch
  * tensors the collective runs on); sizes as above; must outlive the solver */

@@ -44,6 +44,9 @@ class FakeSolver:
         c.status = _lib.ZF_BACKTRACK_FAILED if c.max_backtrack == 0 else _lib.ZF_RUNNING
         c.nesterov, c.deprecated = options["nesterov"], options["deprecated"]
         c.need_grad, c.world, c.cur = 1, self.world, 0
+        c.ring_size, c.sub_iters, c.prev = 3, 1, 2
+        c.plan_n, c.cut_at, c.ncuts = 1, -1, 0
+        self.sub_iters = 1
         self.ctl = c
         self.trace = np.zeros((_lib.ZF_RING, _lib.ZF_TRACE_COLS))
         self.beta = np.zeros(_lib.ZF_RING)
@@ -71,14 +74,14 @@ class FakeSolver:
 
     def _trial_pack(self):
         c, p = self.ctl, self.p
-        xk, xo = self.xb[c.cur], self.xb[(c.cur + 2) % 3]
+        xk, xo = self.xb[c.cur], self.xb[c.prev]
         beta = self.beta[c.nit % _lib.ZF_RING] if c.nesterov else 0.0
         y = xk + beta * (xk - xo) if c.nesterov else xk
         ref = P.DiagQuadL1Ref(p.d, p.c, p.lam)
         grad = ref.jac_f(y)
         xn = ref.prox_wsum_g(c.lr, y - c.lr * grad)
         dx = xn - y
-        self.xb[(c.cur + 1) % 3] = xn
+        self.xb[3 - c.cur - c.prev] = xn   # the buffer holding neither x_k nor x_{k-1}
         return np.array([ref.f(y), grad @ dx, np.sum(dx * dx), ref.g(xn), ref.f(xn),
                          np.max(np.abs(dx)) if dx.size else 0.0, 0.0, 0.0])
 

@@ -30,9 +30,9 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_struct_mirrors():
     lib = _lib.load()
-    assert lib.zf_sizeof_control() == C.sizeof(_lib.Control) == 152
+    assert lib.zf_sizeof_control() == C.sizeof(_lib.Control) == 176
     assert C.sizeof(_lib.ProblemDesc) == 96
-    assert C.sizeof(_lib.Options) == 56
+    assert C.sizeof(_lib.Options) == 64
 
 
 def test_error_reporting_is_c_style():

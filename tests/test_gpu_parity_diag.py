@@ -180,7 +180,7 @@ def test_diag_n1e8_properties():
     o = dict(lr=0.45, tol=1e-9, tol_internal=1e-12, max_iter=5, max_backtrack_iter=100, decay_rate=0.5,
              nesterov=True, nesterov_ratio=(0, 0.25), deprecated=False)
     run = NativeRun(prob, xstar, o)
-    rows = run.advance(1)
+    rows = run.advance(2)   # a chain that terminates at its first trial is run again, one trial long
     assert run.status == _lib.ZF_CONVERGED and len(rows) == 1
     assert rows[0, _lib.TR_ERR] <= 1e-15
     Fstar = rows[0, _lib.TR_F]

@@ -149,11 +149,12 @@ def test_sharded_lockstep_matches_oracle(kw, world):
     seen = 0
     while status == _lib.ZF_RUNNING:
         chunk = 50
-        # factors for accepted counts <= seen + chunk: the last decide resolves the next trial's
-        if kw["nesterov"] and seen + chunk + 1 > filled:
+        ahead = chunk * solvers[0].sub_iters   # a pass may accept up to sub_iters iterations
+        # factors for accepted counts <= seen + ahead: the last decide resolves the next trial's
+        if kw["nesterov"] and seen + ahead + 1 > filled:
             for s in solvers:
-                s.set_beta(filled, betas[filled:seen + chunk + 1])
-            filled = min(seen + chunk + 1, betas.size)
+                s.set_beta(filled, betas[filled:seen + ahead + 1])
+            filled = min(seen + ahead + 1, betas.size)
         for _ in range(chunk):
             for s in solvers:
                 s.enqueue_trial()

@@ -421,27 +421,36 @@ template <int FB> void run_split(const Bufs& B) {
     printf("SPLIT  streaming + finalize_fast<%2d> : %7.3f ms per step (loop of %d)\n", FB, ms / K, K);
 }
 // the shipped pair: library trial kernel (plain partial stores) + library finalize/decide kernel
-template <bool NT> void run_lib_loop(const Bufs& B, int T) {
+template <bool NT, int S> void run_lib_loop(const Bufs& B, int T) {
     const int64_t n2 = B.n / 2;
     const int64_t nt_all = (n2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
     int grid = (int)((nt_all + T - 1) / T);
     zf_control h; memset(&h, 0, sizeof(h)); h.lr = 0.45; h.status = ZF_RUNNING; h.world = 1; h.max_iter = 1 << 30;
     h.max_backtrack = 100; h.decay_rate = 0.5; h.tol_internal = 1e300; h.F_old = 1e300; h.nesterov = 1;
+    constexpr int RINGSZ = S > 1 ? 4 : 3;
+    h.ring_size = RINGSZ; h.sub_iters = S; h.prev = RINGSZ - 1; h.plan_n = S; h.cut_at = -1; h.ncuts = 0;
     zf_control* ctl; CK(hipMalloc(&ctl, sizeof(h))); CK(hipMemcpy(ctl, &h, sizeof(h), hipMemcpyHostToDevice));
     double *beta, *trace, *pack; zf_step_args A; zf_finalize_args F;
     CK(hipMalloc(&beta, 8 * ZF_RING)); CK(hipMemset(beta, 0, 8 * ZF_RING)); CK(hipMalloc(&trace, 8 * ZF_RING * 8));
-    CK(hipMalloc(&pack, 64)); CK(hipMalloc(&F.cnt, 64)); CK(hipMemset(F.cnt, 0, 64));
-    CK(hipMalloc(&A.blk_part, 8 * ZF_NPART * grid)); CK(hipMalloc(&F.slice_part, 8 * ZF_NPART * ZF_FIN_WGS));
-    A.ctl = ctl; A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[2] = B.xo; A.p0 = B.d; A.p1 = B.c;
+    CK(hipMalloc(&pack, 64 * S)); CK(hipMalloc(&F.cnt, 64)); CK(hipMemset(F.cnt, 0, 64));
+    CK(hipMalloc(&A.blk_part, 8 * ZF_NPART * S * grid)); CK(hipMalloc(&F.slice_part, 8 * ZF_NPART * S * ZF_FIN_WGS));
+    A.ctl = ctl; A.beta_ring = beta;
+    double* extra[ZF_MAX_RING] = {};
+    for (int k = 0; k < ZF_MAX_RING; ++k) A.xb[k] = B.xk;
+    A.xb[0] = B.xk; A.xb[1] = B.xn; A.xb[RINGSZ - 1] = B.xo;     // ring: x_k, free..., x_{k-1}
+    for (int k = 2; k < RINGSZ - 1; ++k) { CK(hipMalloc(&extra[k], 8 * B.n)); A.xb[k] = extra[k]; }
+    A.p0 = B.d; A.p1 = B.c;
     A.lam = 0.1; A.lo = 0; A.hi = 0; A.n = B.n; A.tiles_per_wg = T;
-    F.blk_part = A.blk_part; F.nblocks = grid; for (int k = 0; k < ZF_NPART; ++k) F.scale[k] = 1.0;
+    F.blk_part = A.blk_part; F.nblocks = grid; F.sub_iters = S; for (int k = 0; k < ZF_NPART; ++k) F.scale[k] = 1.0;
     F.f_y_ext = F.f_x_ext = nullptr; F.contribute_f = 1; F.pack = pack; F.ctl = ctl; F.decide = 1; F.trace = trace; F.beta_ring = beta;
     int wgs = (grid + ZF_FIN_THREADS - 1) / ZF_FIN_THREADS; if (wgs > ZF_FIN_WGS) wgs = ZF_FIN_WGS; if (wgs < 1) wgs = 1;
     const int K = 20;
     double ms = time_ms([&] { for (int k = 0; k < K; ++k) {
-        hipLaunchKernelGGL((zf_trial_kernel<true, true, false, NT>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A);
-        hipLaunchKernelGGL(zf_finalize_kernel, dim3(wgs), dim3(ZF_FIN_THREADS), 0, 0, F); } }, 5);
-    printf("LIBRARY trial + finalize  T=%d nt=%d : %7.3f ms per step (loop of %d)\n", T, (int)NT, ms / K, K);
+        hipLaunchKernelGGL((zf_trial_kernel<true, true, false, NT, S>), dim3(grid), dim3(ZF_BLOCK), 0, 0, A);
+        hipLaunchKernelGGL(zf_finalize_kernel<S>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, 0, F); } }, 5);
+    printf("LIBRARY trial + finalize  S=%d T=%d nt=%d : %7.3f ms per pass = %7.3f ms per iteration (loop of %d)\n",
+           S, T, (int)NT, ms / K, ms / K / S, K);
+    for (int k = 2; k < RINGSZ - 1; ++k) CK(hipFree(extra[k]));
 }
 template <int LEVEL> void run_dbg(const Bufs& B) {
     const int64_t n2 = B.n / 2;
@@ -488,7 +497,10 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; ++rep) {
         run_c<4, 256, 9>(B);
         run_split<16>(B);
-        run_lib_loop<true>(B, 1); run_lib_loop<true>(B, 2); run_lib_loop<true>(B, 4); run_lib_loop<false>(B, 1);
+        run_lib_loop<true, 1>(B, 1); run_lib_loop<true, 1>(B, 2); run_lib_loop<true, 1>(B, 4); run_lib_loop<false, 1>(B, 1);
+        run_lib_loop<true, 2>(B, 1); run_lib_loop<true, 2>(B, 2); run_lib_loop<false, 2>(B, 1);
+        run_lib_loop<true, 4>(B, 1); run_lib_loop<true, 4>(B, 2); run_lib_loop<true, 4>(B, 4); run_lib_loop<false, 4>(B, 1);
+        run_lib_loop<true, 8>(B, 1); run_lib_loop<true, 8>(B, 2); run_lib_loop<true, 8>(B, 4); run_lib_loop<false, 8>(B, 1);
     }
     return 0;
 }

@@ -45,6 +45,8 @@ class Control(C.Structure):
         ("status", C.c_int32), ("cur", C.c_int32), ("nesterov", C.c_int32),
         ("deprecated", C.c_int32), ("need_grad", C.c_int32), ("world", C.c_int32),
         ("beta_next", C.c_double),
+        ("ring_size", C.c_int32), ("sub_iters", C.c_int32), ("prev", C.c_int32),
+        ("plan_n", C.c_int32), ("cut_at", C.c_int32), ("ncuts", C.c_int32),
     ]
 
 
@@ -61,7 +63,7 @@ class Options(C.Structure):
     _fields_ = [
         ("lr", C.c_double), ("tol", C.c_double), ("tol_internal", C.c_double),
         ("decay_rate", C.c_double), ("max_iter", C.c_int64), ("max_backtrack_iter", C.c_int64),
-        ("nesterov", C.c_int32), ("deprecated", C.c_int32),
+        ("nesterov", C.c_int32), ("deprecated", C.c_int32), ("sub_iters", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -90,6 +92,8 @@ SIGNATURES = {
     "zf_solver_autotune": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "zf_solver_enqueue_trial": (C.c_int, [_P]),
     "zf_solver_enqueue_decide": (C.c_int, [_P]),
+    "zf_solver_sub_iters": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "zf_solver_set_max_iter": (C.c_int, [_P, C.c_int64]),
     "zf_solver_pack_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "zf_solver_set_pack_buffers": (C.c_int, [_P, _P, _P]),
     "zf_solver_svec_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),

@@ -81,6 +81,48 @@ __device__ __forceinline__ void zf_block_reduce(const double (&sums)[NS], const 
     }
 }
 
+// Wave reduction of N values per lane at once, for N = C * 2^H.  The pairing is the xor
+// butterfly 32, 16, ... 1 - the tree zf_wave_sum builds for lane 0 (a + b == b + a exactly) -
+// but during the first H levels each partner keeps only HALF of the values and hands the other
+// half over, so a level costs N/2, N/4, ... exchanges instead of N.  On return slot q < C of
+// lane L holds the wave total of the value with index
+//     q + sum over levels l < H of ((L & (32 >> l)) ? N >> (l + 1) : 0);
+// all lanes that agree in their top H bits hold the same totals.
+template <int N, int H, bool IS_MAX>
+__device__ __forceinline__ void zf_wave_reduce_multi(double (&v)[N], int lane) {
+    static_assert(N % (1 << H) == 0, "N must be a multiple of 2^H");
+#pragma unroll
+    for (int lvl = 0; lvl < 6; ++lvl) {
+        const int off = 32 >> lvl;
+        if (lvl < H) {
+            const int half = N >> (lvl + 1);
+            const bool hi = (lane & off) != 0;
+#pragma unroll
+            for (int q = 0; q < half; ++q) {
+                const double send = hi ? v[q] : v[q + half];
+                const double keep = hi ? v[q + half] : v[q];
+                const double recv = __shfl_xor(send, off, 64);
+                v[q] = IS_MAX ? fmax(keep, recv) : keep + recv;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < (N >> H); ++q) {
+                const double recv = __shfl_xor(v[q], off, 64);
+                v[q] = IS_MAX ? fmax(v[q], recv) : v[q] + recv;
+            }
+        }
+    }
+}
+// index of the value whose total ends in slot q of lane `lane` (see above)
+template <int N, int H>
+__device__ __forceinline__ int zf_wave_reduce_multi_index(int q, int lane) {
+    int idx = q;
+#pragma unroll
+    for (int lvl = 0; lvl < H; ++lvl)
+        if (lane & (32 >> lvl)) idx += N >> (lvl + 1);
+    return idx;
+}
+
 // soft-threshold, prox of tau*|.|:  sign(u) * max(|u| - tau, 0)
 // (jaxopt.prox.prox_lasso as used at zfista/problems.py:128-135 and
 // tests/test_proximal_gradient.py:61).  NaN propagates as in NumPy.

@@ -11,6 +11,20 @@
 // The arithmetic is plain IEEE double with contraction disabled (the library
 // is built with -ffp-contract=off) so the branch decisions are the ones NumPy
 // scalars would take on the same reduced sums.
+//
+// Temporal blocking (separable f): one pass of the trial kernel chains up to S trials in
+// registers, each assuming the previous one was accepted, and stores only the last two
+// iterates of the chain.  zf_decide_pass() examines the S packs in order on a COPY of the
+// control block.  If the whole chain holds, the copy is committed.  If the chain breaks at
+// trial a (a rejection, or a termination before the last trial):
+//   a == 0  -> nothing of the chain was accepted: the rejection itself (lr decay, trial
+//              counters, possibly failure) is committed;
+//   a  > 0  -> the a accepted iterates were never stored, so nothing is committed; the PLAN of
+//              the next pass is set instead: the same a trials again (same inputs, same sums,
+//              same decisions), followed - after a rejection - by trials at the reduced step
+//              size, or - after a termination - by nothing.
+// Either way every committed state is one the one-trial-per-pass loop passes through, with the
+// same sums: results do not depend on S.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -31,10 +45,11 @@ enum { ZF_PK_FY = 0, ZF_PK_DOT = 1, ZF_PK_SS = 2, ZF_PK_GX = 3, ZF_PK_FX = 4, ZF
 enum { ZF_TR_ERR = 0, ZF_TR_F = 1, ZF_TR_LR = 2, ZF_TR_FUN = 3, ZF_TR_TRIALS = 4,
        ZF_TR_FX = 5, ZF_TR_GX = 6, ZF_TR_FY = 7 };
 
-ZF_HD inline void zf_reduce_packs(const double* packs, int world, double* out) {
+// `stride` = doubles between the packs of consecutive ranks (ZF_PACK_LEN x trials per pass)
+ZF_HD inline void zf_reduce_packs(const double* packs, int world, int stride, double* out) {
     for (int k = 0; k < ZF_PACK_LEN; ++k) out[k] = packs[k];
     for (int r = 1; r < world; ++r) {
-        const double* p = packs + (int64_t)r * ZF_PACK_LEN;
+        const double* p = packs + (int64_t)r * stride;
         for (int k = 0; k < ZF_PACK_LEN; ++k) {
             if (k == ZF_PK_ERR) out[k] = (p[k] > out[k] || p[k] != p[k]) ? p[k] : out[k];
             else out[k] = out[k] + p[k];
@@ -42,13 +57,44 @@ ZF_HD inline void zf_reduce_packs(const double* packs, int world, double* out) {
     }
 }
 
-// beta_ring (may be NULL on the host): momentum ring indexed by the accepted-iteration count;
-// on acceptance the factor of the NEXT trial is copied into the control block.
-ZF_HD inline void zf_decide_step(zf_control* c, const double* packs, double* trace,
-                                 const double* beta_ring = nullptr) {
-    if (c->status != ZF_RUNNING) return;
+// The x ring: x_k in buffer `cur`, x_{k-1} in `prev`; a pass writes into the lowest-numbered
+// buffers that hold neither.  One trial: x+ -> *first.  A chain of n >= 2 trials:
+// x_{k+n-1} -> *first, x_{k+n} -> *second (ring_size 4).
+ZF_HD inline void zf_free_bufs(int cur, int prev, int ring, int* first, int* second) {
+    int f[2] = {-1, -1}, m = 0;
+    for (int i = 0; i < ring && m < 2; ++i)
+        if (i != cur && i != prev) f[m++] = i;
+    *first = f[0];
+    *second = (m > 1) ? f[1] : f[0];
+}
+
+// trials of the next pass: the plan, bounded by the iterations left (:539)
+ZF_HD inline int zf_plan_len(const zf_control* c) {
+    int64_t n = c->plan_n > 0 ? c->plan_n : 1;
+    const int64_t left = c->max_iter - c->nit;
+    if (n > left) n = left;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+// a rejection observed by an earlier pass at this position of the chain (:305-307)
+ZF_HD inline void zf_apply_known_reject(zf_control* c) {
+    c->trial += 1;
+    c->total_trials += 1;
+    c->lr = c->lr * c->decay_rate;
+    c->need_grad = 0;
+    if (c->trial >= c->max_backtrack) c->status = ZF_BACKTRACK_FAILED;
+}
+
+// One trial against the control block *c (buffer indices are not touched: the caller commits
+// them).  beta_ring (may be NULL on the host): momentum ring indexed by the accepted-iteration
+// count; on acceptance the factor of the NEXT trial is copied into the control block.
+// Returns true when the trial was accepted and the loop goes on.
+ZF_HD inline bool zf_decide_step(zf_control* c, const double* packs, double* trace,
+                                 const double* beta_ring = nullptr, int pack_stride = ZF_PACK_LEN) {
+    if (c->status != ZF_RUNNING) return false;
     double pk[ZF_PACK_LEN];
-    zf_reduce_packs(packs, c->world, pk);
+    zf_reduce_packs(packs, c->world, pack_stride, pk);
     const double f_y = pk[ZF_PK_FY], dot = pk[ZF_PK_DOT], ss = pk[ZF_PK_SS];
     const double g_x = pk[ZF_PK_GX], f_x = pk[ZF_PK_FX], err = pk[ZF_PK_ERR];
     const double lr = c->lr;
@@ -71,7 +117,7 @@ ZF_HD inline void zf_decide_step(zf_control* c, const double* packs, double* tra
         c->lr = lr * c->decay_rate;                                           // :305
         c->need_grad = 0;   // y_k unchanged: grad f(y_k), f(y_k) stay valid
         if (c->trial >= c->max_backtrack) c->status = ZF_BACKTRACK_FAILED;    // :306-307
-        return;
+        return false;
     }
     const int64_t nit = c->nit + 1;
     double* row = trace + ((nit - 1) % ZF_RING) * ZF_TRACE_COLS;
@@ -90,9 +136,79 @@ ZF_HD inline void zf_decide_step(zf_control* c, const double* packs, double* tra
     c->err = err;
     c->fun = fun;
     c->trial = 0;
-    c->cur = (c->cur + 1) % 3;   // x+ becomes x_k; old x_k becomes x_{k-1} (:538)
     c->need_grad = 1;
     if (beta_ring) c->beta_next = beta_ring[nit % ZF_RING];   // y_{k+1} = x_k + beta (x_k - x_{k-1})  :533-534
     if (err < c->tol) c->status = ZF_CONVERGED;               // :525
     else if (nit >= c->max_iter) c->status = ZF_MAXITER;      // :539
+    return c->status == ZF_RUNNING;
+}
+
+// All trials of one pass.  packs: world x sub_iters x ZF_PACK_LEN (rank-major), pack j of a
+// rank = trial j of the chain.
+ZF_HD inline void zf_decide_pass(zf_control* ctl, const double* packs, double* trace,
+                                 const double* beta_ring = nullptr) {
+    if (ctl->status != ZF_RUNNING) return;
+    const int sub = ctl->sub_iters > 0 ? ctl->sub_iters : 1;
+    const int ring = ctl->ring_size > 0 ? ctl->ring_size : 3;
+    const int stride = sub * ZF_PACK_LEN;
+    const int n = zf_plan_len(ctl);
+    const int cut_at = ctl->cut_at, ncuts = ctl->ncuts;
+
+    zf_control c = *ctl;   // the chain is examined on a copy
+    int accepted = 0;
+    bool rejected = false;
+    for (int j = 0; j < n; ++j) {
+        if (j == cut_at) {
+            for (int r = 0; r < ncuts && c.status == ZF_RUNNING; ++r) zf_apply_known_reject(&c);
+            if (c.status != ZF_RUNNING) break;
+        }
+        const int64_t before = c.nit;
+        const bool go = zf_decide_step(&c, packs + j * ZF_PACK_LEN, trace, beta_ring, stride);
+        if (c.nit > before) accepted += 1;
+        else rejected = true;
+        if (!go) break;
+    }
+
+    c.plan_n = sub;
+    c.cut_at = -1;
+    c.ncuts = 0;
+    if (accepted == n) {
+        // the whole chain holds: its last two iterates are what the pass stored (:538)
+        if (cut_at >= n && c.status == ZF_RUNNING)
+            for (int r = 0; r < ncuts && c.status == ZF_RUNNING; ++r) zf_apply_known_reject(&c);
+        int first, second;
+        zf_free_bufs(ctl->cur, ctl->prev, ring, &first, &second);
+        if (n == 1) {
+            c.prev = ctl->cur;
+            c.cur = first;
+        } else {
+            c.prev = first;
+            c.cur = second;
+        }
+        *ctl = c;
+        return;
+    }
+    if (accepted == 0) {
+        // the first trial of the chain failed: x_k, x_{k-1} unchanged, the rejection stands
+        *ctl = c;
+        return;
+    }
+    // 0 < accepted < n: the accepted iterates exist in no buffer.  Plan the pass again.
+    const bool keep_cut = (cut_at >= 0 && cut_at < accepted);
+    int plan_n = accepted, new_cut = keep_cut ? cut_at : -1, new_ncuts = keep_cut ? ncuts : 0;
+    if (rejected && c.status == ZF_RUNNING) {
+        if (cut_at == accepted) {            // rejected again at the same position
+            plan_n = sub;
+            new_cut = accepted;
+            new_ncuts = ncuts + 1;
+        } else if (!keep_cut) {              // first rejection of this chain
+            plan_n = sub;
+            new_cut = accepted;
+            new_ncuts = 1;
+        }
+        // else: a second cut position - stop exactly before it; the next pass meets it as trial 0
+    }
+    ctl->plan_n = plan_n;
+    ctl->cut_at = new_cut;
+    ctl->ncuts = new_ncuts;
 }

@@ -1,9 +1,9 @@
 // zf_kernels_step.h - the fused trial kernels of the single-objective path.
 //
-// One HBM pass per line-search trial.  For the separable problem (P-diag) the
-// pass reads x_k, x_{k-1}, d, c and writes x+ : 40 B per element, which is the
-// algorithmic minimum; y_k, grad f(y_k) and all six reductions
-// live in registers.  Reference sites carried by the element body:
+// One HBM pass per line-search trial - or, for the separable problem (P-diag), per CHAIN of up
+// to S trials (temporal blocking, see zf_trial_kernel).  A one-trial pass reads x_k, x_{k-1},
+// d, c and writes x+ : 40 B per element; y_k, grad f(y_k) and all six
+// reductions live in registers.  Reference sites carried by the element body:
 //   y  = x_k + beta (x_k - x_{k-1})          proximal_gradient.py:534
 //   v  = y - lr * grad f(y)                  proximal_gradient.py:148
 //   x+ = prox_{lr g}(v)                      proximal_gradient.py:148 (callback :13)
@@ -87,6 +87,9 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
 // single-workgroup finalize with dependent load rounds 0.849 / 0.098 ms.
 // ---------------------------------------------------------------------------
 constexpr int ZF_TILE_U = 4;
+#ifndef ZF_S8_UB
+#define ZF_S8_UB 4   // units per load batch of the 8-trial chain (tools/tune_trial.hip: 4 is 3 % faster than 2)
+#endif
 constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per tile
 constexpr int ZF_MAX_TILES_PER_WG = 8;                // upper bound of zf_step_args.tiles_per_wg
 constexpr int ZF_FIN_WGS = 48;                        // workgroups of the finalize kernel
@@ -109,72 +112,85 @@ __device__ __forceinline__ double zf_consume(const double* p) {     // sc1 load,
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int ZF_MAX_SUB = ZF_MAX_SUB_ITERS;   // trials chained per pass (temporal blocking), upper bound
+constexpr int ZF_MAX_RING = 4;
+
 struct zf_step_args {
     const zf_control* ctl;
-    double* xb[3];            // x ring
+    const double* beta_ring;  // momentum ring: trial j > 0 of a chain uses beta_ring[(nit + j) % ZF_RING]
+    double* xb[ZF_MAX_RING];  // x ring of ctl->ring_size buffers
     const double* p0;         // diag: d        vec: grad
     const double* p1;         // diag: c        vec: unused
     double lam, lo, hi;
     int64_t n;
     int tiles_per_wg;         // interleaved tiles per workgroup (1 .. ZF_MAX_TILES_PER_WG)
-    double* blk_part;         // ZF_NPART x gridDim.x per-workgroup partials, quantity-major
+    double* blk_part;         // (S * ZF_NPART) x gridDim.x per-workgroup partials, quantity-major
 };
 
 struct zf_finalize_args {
-    const double* blk_part;   // ZF_NPART x nblocks (written by the trial kernel)
+    const double* blk_part;   // (S * ZF_NPART) x nblocks (written by the trial kernel)
     int nblocks;
-    double* slice_part;       // ZF_NPART x ZF_FIN_WGS
+    int sub_iters;            // S
+    double* slice_part;       // (S * ZF_NPART) x ZF_FIN_WGS
     unsigned* cnt;            // arrival counter of the finalize workgroups (zero between launches)
     double scale[ZF_NPART];   // pack[k] = scale[k] * total[k]
     const double* f_y_ext;    // least squares: f(y), f(x+) come from the GEMV side (else NULL)
     const double* f_x_ext;
     int contribute_f;         // sharded least squares: only rank 0 contributes the replicated f values
-    double* pack;             // local pack out (ZF_PACK_LEN)
+    double* pack;             // local packs out (S x ZF_PACK_LEN)
     zf_control* ctl;          // read for the early exit; written when `decide`
-    int decide;               // unsharded x: run the decide step here
+    int decide;               // unsharded x: run the decide pass here
     double* trace;
     const double* beta_ring;
 };
 
-// Second launch of a step.  Every workgroup adds its slice of the per-workgroup partials
-// (thread t takes workgroups t, t+1024, ... of the slice: index order; six independent loads per
-// index), publishes the slice totals write-through and takes a ticket; the last arriver adds
-// the ZF_FIN_WGS slices in slice order, builds the pack and (decide) runs the decide step:
-// model value, acceptance, lr decay, failure, termination, buffer rotation, trace row
-// (proximal_gradient.py:149-155,:298-307,:510,:525,:539).  Deterministic: no float atomics,
-// sums in index order.
+// Second launch of a step.  The trial kernel left S x 6 partial rows per workgroup (S = trials
+// of the chain).  Every finalize workgroup adds its slice of them (thread t takes workgroups
+// t, t+1024, ... of the slice: index order; the loads of one index are independent), publishes
+// the slice totals write-through and takes a ticket; the last arriver's wave 0 adds the <= 48
+// slices lane-parallel in slice order, builds the S packs and (decide) runs zf_decide_pass:
+// model value, acceptance, lr decay, failure, termination, buffer hand-over, trace rows
+// (proximal_gradient.py:149-155,:298-307,:510,:525,:539) for the trials of the chain in order.
+// Deterministic: no float atomics, sums in index order.
+template <int S>
 __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize_args F) {
-    __shared__ double lds[(ZF_FIN_THREADS / 64) * 8];
+    constexpr int NQ = S * ZF_NPART;
+    constexpr int QG = (NQ > 24) ? 24 : NQ;   // quantities per round (register budget at 1024 threads)
+    constexpr int NW = ZF_FIN_THREADS / 64;
+    __shared__ double lds[NW * NQ];
     __shared__ int s_last;
     if (F.ctl->status != ZF_RUNNING) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = ZF_FIN_THREADS / 64;
     const int per = (F.nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
     const int b0 = blockIdx.x * per;
     int b1 = b0 + per;
     if (b1 > F.nblocks) b1 = F.nblocks;
-    double v[ZF_NPART];
 #pragma unroll
-    for (int k = 0; k < ZF_NPART; ++k) v[k] = 0.0;
-    for (int b = b0 + threadIdx.x; b < b1; b += ZF_FIN_THREADS) {
-        double p[ZF_NPART];
+    for (int q0 = 0; q0 < NQ; q0 += QG) {
+        double v[QG];
 #pragma unroll
-        for (int k = 0; k < ZF_NPART; ++k) p[k] = F.blk_part[(int64_t)k * F.nblocks + b];
+        for (int k = 0; k < QG; ++k) v[k] = 0.0;
+        for (int b = b0 + threadIdx.x; b < b1; b += ZF_FIN_THREADS) {
+            double p[QG];
 #pragma unroll
-        for (int k = 0; k < ZF_NPART - 1; ++k) v[k] += p[k];
-        v[ZF_NPART - 1] = fmax(v[ZF_NPART - 1], p[ZF_NPART - 1]);
-    }
+            for (int k = 0; k < QG; ++k) p[k] = F.blk_part[(int64_t)(q0 + k) * F.nblocks + b];
 #pragma unroll
-    for (int k = 0; k < ZF_NPART; ++k) {
-        const double r = (k == ZF_NPART - 1) ? zf_wave_max(v[k]) : zf_wave_sum(v[k]);
-        if (lane == 0) lds[wave * 8 + k] = r;
+            for (int k = 0; k < QG; ++k)
+                v[k] = ((q0 + k) % ZF_NPART == ZF_NPART - 1) ? fmax(v[k], p[k]) : v[k] + p[k];
+        }
+#pragma unroll
+        for (int k = 0; k < QG; ++k) {
+            const double r = ((q0 + k) % ZF_NPART == ZF_NPART - 1) ? zf_wave_max(v[k]) : zf_wave_sum(v[k]);
+            if (lane == 0) lds[wave * NQ + q0 + k] = r;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 64) {
-        if (threadIdx.x < ZF_NPART) {
+        if (threadIdx.x < NQ) {
             const int k = threadIdx.x;
             double r = lds[k];
-            for (int w = 1; w < NW; ++w) r = (k == ZF_NPART - 1) ? fmax(r, lds[w * 8 + k]) : r + lds[w * 8 + k];
+            for (int w = 1; w < NW; ++w)
+                r = (k % ZF_NPART == ZF_NPART - 1) ? fmax(r, lds[w * NQ + k]) : r + lds[w * NQ + k];
             zf_publish(F.slice_part + (int64_t)k * ZF_FIN_WGS + blockIdx.x, r);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -191,73 +207,134 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     }
     __syncthreads();
     if (!s_last || wave != 0) return;
-    // last arriver, wave 0: lane q holds slice q (six independent sc1 loads: one round trip),
+    // last arriver, wave 0: lane q holds slice q (independent sc1 loads: one round trip),
     // then the fixed shuffle tree adds the slices in slice order
-    double tot[ZF_NPART];
+    double tot[NQ];
 #pragma unroll
-    for (int k = 0; k < ZF_NPART; ++k)
+    for (int k = 0; k < NQ; ++k)
         tot[k] = (lane < (int)gridDim.x) ? zf_consume(F.slice_part + (int64_t)k * ZF_FIN_WGS + lane) : 0.0;
 #pragma unroll
-    for (int k = 0; k < ZF_NPART; ++k) tot[k] = (k == ZF_NPART - 1) ? zf_wave_max(tot[k]) : zf_wave_sum(tot[k]);
+    for (int k = 0; k < NQ; ++k) tot[k] = (k % ZF_NPART == ZF_NPART - 1) ? zf_wave_max(tot[k]) : zf_wave_sum(tot[k]);
     if (lane != 0) return;
-    double* pack = F.pack;
-    pack[ZF_PK_FY] = F.f_y_ext ? (F.contribute_f ? *F.f_y_ext : 0.0) : F.scale[0] * tot[0];
-    pack[ZF_PK_DOT] = tot[1];
-    pack[ZF_PK_SS] = tot[2];
-    pack[ZF_PK_GX] = F.scale[3] * tot[3];
-    pack[ZF_PK_FX] = F.f_x_ext ? (F.contribute_f ? *F.f_x_ext : 0.0) : F.scale[4] * tot[4];
-    pack[ZF_PK_ERR] = tot[5];
-    pack[6] = 0.0;
-    pack[7] = 0.0;
-    if (F.decide) zf_decide_step(F.ctl, pack, F.trace, F.beta_ring);
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        double* pack = F.pack + j * ZF_PACK_LEN;
+        const double* t = tot + j * ZF_NPART;
+        pack[ZF_PK_FY] = F.f_y_ext ? (F.contribute_f ? *F.f_y_ext : 0.0) : F.scale[0] * t[0];
+        pack[ZF_PK_DOT] = t[1];
+        pack[ZF_PK_SS] = t[2];
+        pack[ZF_PK_GX] = F.scale[3] * t[3];
+        pack[ZF_PK_FX] = F.f_x_ext ? (F.contribute_f ? *F.f_x_ext : 0.0) : F.scale[4] * t[4];
+        pack[ZF_PK_ERR] = t[5];
+        pack[6] = 0.0;
+        pack[7] = 0.0;
+    }
+    if (F.decide) zf_decide_pass(F.ctl, F.pack, F.trace, F.beta_ring);
 }
 
 // GRAD_INLINE: true  -> separable quadratic, gradient computed from d, c
-//              false -> gradient vector read from HBM (least squares)
+//              false -> gradient vector read from HBM (least squares; S = 1 only)
 // NT: nontemporal policy for the once-touched streams (p0, p1 loads, x+ stores)
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT>
+// S:  trials chained per pass (temporal blocking).  For a separable f the whole recursion
+//     x_{k+1} = prox(y_k - lr grad f(y_k)), y_{k+1} = x_{k+1} + beta_{k+1} (x_{k+1} - x_k)
+//     is elementwise, so one pass over x_k, x_{k-1}, d, c can run the next S iterations of an
+//     element in registers (each assuming the one before was accepted), emit the six reductions
+//     of EVERY trial and store only the last two iterates of the chain: 48 bytes per element
+//     for S iterations instead of 40 S.  zf_decide_pass (zf_decide.h) then examines the S
+//     acceptance / termination tests in order on exactly the sums a one-trial pass would have
+//     produced; a chain that breaks in the middle is planned again up to the break (ctl->plan_n)
+//     and continued at the reduced step size (ctl->cut_at, ctl->ncuts), so iterates, traces and
+//     decisions are bit-identical to S = 1 (tests/test_gpu_temporal.py).
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
-    __shared__ double lds[ZF_WAVES * 8 + 8];
-    // wave-uniform control reads (scalar loads); written by the previous launch's decide step
+    static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
+    __shared__ double lds[ZF_WAVES * S * ZF_NPART];
+    // wave-uniform control reads (scalar loads); written by the previous step's decide
     const int status = A.ctl->status;
     if (status != ZF_RUNNING) return;
     const int cur = A.ctl->cur;
+    const int prev = A.ctl->prev;
+    const int ring = A.ctl->ring_size;
     const double lr = A.ctl->lr;
-    const double beta = NESTEROV ? A.ctl->beta_next : 0.0;   // same cache line as status / cur / lr
-    const double tau = A.lam * lr;   // oracle: soft_threshold(x, lam * weight)
+    const int ntr = (S == 1) ? 1 : zf_plan_len(A.ctl);   // trials of this chain
+    double beta[S], lrj[S], tau[S];
+    beta[0] = NESTEROV ? A.ctl->beta_next : 0.0;   // same cache line as status / cur / lr
+    lrj[0] = lr;
+    if (S > 1) {
+        const int64_t nit = A.ctl->nit;
+        const int cut_at = A.ctl->cut_at, ncuts = A.ctl->ncuts;
+        double lr_cut = lr;
+        for (int r = 0; r < ncuts; ++r) lr_cut = lr_cut * A.ctl->decay_rate;   // :305, once per known rejection
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            if (j > 0) beta[j] = NESTEROV ? A.beta_ring[(nit + j) % ZF_RING] : 0.0;
+            lrj[j] = (cut_at >= 0 && j >= cut_at) ? lr_cut : lr;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) tau[j] = A.lam * lrj[j];   // oracle: soft_threshold(x, lam * weight)
+    int first, second;
+    zf_free_bufs(cur, prev, ring, &first, &second);
     const double* __restrict__ xk = A.xb[cur];
-    const double* __restrict__ xo = A.xb[(cur + 2) % 3];
-    double* __restrict__ xn = A.xb[(cur + 1) % 3];
+    const double* __restrict__ xo = A.xb[prev];
+    double* __restrict__ out_last = A.xb[ntr == 1 ? first : second];   // x_{k+ntr}
+    double* __restrict__ out_prev = A.xb[first];                       // x_{k+ntr-1} when ntr >= 2
     const double* __restrict__ p0 = A.p0;
     const double* __restrict__ p1 = A.p1;
     const int64_t n = A.n;
 
-    zf_elem_acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    zf_elem_acc acc[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     const int64_t n2 = n >> 1;  // 16-byte units
     const zf_d2* __restrict__ xk2 = reinterpret_cast<const zf_d2*>(xk);
     const zf_d2* __restrict__ xo2 = reinterpret_cast<const zf_d2*>(xo);
     const zf_d2* __restrict__ p02 = reinterpret_cast<const zf_d2*>(p0);
     const zf_d2* __restrict__ p12 = reinterpret_cast<const zf_d2*>(p1);
-    zf_d2* __restrict__ xn2 = reinterpret_cast<zf_d2*>(xn);
+
+    // one 16-byte unit through the chain (a = x_k, o = x_{k-1} on entry)
+    auto advance = [&](zf_d2 a, zf_d2 o, zf_d2 q, zf_d2 cc, int64_t i) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            if (j < ntr) {
+                zf_d2 r;
+                if (GRAD_INLINE) {
+                    r.x = zf_elem_diag<NESTEROV, BOX>(a.x, o.x, q.x, cc.x, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
+                    r.y = zf_elem_diag<NESTEROV, BOX>(a.y, o.y, q.y, cc.y, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
+                } else {
+                    r.x = zf_elem_vec<NESTEROV, BOX>(a.x, o.x, q.x, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
+                    r.y = zf_elem_vec<NESTEROV, BOX>(a.y, o.y, q.y, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
+                }
+                o = a;
+                a = r;
+            }
+        }
+        zf_st2<NT>(reinterpret_cast<zf_d2*>(out_last) + i, a);
+        if (S > 1 && ntr >= 2) zf_st2<NT>(reinterpret_cast<zf_d2*>(out_prev) + i, o);
+        // long chains: finish one unit before the next (interleaving four 8-trial chains costs
+        // ~100 more VGPRs and halves the occupancy)
+        if (S >= 8) __builtin_amdgcn_sched_barrier(0);
+    };
 
     // Workgroup b owns tiles b, b + G, b + 2G, ... (G = gridDim.x, A.tiles_per_wg of them):
     // interleaved, so that at any time the resident workgroups still cover one contiguous window
-    // of every stream (consecutive tiles per workgroup measured 4-8 % slower), while the
-    // per-workgroup costs (block reduction, partial stores) are paid once per T tiles.  Which T
-    // wins is device-dependent (T = 4: -1 % on some MI355X boxes, +7 % on others, against T = 1),
-    // so the solver measures it once at initialisation (zf_solver_autotune); T = 1 otherwise.
-    const int64_t ntiles = (n2 + ZF_TILE_UNITS - 1) / ZF_TILE_UNITS;
+    // of every stream (consecutive tiles per workgroup measured 4-8 % slower).  Which T wins is
+    // device-dependent (T = 4: -1 % on some MI355X boxes, +7 % on others, against T = 1), so the
+    // solver measures it once at initialisation (zf_solver_autotune); T = 1 otherwise.
+    const int64_t full_tiles = n2 / ZF_TILE_UNITS;
     const int64_t G = gridDim.x;
-    zf_d2 r[ZF_TILE_U];
     for (int t = 0; t < A.tiles_per_wg; ++t) {
         const int64_t tile = (int64_t)t * G + blockIdx.x;
-        if (tile >= ntiles) break;
+        if (tile >= full_tiles) break;
         const int64_t base = tile * ZF_TILE_UNITS + threadIdx.x;
-        if ((tile + 1) * ZF_TILE_UNITS <= n2) {   // full tile (workgroup-uniform)
-            zf_d2 a[ZF_TILE_U], o[ZF_TILE_U], q[ZF_TILE_U], cc[ZF_TILE_U];
+        // UB units are loaded, then computed, at a time (16 loads in flight per thread at UB = 4)
+        constexpr int UB = (S >= 8) ? ZF_S8_UB : ZF_TILE_U;
 #pragma unroll
-            for (int u = 0; u < ZF_TILE_U; ++u) {
-                const int64_t i = base + u * ZF_BLOCK;
+        for (int u0 = 0; u0 < ZF_TILE_U; u0 += UB) {
+            zf_d2 a[UB], o[UB], q[UB], cc[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int64_t i = base + (u0 + u) * ZF_BLOCK;
                 a[u] = xk2[i];
                 o[u] = a[u];
                 if (NESTEROV) o[u] = xo2[i];
@@ -265,58 +342,70 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
                 cc[u] = q[u];
                 if (GRAD_INLINE) cc[u] = zf_ld2<NT>(p12 + i);
             }
-            // keep all 16 loads of the tile in flight: without this fence the scheduler sinks the
-            // last four below the first arithmetic to save registers
+            // keep all loads of the batch in flight: without this fence the scheduler sinks the
+            // last ones below the first arithmetic to save registers
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < ZF_TILE_U; ++u) {
-                if (GRAD_INLINE) {
-                    r[u].x = zf_elem_diag<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, cc[u].x, beta, lr, tau, A.lo, A.hi, acc);
-                    r[u].y = zf_elem_diag<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, cc[u].y, beta, lr, tau, A.lo, A.hi, acc);
-                } else {
-                    r[u].x = zf_elem_vec<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, beta, lr, tau, A.lo, A.hi, acc);
-                    r[u].y = zf_elem_vec<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, beta, lr, tau, A.lo, A.hi, acc);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < ZF_TILE_U; ++u) zf_st2<NT>(xn2 + base + u * ZF_BLOCK, r[u]);
-        } else {
-            // ragged last tile of the vector: stored at once (one workgroup per launch)
-            for (int u = 0; u < ZF_TILE_U; ++u) {
-                const int64_t i = base + u * ZF_BLOCK;
-                if (i < n2) {
-                    const zf_d2 a0 = xk2[i];
-                    const zf_d2 o0 = NESTEROV ? xo2[i] : a0;
-                    const zf_d2 q0 = p02[i];
-                    const zf_d2 c0 = GRAD_INLINE ? p12[i] : q0;
-                    zf_d2 r0;
-                    if (GRAD_INLINE) {
-                        r0.x = zf_elem_diag<NESTEROV, BOX>(a0.x, o0.x, q0.x, c0.x, beta, lr, tau, A.lo, A.hi, acc);
-                        r0.y = zf_elem_diag<NESTEROV, BOX>(a0.y, o0.y, q0.y, c0.y, beta, lr, tau, A.lo, A.hi, acc);
-                    } else {
-                        r0.x = zf_elem_vec<NESTEROV, BOX>(a0.x, o0.x, q0.x, beta, lr, tau, A.lo, A.hi, acc);
-                        r0.y = zf_elem_vec<NESTEROV, BOX>(a0.y, o0.y, q0.y, beta, lr, tau, A.lo, A.hi, acc);
-                    }
-                    xn2[i] = r0;
-                }
-            }
+            for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], base + (u0 + u) * ZF_BLOCK);
         }
     }
-    // odd trailing element (n odd): workgroup 0
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int64_t t = n - 1;
-        const double xo_t = NESTEROV ? xo[t] : xk[t];
-        if (GRAD_INLINE)
-            xn[t] = zf_elem_diag<NESTEROV, BOX>(xk[t], xo_t, p0[t], p1[t], beta, lr, tau, A.lo, A.hi, acc);
-        else
-            xn[t] = zf_elem_vec<NESTEROV, BOX>(xk[t], xo_t, p0[t], beta, lr, tau, A.lo, A.hi, acc);
+    // remainder of the vector (less than one tile, including an odd last element): element by
+    // element, after its own tiles, by the workgroup next in the round-robin
+    const int64_t rem0 = full_tiles * ZF_TILE_UNITS * 2;
+    if (rem0 < n && blockIdx.x == full_tiles % G) {
+        for (int64_t e = rem0 + threadIdx.x; e < n; e += ZF_BLOCK) {
+            double a = xk[e], o = NESTEROV ? xo[e] : a;
+            const double q = p0[e], cc = GRAD_INLINE ? p1[e] : q;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                if (j < ntr) {
+                    double r;
+                    if (GRAD_INLINE)
+                        r = zf_elem_diag<NESTEROV, BOX>(a, o, q, cc, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
+                    else r = zf_elem_vec<NESTEROV, BOX>(a, o, q, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
+                    o = a;
+                    a = r;
+                }
+            }
+            out_last[e] = a;
+            if (S > 1 && ntr >= 2) out_prev[e] = o;
+        }
     }
 
-    const double sums[5] = {acc.fy, acc.dot, acc.ss, acc.l1, acc.fx};
-    const double maxs[1] = {acc.mx};
-    double mine = 0.0;
-    zf_block_reduce<5, 1, ZF_WAVES>(sums, maxs, lds, mine);
-    if (threadIdx.x < ZF_NPART) A.blk_part[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = mine;
+    // workgroup partials of every trial of the chain: rows j * ZF_NPART + k.  All 6 S wave
+    // reductions run as ONE transposing butterfly (zf_wave_reduce_multi: same pairing, hence the
+    // same bits, as a butterfly per quantity), then the four wave totals are added in wave order.
+    constexpr int H = (S >= 8) ? 3 : (S >= 4) ? 2 : (S >= 2) ? 1 : 0;
+    constexpr int NQ = S * ZF_NPART;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double sums[5 * S], maxs[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        sums[j * 5 + 0] = acc[j].fy;
+        sums[j * 5 + 1] = acc[j].dot;
+        sums[j * 5 + 2] = acc[j].ss;
+        sums[j * 5 + 3] = acc[j].l1;
+        sums[j * 5 + 4] = acc[j].fx;
+        maxs[j] = acc[j].mx;
+    }
+    zf_wave_reduce_multi<5 * S, H, false>(sums, lane);
+    zf_wave_reduce_multi<S, H, true>(maxs, lane);
+    if ((lane & ((64 >> H) - 1)) == 0) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int idx = zf_wave_reduce_multi_index<5 * S, H>(q, lane);
+            lds[wave * NQ + (idx / 5) * ZF_NPART + idx % 5] = sums[q];
+        }
+        lds[wave * NQ + zf_wave_reduce_multi_index<S, H>(0, lane) * ZF_NPART + 5] = maxs[0];
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        const int t = threadIdx.x;
+        double v = lds[t];
+#pragma unroll
+        for (int w = 1; w < ZF_WAVES; ++w) v = (t % ZF_NPART == 5) ? fmax(v, lds[w * NQ + t]) : v + lds[w * NQ + t];
+        A.blk_part[(int64_t)t * gridDim.x + blockIdx.x] = v;
+    }
 }
 
 // --- f(x), g(x) at a point (initial F(x0), proximal_gradient.py:466,472) -------

@@ -36,8 +36,19 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_sum_parts_kernel(const zf_control
     }
 }
 
-__global__ void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace, const double* beta_ring) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) zf_decide_step(ctl, packs, trace, beta_ring);
+// sharded x: packs = world x sub x ZF_PACK_LEN (rank-major).  The sub-iterations of a pass are
+// examined in order; the first rejection / termination discards the speculative rest.
+__global__ void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace, const double* beta_ring,
+                                 int sub) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    (void)sub;   // == ctl->sub_iters
+    zf_decide_pass(ctl, packs, trace, beta_ring);
+}
+
+__global__ void zf_set_max_iter_kernel(zf_control* ctl, int64_t max_iter) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ctl->max_iter = max_iter;
+    if (ctl->status == ZF_MAXITER && ctl->nit < max_iter) ctl->status = ZF_RUNNING;
 }
 
 // after the host refilled the momentum ring: re-resolve the factor of the pending trial
@@ -67,13 +78,13 @@ __global__ __launch_bounds__(ZF_FIN_BLOCK) void zf_init_finalize_kernel(zf_init_
         I.pack[2] = totals[2];
     }
 }
-__global__ void zf_init_commit_kernel(zf_control* ctl, const double* packs, int f_replicated) {
+__global__ void zf_init_commit_kernel(zf_control* ctl, const double* packs, int f_replicated, int stride) {
     if (threadIdx.x || blockIdx.x) return;
     double f = packs[0], g = packs[1], viol = packs[2];
     for (int r = 1; r < ctl->world; ++r) {
-        if (!f_replicated) f = f + packs[r * ZF_PACK_LEN + 0];
-        g = g + packs[r * ZF_PACK_LEN + 1];
-        viol = viol + packs[r * ZF_PACK_LEN + 2];
+        if (!f_replicated) f = f + packs[r * stride + 0];
+        g = g + packs[r * stride + 1];
+        viol = viol + packs[r * stride + 2];
     }
     if (viol > 0.0) g = INFINITY;
     ctl->f_x = f;
@@ -91,8 +102,10 @@ struct zf_solver {
     int grid;                 // trial kernel grid
     bool box;
     // device memory owned by the solver
-    double* xbuf = nullptr;   // 3 * n_pad
-    double* xb[3] = {nullptr, nullptr, nullptr};
+    double* xbuf = nullptr;   // ring * n_pad
+    double* xb[ZF_MAX_RING] = {};
+    int sub = 1;              // FISTA iterations computed per pass (temporal blocking; separable f only)
+    int ring = 3;             // iterate buffers (zf_decide.h: zf_free_bufs)
     double* partials = nullptr;   // init-time evaluation partials
     double* blk_part = nullptr;   // ZF_NPART x max_grid per-workgroup partials of the trial kernel
     double* slice_part = nullptr; // ZF_NPART x ZF_FIN_WGS
@@ -193,21 +206,32 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
             return zf_fail(ZF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));         \
         }                                                                               \
     } while (0)
-    ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * 3 * n_pad));
-    for (int k = 0; k < 3; ++k) s->xb[k] = s->xbuf + k * n_pad;
+    if (desc->kind == ZF_PROBLEM_DIAG_QUAD_L1) {
+        // every term of the recursion is elementwise for this f, so one pass may run `sub`
+        // consecutive iterations in registers (zf_kernels_step.h); 0 = library default
+        int sub = opt->sub_iters;
+        const char* se = getenv("ZF_SUB_ITERS");
+        if (sub <= 0 && se) sub = atoi(se);
+        if (sub <= 0) sub = ZF_MAX_SUB;
+        if (sub > ZF_MAX_SUB) sub = ZF_MAX_SUB;
+        s->sub = sub >= 8 ? 8 : sub >= 4 ? 4 : sub >= 2 ? 2 : 1;
+    }
+    s->ring = s->sub > 1 ? 4 : 3;   // x_k, x_{k-1} + the one or two iterates a pass stores
+    ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * s->ring * n_pad));
+    for (int k = 0; k < s->ring; ++k) s->xb[k] = s->xbuf + k * n_pad;
     ZF_TRY(hipMalloc(&s->partials, sizeof(double) * ZF_NPART * ZF_MAX_GRID));
-    ZF_TRY(hipMalloc(&s->blk_part, sizeof(double) * ZF_NPART * s->max_grid));
-    ZF_TRY(hipMalloc(&s->slice_part, sizeof(double) * ZF_NPART * ZF_FIN_WGS));
+    ZF_TRY(hipMalloc(&s->blk_part, sizeof(double) * ZF_NPART * s->sub * s->max_grid));
+    ZF_TRY(hipMalloc(&s->slice_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_WGS));
     ZF_TRY(hipMalloc(&s->fin_cnt, 64));
     ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, 64, s->stream));
     ZF_TRY(hipMalloc(&s->ctl, sizeof(zf_control)));
     ZF_TRY(hipMalloc(&s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS));
     ZF_TRY(hipMalloc(&s->beta_ring, sizeof(double) * ZF_RING));
-    ZF_TRY(hipMalloc(&s->pack_local, sizeof(double) * ZF_PACK_LEN));
-    ZF_TRY(hipMalloc(&s->pack_all, sizeof(double) * ZF_PACK_LEN * desc->world));
+    ZF_TRY(hipMalloc(&s->pack_local, sizeof(double) * ZF_PACK_LEN * s->sub));
+    ZF_TRY(hipMalloc(&s->pack_all, sizeof(double) * ZF_PACK_LEN * s->sub * desc->world));
     ZF_TRY(hipMemsetAsync(s->trace, 0, sizeof(double) * ZF_RING * ZF_TRACE_COLS, s->stream));
     ZF_TRY(hipMemsetAsync(s->beta_ring, 0, sizeof(double) * ZF_RING, s->stream));
-    ZF_TRY(hipMemsetAsync(s->pack_all, 0, sizeof(double) * ZF_PACK_LEN * desc->world, s->stream));
+    ZF_TRY(hipMemsetAsync(s->pack_all, 0, sizeof(double) * ZF_PACK_LEN * s->sub * desc->world, s->stream));
     if (desc->kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
         const int64_t m = desc->m_rows;
         const int64_t m_pad = (m + 63) & ~int64_t(63);
@@ -247,14 +271,23 @@ extern "C" int zf_solver_destroy(zf_solver* s) {
 }
 
 // ---- launches ---------------------------------------------------------------
-template <bool GI, bool NT>
-static void zf_launch_trial_t2(zf_solver* s, const zf_step_args& a) {
+template <bool GI, bool NT, int S>
+static void zf_launch_trial_t3(zf_solver* s, const zf_step_args& a) {
     const bool nest = s->opt.nesterov != 0;
     dim3 g(s->grid), b(ZF_BLOCK);
-    if (nest && s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, true, true, NT>), g, b, 0, s->stream, a);
-    else if (nest) hipLaunchKernelGGL((zf_trial_kernel<GI, true, false, NT>), g, b, 0, s->stream, a);
-    else if (s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, false, true, NT>), g, b, 0, s->stream, a);
-    else hipLaunchKernelGGL((zf_trial_kernel<GI, false, false, NT>), g, b, 0, s->stream, a);
+    if (nest && s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, true, true, NT, S>), g, b, 0, s->stream, a);
+    else if (nest) hipLaunchKernelGGL((zf_trial_kernel<GI, true, false, NT, S>), g, b, 0, s->stream, a);
+    else if (s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, false, true, NT, S>), g, b, 0, s->stream, a);
+    else hipLaunchKernelGGL((zf_trial_kernel<GI, false, false, NT, S>), g, b, 0, s->stream, a);
+}
+template <bool GI, bool NT>
+static void zf_launch_trial_t2(zf_solver* s, const zf_step_args& a) {
+    if constexpr (GI) {   // temporal blocking needs the gradient inline (separable f)
+        if (s->sub == 8) return zf_launch_trial_t3<GI, NT, 8>(s, a);
+        if (s->sub == 4) return zf_launch_trial_t3<GI, NT, 4>(s, a);
+        if (s->sub == 2) return zf_launch_trial_t3<GI, NT, 2>(s, a);
+    }
+    zf_launch_trial_t3<GI, NT, 1>(s, a);
 }
 template <bool GI>
 static void zf_launch_trial_t(zf_solver* s, const zf_step_args& a) {
@@ -268,6 +301,7 @@ static void zf_launch_finalize(zf_solver* s, bool decide) {
     zf_finalize_args F;
     F.blk_part = s->blk_part;
     F.nblocks = s->grid;
+    F.sub_iters = s->sub;
     F.slice_part = s->slice_part;
     F.cnt = s->fin_cnt;
     for (int k = 0; k < ZF_NPART; ++k) F.scale[k] = 1.0;
@@ -291,14 +325,18 @@ static void zf_launch_finalize(zf_solver* s, bool decide) {
     int wgs = (s->grid + ZF_FIN_THREADS - 1) / ZF_FIN_THREADS;   // no more workgroups than slices of work
     if (wgs > ZF_FIN_WGS) wgs = ZF_FIN_WGS;
     if (wgs < 1) wgs = 1;
-    hipLaunchKernelGGL(zf_finalize_kernel, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
+    if (s->sub == 8) hipLaunchKernelGGL(zf_finalize_kernel<8>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
+    else if (s->sub == 4) hipLaunchKernelGGL(zf_finalize_kernel<4>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
+    else if (s->sub == 2) hipLaunchKernelGGL(zf_finalize_kernel<2>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
+    else hipLaunchKernelGGL(zf_finalize_kernel<1>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
 }
 
 static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false) {
     const zf_problem_desc& d = s->desc;
     zf_step_args a;
     a.ctl = s->ctl;
-    for (int k = 0; k < 3; ++k) a.xb[k] = s->xb[k];
+    a.beta_ring = s->beta_ring;
+    for (int k = 0; k < ZF_MAX_RING; ++k) a.xb[k] = s->xb[k < s->ring ? k : 0];
     a.lam = d.lam;
     a.lo = d.box_lo;
     a.hi = d.box_hi;
@@ -450,7 +488,7 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
     const int64_t n = d.n;
     // x_k = x_{k-1} = y = x0  (proximal_gradient.py:463-465)
     ZF_HIP(hipMemcpyAsync(s->xb[0], x0_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream));
-    ZF_HIP(hipMemcpyAsync(s->xb[2], x0_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream));
+    ZF_HIP(hipMemcpyAsync(s->xb[s->ring - 1], x0_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream));
     zf_control c;
     memset(&c, 0, sizeof(c));
     c.lr = s->opt.lr;
@@ -465,6 +503,12 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
     c.deprecated = s->opt.deprecated;
     c.need_grad = 1;
     c.world = d.world;
+    c.ring_size = s->ring;
+    c.sub_iters = s->sub;
+    c.prev = s->ring - 1;   // x_{-1} = x_0 (:463-465)
+    c.plan_n = s->sub;
+    c.cut_at = -1;
+    c.ncuts = 0;
     ZF_HIP(hipMemcpyAsync(s->ctl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));   // `c` is a stack object
     zf_init_args I;
@@ -525,7 +569,8 @@ extern "C" int zf_solver_enqueue_init_finish(zf_solver* s) {
 extern "C" int zf_solver_enqueue_init_commit(zf_solver* s) {
     ZF_REQUIRE(s, "zf_solver_enqueue_init_commit: null solver");
     const int f_repl = (s->desc.kind == ZF_PROBLEM_LEAST_SQUARES_L1) ? 1 : 0;
-    hipLaunchKernelGGL(zf_init_commit_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, f_repl);
+    hipLaunchKernelGGL(zf_init_commit_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, f_repl,
+                       s->sub * ZF_PACK_LEN);
     ZF_HIP(hipGetLastError());
     s->initialised = true;
     return ZF_OK;
@@ -558,7 +603,22 @@ extern "C" int zf_solver_enqueue_trial(zf_solver* s) {
 extern "C" int zf_solver_enqueue_decide(zf_solver* s) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_decide: solver not initialised");
     hipLaunchKernelGGL(zf_decide_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, s->trace,
-                       s->beta_ring);
+                       s->beta_ring, s->sub);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_sub_iters(zf_solver* s, int32_t* sub_iters) {
+    ZF_REQUIRE(s && sub_iters, "zf_solver_sub_iters: null argument");
+    *sub_iters = s->sub;
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_set_max_iter(zf_solver* s, int64_t max_iter) {
+    ZF_REQUIRE(s && s->initialised, "zf_solver_set_max_iter: solver not initialised");
+    ZF_REQUIRE(max_iter >= 1, "zf_solver_set_max_iter: max_iter must be >= 1");
+    s->opt.max_iter = max_iter;
+    hipLaunchKernelGGL(zf_set_max_iter_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, max_iter);
     ZF_HIP(hipGetLastError());
     return ZF_OK;
 }
@@ -581,7 +641,7 @@ static void zf_set_tiles(zf_solver* s, int tiles) {
     s->grid = (int)((s->ntiles + tiles - 1) / tiles);
 }
 
-// Measure the trial kernel with 1, 2 and 4 interleaved tiles per workgroup on THIS device and
+// Measure the trial kernel with 1, 2, 4 (and 8) interleaved tiles per workgroup on THIS device and
 // keep the fastest: the ranking differs between MI355X boxes (tools/tune_trial.hip: T = 4 is
 // 1 % faster than T = 1 on some, 7 % slower on others).  The probe launches are dry runs of the
 // pending trial: they write only the scratch x+ buffer and the reduction workspace (re-armed by
@@ -593,7 +653,8 @@ extern "C" int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles) {
         zf_set_tiles(s, atoi(env));
     } else if (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->ntiles >= 4096) {
         // (below ~64 MB per stream the launch is latency-, not bandwidth-bound: keep T = 1)
-        const int cand[3] = {1, 2, 4};
+        const int cand[4] = {1, 2, 4, 8};
+        const int ncand = s->sub >= 8 ? 4 : 3;   // long chains amortise the per-workgroup reduction
         double best = 1e300;
         int best_t = 1;
         hipEvent_t e0, e1;
@@ -601,7 +662,7 @@ extern "C" int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles) {
         ZF_HIP(hipEventCreate(&e1));
         const bool timing = s->timing;
         s->timing = false;
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < ncand; ++c) {
             zf_set_tiles(s, cand[c]);
             double t_min = 1e300;
             for (int rep = 0; rep < 7; ++rep) {   // first repetition warms up
@@ -758,7 +819,7 @@ extern "C" int zf_stream_synchronize(void* stream) {
 
 extern "C" int zf_decide_host(zf_control* ctl, const double* packs, double* trace) {
     ZF_REQUIRE(ctl && packs && trace, "zf_decide_host: null argument");
-    zf_decide_step(ctl, packs, trace);
+    zf_decide_pass(ctl, packs, trace);
     return ZF_OK;
 }
 

@@ -80,6 +80,9 @@ class DeviceSolver:
         _lib.check(self.lib.zf_solver_create(C.byref(h), C.byref(d), C.byref(o), C.c_void_p(stream)),
                    "zf_solver_create")
         self.handle = h
+        sub = C.c_int32(1)
+        _lib.check(self.lib.zf_solver_sub_iters(h, C.byref(sub)), "zf_solver_sub_iters")
+        self.sub_iters = int(sub.value)   # iterations one pass may accept (temporal blocking)
         self.ctl = _lib.Control()
         self.trace = np.zeros((_lib.ZF_RING, _lib.ZF_TRACE_COLS), dtype=np.float64)
         self._pack_local = self._pack_all = None
@@ -97,8 +100,9 @@ class DeviceSolver:
         reads them in place (zf_solver_set_pack_buffers)."""
         import torch
 
-        self._pack_local = torch.zeros(_lib.ZF_PACK_LEN, dtype=torch.float64, device="cuda")
-        self._pack_all = torch.zeros(_lib.ZF_PACK_LEN * self.world, dtype=torch.float64, device="cuda")
+        plen = _lib.ZF_PACK_LEN * self.sub_iters   # one pack per sub-iteration of a pass
+        self._pack_local = torch.zeros(plen, dtype=torch.float64, device="cuda")
+        self._pack_all = torch.zeros(plen * self.world, dtype=torch.float64, device="cuda")
         _lib.check(self.lib.zf_solver_set_pack_buffers(
             self.handle, C.c_void_p(self._pack_local.data_ptr()), C.c_void_p(self._pack_all.data_ptr())))
         self._s_part = self._s_all = None
@@ -156,7 +160,8 @@ class DeviceSolver:
                    "set_beta")
 
     def enqueue(self, steps: int):
-        """Enqueue ``steps`` line-search trials; no host synchronisation."""
+        """Enqueue ``steps`` passes (each = up to ``sub_iters`` line-search trials); no host
+        synchronisation."""
         if not self.split:
             _lib.check(self.lib.zf_solver_enqueue_steps(self.handle, steps), "enqueue_steps")
             return
@@ -166,6 +171,9 @@ class DeviceSolver:
             self.trial_finish()
             self._gather()
             self.enqueue_decide()
+
+    def set_max_iter(self, max_iter: int):
+        _lib.check(self.lib.zf_solver_set_max_iter(self.handle, int(max_iter)), "set_max_iter")
 
     def poll(self):
         """Synchronise and fetch the control block + trace ring."""

@@ -101,6 +101,8 @@ class NativeRun:
             decay_rate=float(opts["decay_rate"]), max_iter=int(opts["max_iter"]),
             max_backtrack_iter=int(opts["max_backtrack_iter"]),
             nesterov=int(bool(opts["nesterov"])), deprecated=int(bool(opts["deprecated"])),
+            # return_all needs every iterate on the host: one iteration per pass then
+            sub_iters=1 if opts.get("return_all") else int(opts.get("sub_iters", 0) or 0),
         )
         if solver_factory is not None:
             # test seam: a stand-in with DeviceSolver's interface (tests/fake_engine.py)
@@ -117,6 +119,8 @@ class NativeRun:
             self.solver = DeviceSolver(fields, options, keepalive=keep, group=problem.group, timing=timing)
             self.solver.init(x0_dev.data_ptr())
             self._x0_dev = x0_dev
+        # iterations one pass may accept (temporal blocking of separable f; csrc/zf_kernels_step.h)
+        self.sub_iters = int(getattr(self.solver, "sub_iters", 1))
         self.ratio = opts["nesterov_ratio"]
         self._t_state = None
         self._beta_filled = 0     # momentum factors uploaded for accepted counts < this
@@ -144,18 +148,25 @@ class NativeRun:
         self._beta_filled = upto
 
     def advance(self, steps):
-        """Enqueue ``steps`` trials, then synchronise.  Returns the trace rows of
-        the iterations accepted meanwhile (array [k, ZF_TRACE_COLS])."""
-        steps = int(min(steps, _lib.ZF_RING - 1))
-        # + 1: the decide step of the last trial resolves the factor of the trial after it
-        self._fill_beta(self.nit_seen + steps + 1)
-        self.solver.enqueue(steps)
+        """Enqueue ``steps`` passes (each examines up to ``sub_iters`` trials), then
+        synchronise.  Returns the trace rows of the iterations accepted meanwhile
+        (array [k, ZF_TRACE_COLS])."""
+        self.enqueue_only(steps)
         return self.collect()
 
     def enqueue_only(self, steps):
-        steps = int(min(steps, _lib.ZF_RING - 1))
-        self._fill_beta(self.nit_seen + steps + 1)
+        # the trace / momentum rings hold ZF_RING iterations: never run further ahead of the host
+        steps = int(min(steps, (_lib.ZF_RING - 1) // self.sub_iters))
+        # + 1: the decide step of the last trial resolves the factor of the trial after it
+        self._fill_beta(self.nit_seen + steps * self.sub_iters + 1)
         self.solver.enqueue(steps)
+
+    def set_max_iter(self, max_iter):
+        """Raise (or lower) max_iter of the live solve; a run stopped by it resumes (:539)."""
+        self.solver.set_max_iter(int(max_iter))
+        self.opts = dict(self.opts, max_iter=int(max_iter))
+        ctl, _ = self.solver.poll()
+        self.status = int(ctl.status)
 
     def collect(self):
         ctl, trace = self.solver.poll()
