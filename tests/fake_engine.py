@@ -32,11 +32,17 @@ class FakeProblem:
 
 
 class FakeSolver:
+    """``options["sub_iters"] = S > 1`` makes a pass chain S trials the way the temporally
+    blocked kernel does (csrc/zf_kernels_step.h): same plan fields, same buffer hand-over,
+    only the last two iterates of a chain are kept."""
+
     def __init__(self, fields, options, problem, x0):
         self.lib = _lib.load()
         self.p = problem
         self.world, self.group = fields["world"], problem.group
         self.n = fields["n"]
+        self.sub_iters = sub = max(1, int(options.get("sub_iters", 0) or 1))
+        ring = 4 if sub > 1 else 3
         c = _lib.Control()
         c.lr, c.tol, c.tol_internal = options["lr"], options["tol"], options["tol_internal"]
         c.decay_rate, c.max_iter = options["decay_rate"], options["max_iter"]
@@ -44,27 +50,27 @@ class FakeSolver:
         c.status = _lib.ZF_BACKTRACK_FAILED if c.max_backtrack == 0 else _lib.ZF_RUNNING
         c.nesterov, c.deprecated = options["nesterov"], options["deprecated"]
         c.need_grad, c.world, c.cur = 1, self.world, 0
-        c.ring_size, c.sub_iters, c.prev = 3, 1, 2
-        c.plan_n, c.cut_at, c.ncuts = 1, -1, 0
-        self.sub_iters = 1
+        c.ring_size, c.sub_iters, c.prev = ring, sub, ring - 1
+        c.plan_n, c.cut_at, c.ncuts = sub, -1, 0
         self.ctl = c
         self.trace = np.zeros((_lib.ZF_RING, _lib.ZF_TRACE_COLS))
         self.beta = np.zeros(_lib.ZF_RING)
         x0 = np.asarray(x0, float)
-        self.xb = [x0.copy(), np.zeros_like(x0), x0.copy()]
+        self.xb = [x0.copy() for _ in range(ring)]
+        self.passes = 0
         ref = P.DiagQuadL1Ref(problem.d, problem.c, problem.lam)
-        packs = self._exchange(np.array([ref.f(x0), ref.g(x0), 0, 0, 0, 0, 0, 0], float))
+        packs = self._exchange(np.array([ref.f(x0), ref.g(x0), 0, 0, 0, 0, 0, 0], float), 1)
         f = sum(packs[r * 8 + 0] for r in range(self.world))
         g = sum(packs[r * 8 + 1] for r in range(self.world))
         c.f_x, c.g_x, c.F_old = f, g, f + g
 
-    def _exchange(self, pack_local):
+    def _exchange(self, pack_local, npacks):
         if self.world == 1:
             return pack_local.copy()
         import torch
 
         local = torch.from_numpy(np.ascontiguousarray(pack_local))
-        allp = torch.zeros(_lib.ZF_PACK_LEN * self.world, dtype=torch.float64)
+        allp = torch.zeros(_lib.ZF_PACK_LEN * npacks * self.world, dtype=torch.float64)
         gather_packs(allp, local, self.group)
         return allp.numpy()
 
@@ -72,25 +78,46 @@ class FakeSolver:
         for k, b in enumerate(betas):
             self.beta[(first + k) % _lib.ZF_RING] = b
 
-    def _trial_pack(self):
+    def set_max_iter(self, max_iter):
+        c = self.ctl
+        c.max_iter = max_iter
+        if c.status == _lib.ZF_MAXITER and c.nit < max_iter:
+            c.status = _lib.ZF_RUNNING
+
+    def _chain_packs(self):
+        """One pass: the planned chain of trials from (x_k, x_{k-1}); returns sub x 8 packs."""
         c, p = self.ctl, self.p
-        xk, xo = self.xb[c.cur], self.xb[c.prev]
-        beta = self.beta[c.nit % _lib.ZF_RING] if c.nesterov else 0.0
-        y = xk + beta * (xk - xo) if c.nesterov else xk
         ref = P.DiagQuadL1Ref(p.d, p.c, p.lam)
-        grad = ref.jac_f(y)
-        xn = ref.prox_wsum_g(c.lr, y - c.lr * grad)
-        dx = xn - y
-        self.xb[3 - c.cur - c.prev] = xn   # the buffer holding neither x_k nor x_{k-1}
-        return np.array([ref.f(y), grad @ dx, np.sum(dx * dx), ref.g(xn), ref.f(xn),
-                         np.max(np.abs(dx)) if dx.size else 0.0, 0.0, 0.0])
+        n = max(1, min(c.plan_n if c.plan_n > 0 else 1, c.max_iter - c.nit))
+        lr_cut = c.lr
+        for _ in range(c.ncuts):
+            lr_cut = lr_cut * c.decay_rate
+        xk, xo = self.xb[c.cur], self.xb[c.prev]
+        packs = np.zeros((self.sub_iters, _lib.ZF_PACK_LEN))
+        for j in range(n):
+            lr = lr_cut if (c.cut_at >= 0 and j >= c.cut_at) else c.lr
+            beta = self.beta[(c.nit + j) % _lib.ZF_RING] if c.nesterov else 0.0
+            y = xk + beta * (xk - xo) if c.nesterov else xk
+            grad = ref.jac_f(y)
+            xn = ref.prox_wsum_g(lr, y - lr * grad)
+            dx = xn - y
+            packs[j] = [ref.f(y), grad @ dx, np.sum(dx * dx), ref.g(xn), ref.f(xn),
+                        np.max(np.abs(dx)) if dx.size else 0.0, 0.0, 0.0]
+            xo, xk = xk, xn
+        free = [i for i in range(c.ring_size) if i not in (c.cur, c.prev)]
+        if n == 1:
+            self.xb[free[0]] = xk
+        else:
+            self.xb[free[0]], self.xb[free[1]] = xo, xk
+        return packs.reshape(-1)
 
     def enqueue(self, steps):
         for _ in range(steps):
             running = self.ctl.status == _lib.ZF_RUNNING
-            pack = self._trial_pack() if running else np.zeros(_lib.ZF_PACK_LEN)
-            packs = np.ascontiguousarray(self._exchange(pack))
+            pack = self._chain_packs() if running else np.zeros(_lib.ZF_PACK_LEN * self.sub_iters)
+            packs = np.ascontiguousarray(self._exchange(pack, self.sub_iters))
             if running:
+                self.passes += 1
                 _lib.check(self.lib.zf_decide_host(C.byref(self.ctl), C.c_void_p(_lib.ptr(packs)),
                                                    C.c_void_p(_lib.ptr(self.trace))))
 

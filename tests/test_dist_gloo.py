@@ -76,3 +76,63 @@ def test_sharded_pdiag_world2(tmp_path, kw):
     assert np.array_equal(full, np.stack(exp.allvecs))
     np.testing.assert_allclose(r[0]["allerrs"], exp.allerrs, rtol=0, atol=0)
     np.testing.assert_allclose(r[0]["allfuns"], exp.allfuns, rtol=1e-12)
+
+
+def _worker_chain(rank, world, port, n, kw, sub, outdir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    from fake_engine import FakeProblem, FakeSolver
+    from oracle import problems_ref as P
+    from zfista_amd import _lib
+    from zfista_amd.proximal_gradient import NativeRun
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    d, c, lam = P.make_pdiag(n, seed=1)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    prob = FakeProblem(d[lo:hi], c[lo:hi], lam, group=dist.group.WORLD, world=world, rank=rank)
+    base = dict(lr=1, tol=1e-5, tol_internal=1e-12, max_iter=1000000, max_iter_internal=100000,
+                max_backtrack_iter=100, warm_start=False, decay_rate=0.5, nesterov=False,
+                nesterov_ratio=(0, 0.25), return_all=False, verbose=False, deprecated=False, sub_iters=sub)
+    run = NativeRun(prob, np.zeros(hi - lo), base | kw,
+                    solver_factory=lambda f, o, p, x0: FakeSolver(f, o, p, x0))
+    rows = [np.zeros((0, _lib.ZF_TRACE_COLS))]
+    while run.status == _lib.ZF_RUNNING:
+        rows.append(run.advance(5))
+    ctl = run.solver.ctl
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), x=run.solver.get_x(), nit=ctl.nit, status=ctl.status,
+             rows=np.concatenate(rows), lr=ctl.lr, passes=run.solver.passes)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sub", [4, 8])
+@pytest.mark.parametrize("kw", [
+    dict(lr=0.45, nesterov=True, tol=0.0, max_iter=41),
+    dict(lr=4.0, nesterov=True, tol=1e-6, max_iter=500),      # chains break on rejections and on termination
+])
+def test_sharded_pdiag_world2_chained_passes(tmp_path, kw, sub):
+    """The sharded path with chains of `sub` trials per pass: ONE all-gather of sub packs per
+    pass (not per iteration); every rank replays the same plan decisions."""
+    import torch.multiprocessing as mp
+
+    from oracle import cpu_ref, problems_ref as P
+    from zfista_amd import _lib
+
+    n, world = 10007, 2
+    mp.spawn(_worker_chain, args=(world, _free_port(), n, kw, sub, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    d, c, lam = P.make_pdiag(n, seed=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*P.DiagQuadL1Ref(d, c, lam).callbacks(), np.zeros(n),
+                                                 return_all=True, **kw)
+    assert int(r[0]["nit"]) == int(r[1]["nit"]) == exp.nit
+    assert int(r[0]["status"]) == int(r[1]["status"]) and float(r[0]["lr"]) == float(r[1]["lr"])
+    assert np.array_equal(r[0]["rows"], r[1]["rows"]) and int(r[0]["passes"]) == int(r[1]["passes"])
+    assert np.array_equal(np.concatenate([r[0]["x"], r[1]["x"]]), exp.x)
+    np.testing.assert_allclose(r[0]["rows"][:, _lib.TR_ERR], exp.allerrs, rtol=0, atol=0)
+    np.testing.assert_allclose(r[0]["rows"][:, _lib.TR_F], exp.allfuns[1:], rtol=1e-12)
+    assert int(r[0]["passes"]) < exp.nit   # fewer exchanges than iterations

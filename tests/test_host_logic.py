@@ -184,3 +184,148 @@ def test_public_entry_warns_like_the_reference(monkeypatch):
     # verbose prints a header and one row per iteration (documented deviation: the reference raises)
     res = pg.minimize_proximal_gradient(None, None, None, None, np.zeros(17), lr=0.4, tol=1e-3, verbose=True)
     assert res.success
+
+
+# ---------------------------------------------------------------------------
+# temporal blocking: chains of S trials per pass (zf_decide_pass, csrc/zf_decide.h)
+# ---------------------------------------------------------------------------
+ACCEPT = [10.2, -2.0, 1.0, 1.0, 8.0, 0.5, 0, 0]      # see test_decide_accept_reject_and_failure
+REJECT = [10.0, -2.0, 1.0, 1.0, 9.5, 0.5, 0, 0]
+
+
+def _chain_ctl(sub, **kw):
+    kw = dict(sub_iters=sub, ring_size=4, cur=0, prev=3, plan_n=sub, cut_at=-1, ncuts=0, max_backtrack=5) | kw
+    return _ctl(**kw)
+
+
+def _follow(F_old, pack):
+    """A pack that is accepted after `pack` was: same model terms, F decreases by 1."""
+    p = list(pack)
+    p[0], p[4] = F_old - p[3] + 1.2, F_old - p[3] - 1.0   # f_y, f_x  (g_x = p[3])
+    return p
+
+
+def test_decide_pass_commits_a_full_chain():
+    c = _chain_ctl(4)
+    packs, F = [], 10.0
+    for _ in range(4):
+        p = _follow(F, ACCEPT)
+        packs += p
+        F = p[4] + p[3]
+    tr = _decide(c, packs)
+    assert (c.nit, c.status, c.trial, c.total_trials) == (4, _lib.ZF_RUNNING, 0, 4)
+    assert (c.prev, c.cur) == (1, 2)                  # x_{k+3}, x_{k+4}: the two lowest free buffers
+    assert (c.plan_n, c.cut_at, c.ncuts) == (4, -1, 0)
+    assert np.all(tr[:4, _lib.TR_TRIALS] == 1) and c.F_old == F
+
+
+def test_decide_pass_first_trial_rejected_is_committed():
+    c = _chain_ctl(4)
+    _decide(c, REJECT + ACCEPT * 3)
+    assert (c.nit, c.trial, c.total_trials, c.lr) == (0, 1, 1, 0.5)
+    assert (c.cur, c.prev, c.plan_n, c.cut_at) == (0, 3, 4, -1)
+
+
+def test_decide_pass_broken_chain_is_planned_again():
+    c = _chain_ctl(4)
+    p0 = _follow(10.0, ACCEPT)
+    p1 = _follow(p0[4] + p0[3], ACCEPT)
+    before = bytes(c)
+    _decide(c, p0 + p1 + REJECT + ACCEPT)
+    # two iterates were accepted but exist in no buffer: nothing is committed, only the plan changes
+    assert (c.nit, c.total_trials, c.lr, c.cur, c.prev, c.F_old) == (0, 0, 1.0, 0, 3, 10.0)
+    assert (c.plan_n, c.cut_at, c.ncuts) == (4, 2, 1)
+    assert bytes(c)[:120] == before[:120]
+    # the planned pass: same two trials, then trial 2 again at lr/2 - rejected once more
+    _decide(c, p0 + p1 + REJECT + ACCEPT)
+    assert (c.nit, c.plan_n, c.cut_at, c.ncuts) == (0, 4, 2, 2)
+    # ... and accepted at lr/4, with one more trial behind it
+    F2 = p1[4] + p1[3]
+    q2 = _follow(F2, ACCEPT)
+    q3 = _follow(q2[4] + q2[3], ACCEPT)
+    tr = _decide(c, p0 + p1 + q2 + q3)
+    assert (c.nit, c.lr, c.total_trials, c.trial) == (4, 0.25, 6, 0)
+    assert list(tr[:4, _lib.TR_TRIALS]) == [1, 1, 3, 1] and list(tr[:4, _lib.TR_LR]) == [1.0, 1.0, 0.25, 0.25]
+    assert (c.prev, c.cur, c.plan_n, c.cut_at, c.ncuts) == (1, 2, 4, -1, 0)
+
+
+def test_decide_pass_termination_inside_a_chain():
+    c = _chain_ctl(4)
+    p0 = _follow(10.0, ACCEPT)
+    p1 = _follow(p0[4] + p0[3], ACCEPT)
+    p1[5] = 1e-7                                       # err < tol at the second trial
+    _decide(c, p0 + p1 + ACCEPT + ACCEPT)
+    assert (c.nit, c.status, c.plan_n, c.cut_at) == (0, _lib.ZF_RUNNING, 2, -1)   # exactly two trials next time
+    _decide(c, p0 + p1 + [0.0] * 16)
+    assert (c.nit, c.status, c.prev, c.cur) == (2, _lib.ZF_CONVERGED, 1, 2)
+    # max_iter bounds the chain (:539): 3 iterations left -> 3 trials, one-trial chains store one iterate
+    c = _chain_ctl(4, max_iter=3)
+    packs, F = [], 10.0
+    for _ in range(3):
+        p = _follow(F, ACCEPT)
+        packs += p
+        F = p[4] + p[3]
+    _decide(c, packs + REJECT)
+    assert (c.nit, c.status) == (3, _lib.ZF_MAXITER)
+    c = _chain_ctl(4, max_iter=1)
+    _decide(c, _follow(10.0, ACCEPT) + REJECT * 3)
+    assert (c.nit, c.status, c.prev, c.cur) == (1, _lib.ZF_MAXITER, 0, 1)
+
+
+def test_decide_pass_backtracking_failure_inside_a_chain():
+    c = _chain_ctl(2, max_backtrack=2)
+    p0 = _follow(10.0, ACCEPT)
+    _decide(c, p0 + REJECT)
+    assert (c.nit, c.plan_n, c.cut_at, c.ncuts) == (0, 2, 1, 1)
+    _decide(c, p0 + REJECT)                            # second rejection at the same position: failure (:306)
+    assert (c.nit, c.status, c.plan_n, c.cut_at) == (0, _lib.ZF_RUNNING, 1, -1)   # first commit the accepted one
+    _decide(c, p0 + [0.0] * 8)
+    assert (c.nit, c.status, c.trial, c.lr) == (1, _lib.ZF_RUNNING, 0, 1.0)
+    _decide(c, REJECT + REJECT)
+    _decide(c, REJECT + REJECT)
+    assert (c.nit, c.status, c.lr, c.total_trials) == (1, _lib.ZF_BACKTRACK_FAILED, 0.25, 3)
+
+
+CHAIN_CASES = [
+    dict(lr=0.45, nesterov=True, tol=0.0, max_iter=37),
+    dict(lr=0.45, nesterov=True, tol=0.0, max_iter=1),
+    dict(lr=0.45, nesterov=True, tol=0.0, max_iter=3),
+    dict(lr=64.0, nesterov=True, tol=0.0, max_iter=23),
+    dict(lr=64.0, nesterov=False, tol=1e-9, max_iter=500),
+    dict(lr=3.0, nesterov=True, decay_rate=0.9, tol=1e-8, max_iter=400),
+    dict(lr=0.45, nesterov=True, decay_rate=1.0, tol=1e-7, max_iter=300),
+    dict(lr=0.45, nesterov=True, deprecated=True, tol=1e-7, max_iter=300),
+    dict(lr=1e6, nesterov=True, max_backtrack_iter=3, tol=0.0, max_iter=50),
+    dict(lr=0.45, nesterov=True, tol=1e-12, max_iter=2 * _lib.ZF_RING + 13),
+]
+
+
+def _chain_run(prob, x0, kw, sub, chunk):
+    run = NativeRun(prob, x0, BASE | kw | dict(sub_iters=sub), solver_factory=_factory)
+    assert run.sub_iters == sub
+    rows = [np.zeros((0, _lib.ZF_TRACE_COLS))]
+    while run.status == _lib.ZF_RUNNING:
+        rows.append(run.advance(chunk))
+    c = run.solver.ctl
+    return dict(rows=np.concatenate(rows), x=run.solver.get_x(), nit=int(c.nit), status=int(c.status), lr=c.lr,
+                F=c.F_old, trials=int(c.total_trials), passes=run.solver.passes)
+
+
+@pytest.mark.parametrize("case", range(len(CHAIN_CASES)))
+def test_chained_passes_do_not_change_results(case):
+    """Host driver + decide pass with chains of S trials per pass (the plan / replay logic the
+    GPU kernels follow) against one trial per pass: identical traces, iterates and counters."""
+    n = 501
+    d, c, lam = P.make_pdiag(n, seed=20 + case)
+    prob = FakeProblem(d, c, lam)
+    x0 = np.random.default_rng(case).standard_normal(n)
+    kw = CHAIN_CASES[case]
+    ref = _chain_run(prob, x0, kw, 1, 64)
+    for sub in (2, 4, 8):
+        for chunk in (1, 9):
+            r = _chain_run(prob, x0, kw, sub, chunk)
+            for key in ("nit", "status", "lr", "F", "trials"):
+                assert r[key] == ref[key], (sub, chunk, key)
+            assert np.array_equal(r["rows"], ref["rows"]) and np.array_equal(r["x"], ref["x"]), (sub, chunk)
+        if kw["lr"] == 0.45 and kw.get("decay_rate", 0.5) != 1.0 and ref["nit"] >= 16:
+            assert r["passes"] <= -(-ref["nit"] // sub) + 4   # chains really are S long when nothing is rejected
