@@ -150,7 +150,9 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     while run.status == _lib.ZF_RUNNING:   # a broken chain (rejected trial, lr halves :305) costs extra passes
-        run.enqueue_only(max(1, (K - (run.nit_seen - nit0) + S - 1) // S))
+        # passes the remaining iterations need if no chain breaks, plus two spare ones (a pass
+        # enqueued after the device has reached max_iter exits at once)
+        run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S + 2)
         run.collect()
     sync_all()
     dt = time.perf_counter() - t0

@@ -500,7 +500,7 @@ int main(int argc, char** argv) {
         run_lib_loop<true, 1>(B, 1); run_lib_loop<true, 1>(B, 2); run_lib_loop<true, 1>(B, 4); run_lib_loop<false, 1>(B, 1);
         run_lib_loop<true, 2>(B, 1); run_lib_loop<true, 2>(B, 2); run_lib_loop<false, 2>(B, 1);
         run_lib_loop<true, 4>(B, 1); run_lib_loop<true, 4>(B, 2); run_lib_loop<true, 4>(B, 4); run_lib_loop<false, 4>(B, 1);
-        run_lib_loop<true, 8>(B, 1); run_lib_loop<true, 8>(B, 2); run_lib_loop<true, 8>(B, 4); run_lib_loop<false, 8>(B, 1);
+        run_lib_loop<true, 8>(B, 1); run_lib_loop<true, 8>(B, 2); run_lib_loop<true, 8>(B, 4); run_lib_loop<true, 8>(B, 8); run_lib_loop<false, 8>(B, 8);
     }
     return 0;
 }

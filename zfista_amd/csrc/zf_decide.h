@@ -86,34 +86,47 @@ ZF_HD inline void zf_apply_known_reject(zf_control* c) {
     if (c->trial >= c->max_backtrack) c->status = ZF_BACKTRACK_FAILED;
 }
 
-// One trial against the control block *c (buffer indices are not touched: the caller commits
-// them).  beta_ring (may be NULL on the host): momentum ring indexed by the accepted-iteration
-// count; on acceptance the factor of the NEXT trial is copied into the control block.
-// Returns true when the trial was accepted and the loop goes on.
-ZF_HD inline bool zf_decide_step(zf_control* c, const double* packs, double* trace,
-                                 const double* beta_ring = nullptr, int pack_stride = ZF_PACK_LEN) {
-    if (c->status != ZF_RUNNING) return false;
-    double pk[ZF_PACK_LEN];
-    zf_reduce_packs(packs, c->world, pack_stride, pk);
-    const double f_y = pk[ZF_PK_FY], dot = pk[ZF_PK_DOT], ss = pk[ZF_PK_SS];
-    const double g_x = pk[ZF_PK_GX], f_x = pk[ZF_PK_FX], err = pk[ZF_PK_ERR];
-    const double lr = c->lr;
-    const double F_old = c->F_old;
+// The floating-point part of one trial: model value, F(x+) and the acceptance test for a given
+// F_old and step size (:149-155, :295, :298-303).  Pure: trials of a chain can be evaluated
+// independently (lane-parallel on the device) once F_old of trial j is taken as F(x+) of trial
+// j - 1, which is what it is if the chain holds up to there.
+typedef struct zf_trial_eval {
+    double fun, F_x, f_x, g_x, f_y, err;
+    double lr_used, F_old_used;
+    int accept;
+} zf_trial_eval;
 
+ZF_HD inline void zf_eval_trial(const zf_control* c, double F_old, double lr, const double* pk /* reduced */,
+                                zf_trial_eval* e) {
+    const double f_y = pk[ZF_PK_FY], dot = pk[ZF_PK_DOT], ss = pk[ZF_PK_SS];
+    const double g_x = pk[ZF_PK_GX], f_x = pk[ZF_PK_FX];
     const double nrm = sqrt(ss);                       // np.linalg.norm(x+ - y)
     double fun = (dot + g_x) + nrm * nrm / 2 / lr;     // :150-152
     if (!c->deprecated) fun = fun + (f_y - F_old);     // :155
     const double F_x = f_x + g_x;                      // :295
-
     bool accept;
     if (c->decay_rate == 1.0) accept = true;                                  // :298
     else if (c->deprecated) accept = (f_x - f_y <= fun + c->tol_internal);    // :301
     else accept = (F_x - F_old <= fun + c->tol_internal);                     // :303
+    e->fun = fun;
+    e->F_x = F_x;
+    e->f_x = f_x;
+    e->g_x = g_x;
+    e->f_y = f_y;
+    e->err = pk[ZF_PK_ERR];
+    e->lr_used = lr;
+    e->F_old_used = F_old;
+    e->accept = accept ? 1 : 0;
+}
 
+// The bookkeeping part of one trial (:305-307, :510, :525, :533-543) for an evaluation made with
+// the block's current lr and F_old.  Returns true when the trial was accepted and the loop goes on.
+ZF_HD inline bool zf_apply_trial(zf_control* c, const zf_trial_eval* e, double* trace, const double* beta_ring) {
+    const double lr = c->lr;
     c->trial += 1;
     c->total_trials += 1;
-    c->f_y = f_y;
-    if (!accept) {
+    c->f_y = e->f_y;
+    if (!e->accept) {
         c->lr = lr * c->decay_rate;                                           // :305
         c->need_grad = 0;   // y_k unchanged: grad f(y_k), f(y_k) stay valid
         if (c->trial >= c->max_backtrack) c->status = ZF_BACKTRACK_FAILED;    // :306-307
@@ -121,32 +134,50 @@ ZF_HD inline bool zf_decide_step(zf_control* c, const double* packs, double* tra
     }
     const int64_t nit = c->nit + 1;
     double* row = trace + ((nit - 1) % ZF_RING) * ZF_TRACE_COLS;
-    row[ZF_TR_ERR] = err;
-    row[ZF_TR_F] = F_x;
+    row[ZF_TR_ERR] = e->err;
+    row[ZF_TR_F] = e->F_x;
     row[ZF_TR_LR] = lr;
-    row[ZF_TR_FUN] = fun;
+    row[ZF_TR_FUN] = e->fun;
     row[ZF_TR_TRIALS] = (double)c->trial;
-    row[ZF_TR_FX] = f_x;
-    row[ZF_TR_GX] = g_x;
-    row[ZF_TR_FY] = f_y;
+    row[ZF_TR_FX] = e->f_x;
+    row[ZF_TR_GX] = e->g_x;
+    row[ZF_TR_FY] = e->f_y;
     c->nit = nit;
-    c->F_old = F_x;
-    c->f_x = f_x;
-    c->g_x = g_x;
-    c->err = err;
-    c->fun = fun;
+    c->F_old = e->F_x;
+    c->f_x = e->f_x;
+    c->g_x = e->g_x;
+    c->err = e->err;
+    c->fun = e->fun;
     c->trial = 0;
     c->need_grad = 1;
     if (beta_ring) c->beta_next = beta_ring[nit % ZF_RING];   // y_{k+1} = x_k + beta (x_k - x_{k-1})  :533-534
-    if (err < c->tol) c->status = ZF_CONVERGED;               // :525
+    if (e->err < c->tol) c->status = ZF_CONVERGED;            // :525
     else if (nit >= c->max_iter) c->status = ZF_MAXITER;      // :539
     return c->status == ZF_RUNNING;
 }
 
+// One trial against the control block *c (buffer indices are not touched: the caller commits
+// them).  beta_ring (may be NULL on the host): momentum ring indexed by the accepted-iteration
+// count; on acceptance the factor of the NEXT trial is copied into the control block.
+// `pre` (optional): this trial evaluated in advance; used when it was made with the block's
+// current lr and F_old, recomputed otherwise.
+ZF_HD inline bool zf_decide_step(zf_control* c, const double* packs, double* trace,
+                                 const double* beta_ring = nullptr, int pack_stride = ZF_PACK_LEN,
+                                 const zf_trial_eval* pre = nullptr) {
+    if (c->status != ZF_RUNNING) return false;
+    if (pre && pre->lr_used == c->lr && pre->F_old_used == c->F_old) return zf_apply_trial(c, pre, trace, beta_ring);
+    double pk[ZF_PACK_LEN];
+    zf_reduce_packs(packs, c->world, pack_stride, pk);
+    zf_trial_eval e;
+    zf_eval_trial(c, c->F_old, c->lr, pk, &e);
+    return zf_apply_trial(c, &e, trace, beta_ring);
+}
+
 // All trials of one pass.  packs: world x sub_iters x ZF_PACK_LEN (rank-major), pack j of a
 // rank = trial j of the chain.
+// `pre` (optional): sub_iters evaluations made in advance, one per trial of the chain.
 ZF_HD inline void zf_decide_pass(zf_control* ctl, const double* packs, double* trace,
-                                 const double* beta_ring = nullptr) {
+                                 const double* beta_ring = nullptr, const zf_trial_eval* pre = nullptr) {
     if (ctl->status != ZF_RUNNING) return;
     const int sub = ctl->sub_iters > 0 ? ctl->sub_iters : 1;
     const int ring = ctl->ring_size > 0 ? ctl->ring_size : 3;
@@ -163,7 +194,7 @@ ZF_HD inline void zf_decide_pass(zf_control* ctl, const double* packs, double* t
             if (c.status != ZF_RUNNING) break;
         }
         const int64_t before = c.nit;
-        const bool go = zf_decide_step(&c, packs + j * ZF_PACK_LEN, trace, beta_ring, stride);
+        const bool go = zf_decide_step(&c, packs + j * ZF_PACK_LEN, trace, beta_ring, stride, pre ? pre + j : nullptr);
         if (c.nit > before) accepted += 1;
         else rejected = true;
         if (!go) break;
@@ -212,3 +243,27 @@ ZF_HD inline void zf_decide_pass(zf_control* ctl, const double* packs, double* t
     ctl->cut_at = new_cut;
     ctl->ncuts = new_ncuts;
 }
+
+#if defined(__HIPCC__)
+// Device: the decide pass of one wave.  Lane j evaluates trial j of the chain (sqrt, divisions
+// and the acceptance test cost a few thousand cycles on a single lane; the S of them run side by
+// side) and leaves the result in LDS; lane 0 then walks the chain with the evaluations at hand.
+// `pk`: this lane's pack j, already reduced over ranks (lanes >= sub_iters: ignored);
+// `lds_pre`: ZF_MAX_SUB_ITERS entries of LDS.  Must be called by all 64 lanes of ONE wave.
+__device__ __forceinline__ void zf_decide_pass_wave(zf_control* ctl, const double* packs_global,
+                                                    const double (&pk)[ZF_PACK_LEN], double* trace,
+                                                    const double* beta_ring, int lane, zf_trial_eval* lds_pre) {
+    if (ctl->status != ZF_RUNNING) return;
+    const int cut_at = ctl->cut_at, ncuts = ctl->ncuts;
+    double lr = ctl->lr;
+    if (cut_at >= 0 && lane >= cut_at)
+        for (int r = 0; r < ncuts; ++r) lr = lr * ctl->decay_rate;   // :305 per known rejection
+    const double F_x_mine = pk[ZF_PK_FX] + pk[ZF_PK_GX];               // :295
+    const double F_x_prev = __shfl_up(F_x_mine, 1, 64);
+    const double F_old = (lane == 0) ? ctl->F_old : F_x_prev;
+    zf_trial_eval e;
+    zf_eval_trial(ctl, F_old, lr, pk, &e);
+    if (lane < ZF_MAX_SUB_ITERS) lds_pre[lane] = e;
+    if (lane == 0) zf_decide_pass(ctl, packs_global, trace, beta_ring, lds_pre);
+}
+#endif

@@ -93,7 +93,7 @@ constexpr int ZF_TILE_U = 4;
 constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per tile
 constexpr int ZF_MAX_TILES_PER_WG = 8;                // upper bound of zf_step_args.tiles_per_wg
 constexpr int ZF_FIN_WGS = 48;                        // workgroups of the finalize kernel
-constexpr int ZF_FIN_THREADS = 1024;
+constexpr int ZF_FIN_THREADS = 256;
 
 typedef double zf_d2 __attribute__((ext_vector_type(2)));
 
@@ -155,9 +155,9 @@ struct zf_finalize_args {
 template <int S>
 __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize_args F) {
     constexpr int NQ = S * ZF_NPART;
-    constexpr int QG = (NQ > 24) ? 24 : NQ;   // quantities per round (register budget at 1024 threads)
     constexpr int NW = ZF_FIN_THREADS / 64;
     __shared__ double lds[NW * NQ];
+    __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
     __shared__ int s_last;
     if (F.ctl->status != ZF_RUNNING) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -165,23 +165,37 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     const int b0 = blockIdx.x * per;
     int b1 = b0 + per;
     if (b1 > F.nblocks) b1 = F.nblocks;
+    // GT trials (6 GT quantities) per round: bounded registers; their wave reductions run as one
+    // transposing butterfly (zf_wave_reduce_multi - the same pairing as a butterfly per quantity)
+    constexpr int GT = (S > 4) ? 4 : S;
+    constexpr int GH = (GT >= 4) ? 2 : (GT >= 2) ? 1 : 0;
 #pragma unroll
-    for (int q0 = 0; q0 < NQ; q0 += QG) {
-        double v[QG];
+    for (int j0 = 0; j0 < S; j0 += GT) {
+        double sums[5 * GT], maxs[GT];
 #pragma unroll
-        for (int k = 0; k < QG; ++k) v[k] = 0.0;
+        for (int k = 0; k < 5 * GT; ++k) sums[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < GT; ++k) maxs[k] = 0.0;
         for (int b = b0 + threadIdx.x; b < b1; b += ZF_FIN_THREADS) {
-            double p[QG];
+            double p[ZF_NPART * GT];
 #pragma unroll
-            for (int k = 0; k < QG; ++k) p[k] = F.blk_part[(int64_t)(q0 + k) * F.nblocks + b];
+            for (int k = 0; k < ZF_NPART * GT; ++k) p[k] = F.blk_part[(int64_t)(j0 * ZF_NPART + k) * F.nblocks + b];
 #pragma unroll
-            for (int k = 0; k < QG; ++k)
-                v[k] = ((q0 + k) % ZF_NPART == ZF_NPART - 1) ? fmax(v[k], p[k]) : v[k] + p[k];
+            for (int j = 0; j < GT; ++j) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) sums[j * 5 + k] = sums[j * 5 + k] + p[j * ZF_NPART + k];
+                maxs[j] = fmax(maxs[j], p[j * ZF_NPART + 5]);
+            }
         }
+        zf_wave_reduce_multi<5 * GT, GH, false>(sums, lane);
+        zf_wave_reduce_multi<GT, GH, true>(maxs, lane);
+        if ((lane & ((64 >> GH) - 1)) == 0) {
 #pragma unroll
-        for (int k = 0; k < QG; ++k) {
-            const double r = ((q0 + k) % ZF_NPART == ZF_NPART - 1) ? zf_wave_max(v[k]) : zf_wave_sum(v[k]);
-            if (lane == 0) lds[wave * NQ + q0 + k] = r;
+            for (int q = 0; q < 5; ++q) {
+                const int idx = zf_wave_reduce_multi_index<5 * GT, GH>(q, lane);
+                lds[wave * NQ + (j0 + idx / 5) * ZF_NPART + idx % 5] = sums[q];
+            }
+            lds[wave * NQ + (j0 + zf_wave_reduce_multi_index<GT, GH>(0, lane)) * ZF_NPART + 5] = maxs[0];
         }
     }
     __syncthreads();
@@ -207,29 +221,55 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     }
     __syncthreads();
     if (!s_last || wave != 0) return;
-    // last arriver, wave 0: lane q holds slice q (independent sc1 loads: one round trip),
-    // then the fixed shuffle tree adds the slices in slice order
-    double tot[NQ];
+    // last arriver, wave 0: lane q holds slice q (independent sc1 loads: one round trip per
+    // trial, the next trial's loads in flight meanwhile), the fixed shuffle tree adds the slices
+    // in slice order, lane 0 writes the pack of the trial
+    const int nsl = (int)gridDim.x;
+    double nxt[ZF_NPART];
 #pragma unroll
-    for (int k = 0; k < NQ; ++k)
-        tot[k] = (lane < (int)gridDim.x) ? zf_consume(F.slice_part + (int64_t)k * ZF_FIN_WGS + lane) : 0.0;
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) tot[k] = (k % ZF_NPART == ZF_NPART - 1) ? zf_wave_max(tot[k]) : zf_wave_sum(tot[k]);
-    if (lane != 0) return;
-#pragma unroll
+    for (int k = 0; k < ZF_NPART; ++k)
+        nxt[k] = (lane < nsl) ? zf_consume(F.slice_part + (int64_t)k * ZF_FIN_WGS + lane) : 0.0;
+    double mine[ZF_PACK_LEN] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lane j keeps pack j
+    const double f_y_ext = F.f_y_ext ? (F.contribute_f ? *F.f_y_ext : 0.0) : 0.0;
+    const double f_x_ext = F.f_x_ext ? (F.contribute_f ? *F.f_x_ext : 0.0) : 0.0;
+#pragma unroll 1
     for (int j = 0; j < S; ++j) {
-        double* pack = F.pack + j * ZF_PACK_LEN;
-        const double* t = tot + j * ZF_NPART;
-        pack[ZF_PK_FY] = F.f_y_ext ? (F.contribute_f ? *F.f_y_ext : 0.0) : F.scale[0] * t[0];
-        pack[ZF_PK_DOT] = t[1];
-        pack[ZF_PK_SS] = t[2];
-        pack[ZF_PK_GX] = F.scale[3] * t[3];
-        pack[ZF_PK_FX] = F.f_x_ext ? (F.contribute_f ? *F.f_x_ext : 0.0) : F.scale[4] * t[4];
-        pack[ZF_PK_ERR] = t[5];
-        pack[6] = 0.0;
-        pack[7] = 0.0;
+        double t[ZF_NPART];
+#pragma unroll
+        for (int k = 0; k < ZF_NPART; ++k) t[k] = nxt[k];
+        if (j + 1 < S) {
+#pragma unroll
+            for (int k = 0; k < ZF_NPART; ++k)
+                nxt[k] = (lane < nsl)
+                             ? zf_consume(F.slice_part + (int64_t)((j + 1) * ZF_NPART + k) * ZF_FIN_WGS + lane)
+                             : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < ZF_NPART; ++k) {
+            t[k] = (k == ZF_NPART - 1) ? zf_wave_max(t[k]) : zf_wave_sum(t[k]);
+            t[k] = __shfl(t[k], 0, 64);   // the total of lane 0's tree, to every lane
+        }
+        double pk[ZF_PACK_LEN];
+        pk[ZF_PK_FY] = F.f_y_ext ? f_y_ext : F.scale[0] * t[0];
+        pk[ZF_PK_DOT] = t[1];
+        pk[ZF_PK_SS] = t[2];
+        pk[ZF_PK_GX] = F.scale[3] * t[3];
+        pk[ZF_PK_FX] = F.f_x_ext ? f_x_ext : F.scale[4] * t[4];
+        pk[ZF_PK_ERR] = t[5];
+        pk[6] = 0.0;
+        pk[7] = 0.0;
+        if (lane == j) {
+#pragma unroll
+            for (int k = 0; k < ZF_PACK_LEN; ++k) mine[k] = pk[k];
+        }
+        if (lane == 0) {
+            double* pack = F.pack + j * ZF_PACK_LEN;
+#pragma unroll
+            for (int k = 0; k < ZF_PACK_LEN; ++k) pack[k] = pk[k];
+        }
     }
-    if (F.decide) zf_decide_pass(F.ctl, F.pack, F.trace, F.beta_ring);
+    // unsharded x: the decide pass right here, trial j evaluated by lane j
+    if (F.decide) zf_decide_pass_wave(F.ctl, F.pack, mine, F.trace, F.beta_ring, lane, s_pre);
 }
 
 // GRAD_INLINE: true  -> separable quadratic, gradient computed from d, c
@@ -245,18 +285,14 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 //     produced; a chain that breaks in the middle is planned again up to the break (ctl->plan_n)
 //     and continued at the reduced step size (ctl->cut_at, ctl->ncuts), so iterates, traces and
 //     decisions are bit-identical to S = 1 (tests/test_gpu_temporal.py).
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S>
-__global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
-    static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
-    __shared__ double lds[ZF_WAVES * S * ZF_NPART];
-    // wave-uniform control reads (scalar loads); written by the previous step's decide
-    const int status = A.ctl->status;
-    if (status != ZF_RUNNING) return;
+// FULL: the chain is S trials long (known at compile time: no per-trial branch); otherwise the
+// planned length ctl->plan_n < S is honoured trial by trial (replays, the last pass before max_iter)
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool FULL>
+__device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds, const int ntr) {
     const int cur = A.ctl->cur;
     const int prev = A.ctl->prev;
     const int ring = A.ctl->ring_size;
     const double lr = A.ctl->lr;
-    const int ntr = (S == 1) ? 1 : zf_plan_len(A.ctl);   // trials of this chain
     double beta[S], lrj[S], tau[S];
     beta[0] = NESTEROV ? A.ctl->beta_next : 0.0;   // same cache line as status / cur / lr
     lrj[0] = lr;
@@ -296,7 +332,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     auto advance = [&](zf_d2 a, zf_d2 o, zf_d2 q, zf_d2 cc, int64_t i) {
 #pragma unroll
         for (int j = 0; j < S; ++j) {
-            if (j < ntr) {
+            if (FULL || j < ntr) {
                 zf_d2 r;
                 if (GRAD_INLINE) {
                     r.x = zf_elem_diag<NESTEROV, BOX>(a.x, o.x, q.x, cc.x, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
@@ -310,7 +346,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
             }
         }
         zf_st2<NT>(reinterpret_cast<zf_d2*>(out_last) + i, a);
-        if (S > 1 && ntr >= 2) zf_st2<NT>(reinterpret_cast<zf_d2*>(out_prev) + i, o);
+        if (S > 1 && (FULL || ntr >= 2)) zf_st2<NT>(reinterpret_cast<zf_d2*>(out_prev) + i, o);
         // long chains: finish one unit before the next (interleaving four 8-trial chains costs
         // ~100 more VGPRs and halves the occupancy)
         if (S >= 8) __builtin_amdgcn_sched_barrier(0);
@@ -358,7 +394,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
             const double q = p0[e], cc = GRAD_INLINE ? p1[e] : q;
 #pragma unroll
             for (int j = 0; j < S; ++j) {
-                if (j < ntr) {
+                if (FULL || j < ntr) {
                     double r;
                     if (GRAD_INLINE)
                         r = zf_elem_diag<NESTEROV, BOX>(a, o, q, cc, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
@@ -368,7 +404,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
                 }
             }
             out_last[e] = a;
-            if (S > 1 && ntr >= 2) out_prev[e] = o;
+            if (S > 1 && (FULL || ntr >= 2)) out_prev[e] = o;
         }
     }
 
@@ -405,6 +441,21 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
 #pragma unroll
         for (int w = 1; w < ZF_WAVES; ++w) v = (t % ZF_NPART == 5) ? fmax(v, lds[w * NQ + t]) : v + lds[w * NQ + t];
         A.blk_part[(int64_t)t * gridDim.x + blockIdx.x] = v;
+    }
+}
+
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S>
+__global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
+    static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
+    __shared__ double lds[ZF_WAVES * S * ZF_NPART];
+    // wave-uniform control reads (scalar loads); written by the previous step's decide
+    if (A.ctl->status != ZF_RUNNING) return;
+    if (S == 1) {
+        zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, true>(A, lds, 1);
+    } else {
+        const int ntr = zf_plan_len(A.ctl);   // trials of this chain
+        if (ntr == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, true>(A, lds, S);
+        else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, false>(A, lds, ntr);
     }
 }
 

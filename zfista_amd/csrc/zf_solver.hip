@@ -38,11 +38,14 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_sum_parts_kernel(const zf_control
 
 // sharded x: packs = world x sub x ZF_PACK_LEN (rank-major).  The sub-iterations of a pass are
 // examined in order; the first rejection / termination discards the speculative rest.
-__global__ void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace, const double* beta_ring,
-                                 int sub) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    (void)sub;   // == ctl->sub_iters
-    zf_decide_pass(ctl, packs, trace, beta_ring);
+__global__ __launch_bounds__(64) void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace,
+                                                       const double* beta_ring, int sub) {
+    __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    double pk[ZF_PACK_LEN] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (lane < sub) zf_reduce_packs(packs + lane * ZF_PACK_LEN, ctl->world, sub * ZF_PACK_LEN, pk);   // rank order
+    zf_decide_pass_wave(ctl, packs, pk, trace, beta_ring, lane, s_pre);
 }
 
 __global__ void zf_set_max_iter_kernel(zf_control* ctl, int64_t max_iter) {
