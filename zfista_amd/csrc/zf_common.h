@@ -131,6 +131,15 @@ __device__ __forceinline__ double zf_soft_threshold(double u, double tau) {
     a = (a < 0.0) ? 0.0 : a;
     return copysign(a, u);
 }
+// The same for tau >= 0 in four instructions: u - clamp(u, -tau, tau), sign of u copied onto the
+// result.  |u| > tau: u -/+ tau is the one rounding of sign(u) * (|u| - tau); |u| <= tau: u - u = 0,
+// signed like u, as sign(u) * 0 is; NaN and infinities propagate the same way (max/min drop a
+// NaN operand, u - t restores it).  The solver checks tau >= 0 (lam >= 0, lr > 0, decay_rate > 0)
+// at creation; hosts route other inputs through the general form above.
+__device__ __forceinline__ double zf_soft_threshold_nn(double u, double tau) {
+    const double t = fmin(fmax(u, -tau), tau);
+    return copysign(u - t, u);
+}
 // np.clip(u, lo, hi) = minimum(maximum(u, lo), hi)  (jaxopt projection_box, problems.py:137)
 __device__ __forceinline__ double zf_clip(double u, double lo, double hi) {
     double t = (u < lo) ? lo : u;

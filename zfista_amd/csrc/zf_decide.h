@@ -245,25 +245,28 @@ ZF_HD inline void zf_decide_pass(zf_control* ctl, const double* packs, double* t
 }
 
 #if defined(__HIPCC__)
-// Device: the decide pass of one wave.  Lane j evaluates trial j of the chain (sqrt, divisions
-// and the acceptance test cost a few thousand cycles on a single lane; the S of them run side by
-// side) and leaves the result in LDS; lane 0 then walks the chain with the evaluations at hand.
-// `pk`: this lane's pack j, already reduced over ranks (lanes >= sub_iters: ignored);
+// Device: the decide pass of one wave.  Trial j of the chain is evaluated by lane j * lstr
+// (sqrt, divisions and the acceptance test cost a few thousand cycles on a single lane; the S of
+// them run side by side) and left in LDS; lane 0 then walks the chain with the evaluations at hand.
+// `pk`: the pack of this lane's trial, already reduced over ranks (other lanes: ignored);
+// `packs`: all packs of the pass, readable by lane 0 (used if an evaluation does not apply);
 // `lds_pre`: ZF_MAX_SUB_ITERS entries of LDS.  Must be called by all 64 lanes of ONE wave.
-__device__ __forceinline__ void zf_decide_pass_wave(zf_control* ctl, const double* packs_global,
+__device__ __forceinline__ void zf_decide_pass_wave(zf_control* ctl, const double* packs,
                                                     const double (&pk)[ZF_PACK_LEN], double* trace,
-                                                    const double* beta_ring, int lane, zf_trial_eval* lds_pre) {
+                                                    const double* beta_ring, int lane, int lstr,
+                                                    zf_trial_eval* lds_pre) {
     if (ctl->status != ZF_RUNNING) return;
+    const int trial = lane / lstr;
     const int cut_at = ctl->cut_at, ncuts = ctl->ncuts;
     double lr = ctl->lr;
-    if (cut_at >= 0 && lane >= cut_at)
+    if (cut_at >= 0 && trial >= cut_at)
         for (int r = 0; r < ncuts; ++r) lr = lr * ctl->decay_rate;   // :305 per known rejection
     const double F_x_mine = pk[ZF_PK_FX] + pk[ZF_PK_GX];               // :295
-    const double F_x_prev = __shfl_up(F_x_mine, 1, 64);
-    const double F_old = (lane == 0) ? ctl->F_old : F_x_prev;
+    const double F_x_prev = __shfl_up(F_x_mine, lstr, 64);
+    const double F_old = (trial == 0) ? ctl->F_old : F_x_prev;
     zf_trial_eval e;
     zf_eval_trial(ctl, F_old, lr, pk, &e);
-    if (lane < ZF_MAX_SUB_ITERS) lds_pre[lane] = e;
-    if (lane == 0) zf_decide_pass(ctl, packs_global, trace, beta_ring, lds_pre);
+    if (lane % lstr == 0 && trial < ZF_MAX_SUB_ITERS) lds_pre[trial] = e;
+    if (lane == 0) zf_decide_pass(ctl, packs, trace, beta_ring, lds_pre);
 }
 #endif

@@ -36,7 +36,7 @@ __device__ __forceinline__ double zf_elem_diag(double xk, double xo, double d, d
     const double grad = d * r;          // jac_f = d * (y - c)
     a.fy += d * (r * r);                // f = 0.5 * sum(d * (r*r))
     const double v = y - lr * grad;
-    double xn = zf_soft_threshold(v, tau);
+    double xn = zf_soft_threshold_nn(v, tau);
     if (BOX) xn = zf_clip(xn, lo, hi);
     const double dx = xn - y;
     a.dot += grad * dx;
@@ -54,7 +54,7 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
     double y = xk;
     if (NESTEROV) y = xk + beta * (xk - xo);
     const double v = y - lr * grad;
-    double xn = zf_soft_threshold(v, tau);
+    double xn = zf_soft_threshold_nn(v, tau);
     if (BOX) xn = zf_clip(xn, lo, hi);
     const double dx = xn - y;
     a.dot += grad * dx;
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     constexpr int NW = ZF_FIN_THREADS / 64;
     __shared__ double lds[NW * NQ];
     __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
+    __shared__ double s_pack[ZF_MAX_SUB_ITERS * ZF_PACK_LEN];
     __shared__ int s_last;
     if (F.ctl->status != ZF_RUNNING) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     if (b1 > F.nblocks) b1 = F.nblocks;
     // GT trials (6 GT quantities) per round: bounded registers; their wave reductions run as one
     // transposing butterfly (zf_wave_reduce_multi - the same pairing as a butterfly per quantity)
-    constexpr int GT = (S > 4) ? 4 : S;
-    constexpr int GH = (GT >= 4) ? 2 : (GT >= 2) ? 1 : 0;
+    constexpr int GT = S;   // (256 threads per workgroup: registers allow all 6 S loads of an index in flight)
+    constexpr int GH = (GT >= 8) ? 3 : (GT >= 4) ? 2 : (GT >= 2) ? 1 : 0;
 #pragma unroll
     for (int j0 = 0; j0 < S; j0 += GT) {
         double sums[5 * GT], maxs[GT];
@@ -221,55 +222,44 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     }
     __syncthreads();
     if (!s_last || wave != 0) return;
-    // last arriver, wave 0: lane q holds slice q (independent sc1 loads: one round trip per
-    // trial, the next trial's loads in flight meanwhile), the fixed shuffle tree adds the slices
-    // in slice order, lane 0 writes the pack of the trial
+    // last arriver, wave 0: lane q holds slice q (independent sc1 loads), the fixed shuffle tree
+    // adds the slices in slice order, lane j keeps pack j and lane 0 writes all of them
     const int nsl = (int)gridDim.x;
-    double nxt[ZF_NPART];
+    double tot[NQ];   // all 6 S loads in flight at once: one round trip
 #pragma unroll
-    for (int k = 0; k < ZF_NPART; ++k)
-        nxt[k] = (lane < nsl) ? zf_consume(F.slice_part + (int64_t)k * ZF_FIN_WGS + lane) : 0.0;
-    double mine[ZF_PACK_LEN] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lane j keeps pack j
-    const double f_y_ext = F.f_y_ext ? (F.contribute_f ? *F.f_y_ext : 0.0) : 0.0;
-    const double f_x_ext = F.f_x_ext ? (F.contribute_f ? *F.f_x_ext : 0.0) : 0.0;
-#pragma unroll 1
+    for (int k = 0; k < NQ; ++k)
+        tot[k] = (lane < nsl) ? zf_consume(F.slice_part + (int64_t)k * ZF_FIN_WGS + lane) : 0.0;
+    // one transposing butterfly for all 6 S totals (same pairing as a shuffle tree per quantity):
+    // the totals of trial j end in lane j * (64 / S), which builds, keeps and stores pack j
+    constexpr int LSTR = 64 >> GH;
+    double sums[5 * S], maxs[S];
+#pragma unroll
     for (int j = 0; j < S; ++j) {
-        double t[ZF_NPART];
 #pragma unroll
-        for (int k = 0; k < ZF_NPART; ++k) t[k] = nxt[k];
-        if (j + 1 < S) {
+        for (int k = 0; k < 5; ++k) sums[j * 5 + k] = tot[j * ZF_NPART + k];
+        maxs[j] = tot[j * ZF_NPART + 5];
+    }
+    zf_wave_reduce_multi<5 * S, GH, false>(sums, lane);
+    zf_wave_reduce_multi<S, GH, true>(maxs, lane);
+    const int trial = lane / LSTR;   // slot q of this lane = quantity q of trial `trial`
+    double pk[ZF_PACK_LEN];
+    pk[ZF_PK_FY] = F.f_y_ext ? (F.contribute_f ? *F.f_y_ext : 0.0) : F.scale[0] * sums[0];
+    pk[ZF_PK_DOT] = sums[1];
+    pk[ZF_PK_SS] = sums[2];
+    pk[ZF_PK_GX] = F.scale[3] * sums[3];
+    pk[ZF_PK_FX] = F.f_x_ext ? (F.contribute_f ? *F.f_x_ext : 0.0) : F.scale[4] * sums[4];
+    pk[ZF_PK_ERR] = maxs[0];
+    pk[6] = 0.0;
+    pk[7] = 0.0;
+    if (lane % LSTR == 0) {
 #pragma unroll
-            for (int k = 0; k < ZF_NPART; ++k)
-                nxt[k] = (lane < nsl)
-                             ? zf_consume(F.slice_part + (int64_t)((j + 1) * ZF_NPART + k) * ZF_FIN_WGS + lane)
-                             : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < ZF_NPART; ++k) {
-            t[k] = (k == ZF_NPART - 1) ? zf_wave_max(t[k]) : zf_wave_sum(t[k]);
-            t[k] = __shfl(t[k], 0, 64);   // the total of lane 0's tree, to every lane
-        }
-        double pk[ZF_PACK_LEN];
-        pk[ZF_PK_FY] = F.f_y_ext ? f_y_ext : F.scale[0] * t[0];
-        pk[ZF_PK_DOT] = t[1];
-        pk[ZF_PK_SS] = t[2];
-        pk[ZF_PK_GX] = F.scale[3] * t[3];
-        pk[ZF_PK_FX] = F.f_x_ext ? f_x_ext : F.scale[4] * t[4];
-        pk[ZF_PK_ERR] = t[5];
-        pk[6] = 0.0;
-        pk[7] = 0.0;
-        if (lane == j) {
-#pragma unroll
-            for (int k = 0; k < ZF_PACK_LEN; ++k) mine[k] = pk[k];
-        }
-        if (lane == 0) {
-            double* pack = F.pack + j * ZF_PACK_LEN;
-#pragma unroll
-            for (int k = 0; k < ZF_PACK_LEN; ++k) pack[k] = pk[k];
+        for (int k = 0; k < ZF_PACK_LEN; ++k) {
+            F.pack[trial * ZF_PACK_LEN + k] = pk[k];
+            s_pack[trial * ZF_PACK_LEN + k] = pk[k];
         }
     }
-    // unsharded x: the decide pass right here, trial j evaluated by lane j
-    if (F.decide) zf_decide_pass_wave(F.ctl, F.pack, mine, F.trace, F.beta_ring, lane, s_pre);
+    // unsharded x: the decide pass right here, trial j evaluated by its lane
+    if (F.decide) zf_decide_pass_wave(F.ctl, s_pack, pk, F.trace, F.beta_ring, lane, LSTR, s_pre);
 }
 
 // GRAD_INLINE: true  -> separable quadratic, gradient computed from d, c

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void zf_decide_kernel(zf_control* ctl, const do
     const int lane = threadIdx.x;
     double pk[ZF_PACK_LEN] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (lane < sub) zf_reduce_packs(packs + lane * ZF_PACK_LEN, ctl->world, sub * ZF_PACK_LEN, pk);   // rank order
-    zf_decide_pass_wave(ctl, packs, pk, trace, beta_ring, lane, s_pre);
+    zf_decide_pass_wave(ctl, packs, pk, trace, beta_ring, lane, 1, s_pre);
 }
 
 __global__ void zf_set_max_iter_kernel(zf_control* ctl, int64_t max_iter) {
@@ -169,6 +169,9 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
                "zf_solver_create: bad world/rank");
     ZF_REQUIRE(opt->max_iter >= 1, "zf_solver_create: max_iter must be >= 1");
     ZF_REQUIRE(opt->max_backtrack_iter >= 0, "zf_solver_create: max_backtrack_iter must be >= 0");
+    // the fused kernels threshold with tau = lam * lr >= 0 (zf_soft_threshold_nn)
+    ZF_REQUIRE(desc->lam >= 0.0 && opt->lr > 0.0 && opt->decay_rate > 0.0,
+               "zf_solver_create: needs lam >= 0, lr > 0, decay_rate > 0 (use the callback path otherwise)");
     if (desc->kind == ZF_PROBLEM_DIAG_QUAD_L1) {
         ZF_REQUIRE(desc->d && desc->c, "zf_solver_create: d and c are required");
         ZF_REQUIRE(zf_aligned16(desc->d) && zf_aligned16(desc->c),

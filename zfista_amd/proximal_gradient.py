@@ -71,6 +71,8 @@ def minimize_proximal_gradient(
         deprecated=deprecated,
     )
     native = match_native(f, g, jac_f, prox_wsum_g)
+    if native is not None and not (lr > 0 and decay_rate > 0 and native.lam >= 0):
+        native = None   # the fused kernels assume a threshold lam * lr >= 0; the callback path does not
     native_multi = match_native_multi(f, g, jac_f, prox_wsum_g)
     if native is not None:
         res, status = _solve_native(native, x0, opts)
