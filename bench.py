@@ -143,16 +143,16 @@ def main():
 
     S = run.sub_iters
     while W > 0 and run.status == _lib.ZF_RUNNING:   # warm-up: exactly W iterations, then MAXITER
-        run.advance(_lib.ZF_RING)
+        run.advance((W - run.nit_seen + S - 1) // S)
     run.solver.trial_kernel_ms()          # reset the event window after warm-up
     nit0 = run.nit_seen
     run.set_max_iter(nit0 + K)
     sync_all()
     t0 = time.perf_counter()
     while run.status == _lib.ZF_RUNNING:   # a broken chain (rejected trial, lr halves :305) costs extra passes
-        # passes the remaining iterations need if no chain breaks, plus two spare ones (a pass
-        # enqueued after the device has reached max_iter exits at once)
-        run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S + 2)
+        # exactly the passes the remaining iterations need if no chain breaks (so that every
+        # launch counted below is a real pass); broken chains cost further rounds
+        run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S)
         run.collect()
     sync_all()
     dt = time.perf_counter() - t0

@@ -88,14 +88,14 @@ __device__ __forceinline__ void zf_block_reduce(const double (&sums)[NS], const 
 // lane L holds the wave total of the value with index
 //     q + sum over levels l < H of ((L & (32 >> l)) ? N >> (l + 1) : 0);
 // all lanes that agree in their top H bits hold the same totals.
-template <int N, int H, bool IS_MAX>
-__device__ __forceinline__ void zf_wave_reduce_multi(double (&v)[N], int lane) {
-    static_assert(N % (1 << H) == 0, "N must be a multiple of 2^H");
-#pragma unroll
-    for (int lvl = 0; lvl < 6; ++lvl) {
-        const int off = 32 >> lvl;
-        if (lvl < H) {
-            const int half = N >> (lvl + 1);
+template <int N, int H, bool IS_MAX, int LVL>
+__device__ __forceinline__ void zf_wave_reduce_multi_level(double (&v)[N], int lane) {
+    // (one template instance per level: every array index below is a compile-time constant, so
+    // the values stay in registers - a rolled level loop sent them through scratch memory)
+    if constexpr (LVL < 6) {
+        constexpr int off = 32 >> LVL;
+        if constexpr (LVL < H) {
+            constexpr int half = N >> (LVL + 1);
             const bool hi = (lane & off) != 0;
 #pragma unroll
             for (int q = 0; q < half; ++q) {
@@ -105,13 +105,20 @@ __device__ __forceinline__ void zf_wave_reduce_multi(double (&v)[N], int lane) {
                 v[q] = IS_MAX ? fmax(keep, recv) : keep + recv;
             }
         } else {
+            constexpr int cnt = N >> H;
 #pragma unroll
-            for (int q = 0; q < (N >> H); ++q) {
+            for (int q = 0; q < cnt; ++q) {
                 const double recv = __shfl_xor(v[q], off, 64);
                 v[q] = IS_MAX ? fmax(v[q], recv) : v[q] + recv;
             }
         }
+        zf_wave_reduce_multi_level<N, H, IS_MAX, LVL + 1>(v, lane);
     }
+}
+template <int N, int H, bool IS_MAX>
+__device__ __forceinline__ void zf_wave_reduce_multi(double (&v)[N], int lane) {
+    static_assert(N % (1 << H) == 0, "N must be a multiple of 2^H");
+    zf_wave_reduce_multi_level<N, H, IS_MAX, 0>(v, lane);
 }
 // index of the value whose total ends in slot q of lane `lane` (see above)
 template <int N, int H>
