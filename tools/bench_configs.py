@@ -32,28 +32,33 @@ def _opts(**kw):
 
 
 def run_native(prob, x0, opts, K, W):
+    """Exactly W untimed then K timed accepted iterations (max_iter is raised from W to W + K and
+    the device stops on it), as bench.py does."""
     import torch
 
     from zfista_amd import _lib
     from zfista_amd.proximal_gradient import NativeRun
 
-    run = NativeRun(prob, x0, opts, timing=True)
-    done = 0
-    while done < W and run.status == _lib.ZF_RUNNING:
-        done += len(run.advance(min(W - done, 64)))
+    run = NativeRun(prob, x0, dict(opts, max_iter=max(W, 1)), timing=True)
+    S = run.sub_iters
+    while W > 0 and run.status == _lib.ZF_RUNNING:
+        run.advance((W - run.nit_seen + S - 1) // S)
     run.solver.trial_kernel_ms()
+    nit0, trials0 = run.nit_seen, int(run.solver.ctl.total_trials)
+    run.set_max_iter(nit0 + K)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc = 0
-    while acc < K and run.status == _lib.ZF_RUNNING:
-        run.enqueue_only(min(K - acc, _lib.ZF_RING))
-        acc += len(run.collect())
+    while run.status == _lib.ZF_RUNNING:
+        run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S)
+        run.collect()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    acc = run.nit_seen - nit0
     ms, cnt = run.solver.trial_kernel_ms()
     ctl = run.solver.ctl
-    out = dict(iterations=acc, seconds=dt, it_per_s=acc / dt, trial_kernel_ms=ms, trial_launches=cnt,
-               lr_final=ctl.lr, total_trials=int(ctl.total_trials))
+    out = dict(iterations=acc, seconds=dt, it_per_s=acc / dt, trial_kernel_ms=ms, passes=cnt, chain=S,
+               tiles_per_wg=getattr(run.solver, "tiles_per_wg", None),
+               lr_final=ctl.lr, trials=int(ctl.total_trials) - trials0, status=int(ctl.status))
     run.solver.close()
     return out
 
@@ -110,7 +115,9 @@ def main():
         c = torch.randn(n, dtype=torch.float64, device="cuda", generator=gen)
         r = run_native(DiagQuadL1(d, c, 0.1), torch.zeros(n, dtype=torch.float64, device="cuda"),
                        _opts(lr=0.45, max_iter=a.steps + a.warmup), a.steps, a.warmup)
-        r.update(workload="cfg2 P-diag n=1e7", achieved_GBps_trial_kernel=40.0 * n / r["trial_kernel_ms"] / 1e6)
+        r.update(workload="cfg2 P-diag n=1e7",
+                 algorithmic_GBps_trial_kernel=40.0 * n * r["iterations"] / r["passes"] / r["trial_kernel_ms"] / 1e6,
+                 hbm_GBps_trial_kernel=(48.0 if r["chain"] > 1 else 40.0) * n / r["trial_kernel_ms"] / 1e6)
     elif a.cfg == 3:
         r = lasso(16384, 65536, 3, a.steps, a.warmup)
     elif a.cfg == 4:
