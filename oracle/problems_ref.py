@@ -8,6 +8,11 @@ Restated from the reference (file:line relative to /root/reference):
 * ``Problem.prox_wsum_g``  zfista/problems.py:119-138   (composed soft-thresholds, box clip)
 * ``JOS1.f / jac_f``       zfista/problems.py:193-205
 * ``FDS.f / jac_f``        zfista/problems.py:309-328
+* ``SD``, ``ZDT1``, ``TOI4``, ``TRIDIA``, ``LinearFunctionRank1`` ``f / jac_f``
+                           zfista/problems.py:247-264, 368-386, 430-448, 494-514, 558-575
+                           (SD pinned by tests/test_problems.py:45-74; the other four have no
+                           known answers in the reference: parity unpinned, restated from the source
+                           expressions and cross-checked by finite differences)
 * test-LASSO closures      tests/test_proximal_gradient.py:49-61,81-97
 
 Third-party arithmetic not under /root/reference: jaxopt (unpinned,
@@ -132,6 +137,92 @@ class FDSRef(ProblemRef):
 # --------------------------------------------------------------------------
 # Single-objective operator families (benchmark configurations)
 # --------------------------------------------------------------------------
+class SDRef(ProblemRef):
+    """Stadler-Dauer truss problem as the reference CODES it (zfista/problems.py:238-264):
+    f_2 ends in 2 / x_4 (the docstring says x_4) and the box is (1e-6, inf)."""
+
+    def __init__(self):
+        super().__init__(4, 2, bounds=(1e-6, np.inf))
+
+    def f(self, x):
+        r2 = np.sqrt(2)
+        return np.array([2 * x[0] + r2 * x[1] + r2 * x[2] + x[3],
+                         2 / x[0] + 2 * r2 / x[1] + 2 * r2 / x[2] + 2 / x[3]])
+
+    def jac_f(self, x):
+        r2 = np.sqrt(2)
+        return np.vstack((np.array([2, r2, r2, 1]),
+                          np.array([-2 / x[0] ** 2, -2 * r2 / x[1] ** 2, -2 * r2 / x[2] ** 2, -2 / x[3] ** 2])))
+
+
+class ZDT1Ref(ProblemRef):
+    """zfista/problems.py:365-386.  The coded gradient of f_2 has 9 (2 - sqrt(x_1/h)) / (2 (n-1)) in
+    its tail entries - the derivative (finite-difference checked in tests/test_problem_library.py);
+    the class docstring's 1 - sqrt(...) is a typo.  The restatement follows the code."""
+
+    def __init__(self, n_features=30):
+        super().__init__(n_features, 2, bounds=(1e-6, np.inf))
+
+    def _h(self, x):
+        return 1 + 9 / (self.n_features - 1) * np.sum(x[1:])
+
+    def f(self, x):
+        h = self._h(x)
+        return np.array([x[0], h * (1 - np.sqrt(x[0] / h))])
+
+    def jac_f(self, x):
+        n, h = self.n_features, self._h(x)
+        j1 = np.zeros(n)
+        j1[0] = 1
+        j2 = np.full(n, 9 * (2 - np.sqrt(x[0] / h)) / 2 / (n - 1))
+        j2[0] = -np.sqrt(h / x[0]) / 2
+        return np.vstack((j1, j2))
+
+
+class TOI4Ref(ProblemRef):
+    """zfista/problems.py:415-448."""
+
+    def __init__(self, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(4, 2, l1_ratios, l1_shifts, bounds)
+
+    def f(self, x):
+        return np.array([x[0] ** 2 + x[1] ** 2 + 1, 0.5 * ((x[0] - x[1]) ** 2 + (x[2] - x[3]) ** 2) + 1])
+
+    def jac_f(self, x):
+        a, b = x[0] - x[1], x[2] - x[3]
+        return np.array([[2 * x[0], 2 * x[1], 0.0, 0.0], [a, -a, b, -b]])
+
+
+class TRIDIARef(ProblemRef):
+    """zfista/problems.py:479-514."""
+
+    def __init__(self, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(3, 3, l1_ratios, l1_shifts, bounds)
+
+    def f(self, x):
+        return np.array([(2 * x[0] - 1) ** 2, 2 * (2 * x[0] - x[1]) ** 2, 3 * (2 * x[1] - x[2]) ** 2])
+
+    def jac_f(self, x):
+        return np.array([[8 * x[0] - 4, 0, 0],
+                         [16 * x[0] - 8 * x[1], 4 * x[1] - 8 * x[0], 0],
+                         [0, 24 * x[1] - 12 * x[2], 6 * x[2] - 12 * x[1]]], dtype=np.float64)
+
+
+class LinearFunctionRank1Ref(ProblemRef):
+    """zfista/problems.py:540-575: f_i = (i <j, x> - 1)^2 with j = 1..n."""
+
+    def __init__(self, n_features=10, n_objectives=4, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(n_features, n_objectives, l1_ratios, l1_shifts, bounds)
+        self.i = np.arange(1, n_objectives + 1)
+        self.j = np.arange(1, n_features + 1)
+
+    def f(self, x):
+        return (self.i * np.inner(self.j, x) - 1) ** 2
+
+    def jac_f(self, x):
+        return 2 * self.i[:, None] * self.j * (self.i[:, None] * np.inner(self.j, x) - 1)
+
+
 class DiagQuadL1Ref:
     """f(x) = 1/2 sum d_i (x_i - c_i)^2,  g(x) = lam ||x||_1   (P-diag)."""
 

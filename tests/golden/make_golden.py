@@ -201,6 +201,31 @@ def g4_multi():
     save("g4_multiobjective.npz", **out)
 
 
+def g7_library():
+    """The reference SOLVER (imported) on the remaining problem families of zfista/problems.py,
+    whose callbacks are the oracle's restatements (zfista.problems itself needs jax)."""
+    out = {}
+    rng = np.random.default_rng(11)
+    cases = {
+        "sd": (P.SDRef(), rng.uniform(1.5, 2.5, 4), dict(lr=0.5)),
+        "zdt1_n30": (P.ZDT1Ref(30), rng.uniform(0.2, 0.8, 30), dict(lr=0.1)),
+        "toi4": (P.TOI4Ref(), rng.uniform(-2, 2, 4), dict(lr=0.5)),
+        "toi4_l1": (P.TOI4Ref(l1_ratios=[0.1, 0.2], l1_shifts=[0.0, 0.5]), rng.uniform(-2, 2, 4), dict(lr=0.5)),
+        "tridia": (P.TRIDIARef(), rng.uniform(-1, 1, 3), dict(lr=0.05)),
+        "tridia_l1_box": (P.TRIDIARef(l1_ratios=[0.1, 0.05, 0.02], l1_shifts=[0.0, 0.1, 0.2], bounds=(-0.5, 0.9)),
+                          rng.uniform(-0.4, 0.8, 3), dict(lr=0.05)),
+        "lfr1": (P.LinearFunctionRank1Ref(), rng.uniform(-0.1, 0.1, 10), dict(lr=1e-4)),
+    }
+    for tag, (prob, x0, kw) in cases.items():
+        out[f"{tag}.x0"] = x0
+        for nest in (False, True):
+            r, o = run_both(prob.callbacks(), x0, nesterov=nest, tol=1e-6, max_iter=15, return_all=True, **kw)
+            t = trace_arrays(r, o, keep=range(len(r.allvecs)))
+            for k, v in t.items():
+                out[f"{tag}.{'fista' if nest else 'ista'}.{k}"] = v
+    save("g7_problem_library.npz", **out)
+
+
 def g6_shapes():
     A = np.array([[-1.0], [0.0], [1.0]])
     b = np.array([-1.0, 0.0, 1.0])
@@ -257,7 +282,7 @@ def g6_shapes():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    todo = dict(g1=g1_toy, g2=g2_lasso, g3=g3_diag, g4=g4_multi, g6=g6_shapes)
+    todo = dict(g1=g1_toy, g2=g2_lasso, g3=g3_diag, g4=g4_multi, g6=g6_shapes, g7=g7_library)
     for k, fn in todo.items():
         if not only or k in only:
             fn()

@@ -316,6 +316,108 @@ class FDS(_BuiltinProblem):
         super().__init__(n_features, 3, l1_ratios, l1_shifts, bounds)
 
 
+# The remaining families of zfista/problems.py have n_features between 3 and 30: their f / jac_f
+# are a handful of scalar operations, evaluated on the host (a kernel launch would cost more than
+# the arithmetic); g, prox_wsum_g and the solver's own vector work run on the GPU like for every
+# Problem.  Each follows the reference's CODE where it differs from its docstring.
+class _HostProblem(Problem):
+    def _x(self, x):
+        self._check_len(x)
+        return np.asarray(x, dtype=np.float64)
+
+
+class SD(_HostProblem):
+    """Stadler-Dauer, n = 4, m = 2, box (1e-6, inf)   (zfista/problems.py:208-264)."""
+
+    def __init__(self):
+        super().__init__(4, 2, bounds=(1e-6, np.inf))
+
+    def f(self, x):
+        x = self._x(x)
+        r2 = np.sqrt(2)
+        return np.array([2 * x[0] + r2 * x[1] + r2 * x[2] + x[3],
+                         2 / x[0] + 2 * r2 / x[1] + 2 * r2 / x[2] + 2 / x[3]])   # :251 (2 / x_4 as coded)
+
+    def jac_f(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        r2 = np.sqrt(2)
+        return np.vstack((np.array([2, r2, r2, 1]),
+                          np.array([-2 / x[0] ** 2, -2 * r2 / x[1] ** 2, -2 * r2 / x[2] ** 2, -2 / x[3] ** 2])))
+
+
+class ZDT1(_HostProblem):
+    """Zitzler-Deb-Thiele 1, m = 2, box (1e-6, inf)   (zfista/problems.py:331-386)."""
+
+    def __init__(self, n_features=30):
+        super().__init__(n_features, 2, bounds=(1e-6, np.inf))
+
+    def f(self, x):
+        x = self._x(x)
+        h = 1 + 9 / (self.n_features - 1) * np.sum(x[1:])
+        return np.array([x[0], h * (1 - np.sqrt(x[0] / h))])
+
+    def jac_f(self, x):
+        x = self._x(x)
+        n = self.n_features
+        h = 1 + 9 / (n - 1) * np.sum(x[1:])
+        j1 = np.zeros(n)
+        j1[0] = 1
+        j2 = np.full(n, 9 * (2 - np.sqrt(x[0] / h)) / 2 / (n - 1))   # :381-383 as coded (the derivative)
+        j2[0] = -np.sqrt(h / x[0]) / 2
+        return np.vstack((j1, j2))
+
+
+class TOI4(_HostProblem):
+    """Toint 4, n = 4, m = 2   (zfista/problems.py:389-448)."""
+
+    def __init__(self, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(4, 2, l1_ratios, l1_shifts, bounds)
+
+    def f(self, x):
+        x = self._x(x)
+        return np.array([x[0] ** 2 + x[1] ** 2 + 1, 0.5 * ((x[0] - x[1]) ** 2 + (x[2] - x[3]) ** 2) + 1])
+
+    def jac_f(self, x):
+        x = self._x(x)
+        a, b = x[0] - x[1], x[2] - x[3]
+        return np.array([[2 * x[0], 2 * x[1], 0.0, 0.0], [a, -a, b, -b]])
+
+
+class TRIDIA(_HostProblem):
+    """Toint tridiagonal, n = 3, m = 3   (zfista/problems.py:451-514)."""
+
+    def __init__(self, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(3, 3, l1_ratios, l1_shifts, bounds)
+
+    def f(self, x):
+        x = self._x(x)
+        return np.array([(2 * x[0] - 1) ** 2, 2 * (2 * x[0] - x[1]) ** 2, 3 * (2 * x[1] - x[2]) ** 2])
+
+    def jac_f(self, x):
+        x = self._x(x)
+        return np.array([[8 * x[0] - 4, 0, 0],
+                         [16 * x[0] - 8 * x[1], 4 * x[1] - 8 * x[0], 0],
+                         [0, 24 * x[1] - 12 * x[2], 6 * x[2] - 12 * x[1]]], dtype=np.float64)
+
+
+class LinearFunctionRank1(_HostProblem):
+    """f_i = (i <(1..n), x> - 1)^2, i = 1..m   (zfista/problems.py:517-575)."""
+
+    def __init__(self, n_features=10, n_objectives=4, l1_ratios=None, l1_shifts=None, bounds=None):
+        super().__init__(n_features, n_objectives, l1_ratios, l1_shifts, bounds)
+        self.range_n_objectives = np.arange(1, self.n_objectives + 1)
+        self.range_n_features = np.arange(1, self.n_features + 1)
+
+    def f(self, x):
+        x = self._x(x)
+        return (self.range_n_objectives * np.inner(self.range_n_features, x) - 1) ** 2
+
+    def jac_f(self, x):
+        x = self._x(x)
+        i = self.range_n_objectives[:, None]
+        return 2 * i * self.range_n_features * (i * np.inner(self.range_n_features, x) - 1)
+
+
 def match_native_multi(f, g, jac_f, prox_wsum_g):
     """The built-in multi-objective Problem whose four bound methods these are, else None."""
     owner = getattr(f, "__self__", None)
