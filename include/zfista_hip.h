@@ -116,9 +116,10 @@ typedef struct zf_options {  /* keyword arguments of proximal_gradient.py:317-33
     int64_t max_backtrack_iter;
     int32_t nesterov;
     int32_t deprecated;
-    int32_t sub_iters;   /* S iterations per pass over the data for separable problems (temporal
-                            blocking): 0 = library default (ZF_SUB_ITERS in the environment, else 4),
-                            1..4 explicit.  Results do not depend on it.                            */
+    int32_t sub_iters;   /* S: trials one pass over the data chains in registers, for separable
+                            problems (temporal blocking): 0 = library default (ZF_SUB_ITERS in the
+                            environment, else 8), 1 / 2 / 4 / 8 explicit.  Results do not depend on it;
+                            lam >= 0, lr > 0, decay_rate > 0 are required by the fused kernels.     */
     int32_t reserved;
 } zf_options;
 
@@ -146,14 +147,17 @@ int zf_decide_host(zf_control* ctl, const double* packs, double* trace);
 
 /* ---- device-resident single-objective solver -----------------------------
  * Replaces the body of the outer loop, proximal_gradient.py:474-538, for the
- * recognised problem kinds.  One "step" = one line-search trial:
+ * recognised problem kinds.  One "step" = one pass over the data = a chain of up to sub_iters
+ * line-search trials, each assuming the one before was accepted (least squares: one trial):
  *   trial kernel  : y = x_k + beta (x_k - x_{k-1})            (:534)
  *                   x+ = prox_{lr g}(y - lr grad f(y))         (:148)
  *                   per-block partials of f(y), <grad f,x+-y>, |x+-y|^2,
  *                   g(x+), f(x+), max|x+-y|                    (:140,:150-152,:295,:510)
- *   finalize      : fixed-order reduction of the partials -> pack
- *   decide        : model value, acceptance, lr decay, termination, buffer
- *                   rotation, trace row                        (:149-155,:298-305,:525)
+ *   finalize      : fixed-order reduction of the partials -> one pack per trial
+ *   decide        : per trial, in order: model value, acceptance, lr decay, termination,
+ *                   trace row (:149-155,:298-305,:525); a chain that holds is committed
+ *                   (buffer hand-over), one that breaks after >= 1 accepted trials is
+ *                   planned again (zf_control.plan_n / cut_at / ncuts; csrc/zf_decide.h)
  */
 int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, const zf_options* opt,
                      void* stream);
@@ -164,7 +168,8 @@ int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev);
 int zf_solver_enqueue_init_commit(zf_solver* s);
 /* momentum factors beta_j for accepted-iteration indices first..first+count-1 (:531-533) */
 int zf_solver_set_beta(zf_solver* s, int64_t first, const double* beta_host, int64_t count);
-/* world == 1: enqueue `steps` complete steps (trial+finalize+decide), no host sync */
+/* world == 1: enqueue `steps` complete steps (trial+finalize+decide), no host sync; a step accepts
+ * between 0 and sub_iters iterations, so poll before the device can be ZF_RING iterations ahead */
 int zf_solver_enqueue_steps(zf_solver* s, int64_t steps);
 /* after initialisation: time the trial kernel with 1, 2, 4 interleaved tiles per workgroup on
  * this device (dry runs: no control-block or iterate is modified) and keep the fastest; the
