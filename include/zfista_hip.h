@@ -219,6 +219,13 @@ int zf_host_model_terms(const double* jac_host, const double* x_host, const doub
                         int64_t n, double out3[3]);
 int zf_host_momentum(double* y_out_host, const double* x_host, const double* x_old_host,
                      double beta, int64_t n);
+/* the same three expressions on device vectors (callbacks written against device tensors:
+ * iterates stay in HBM; zf_dev_model_terms synchronises `stream` to return its three scalars) */
+int zf_dev_grad_step(double* v_dev, const double* y_dev, const double* jac_dev, double lr, int64_t n, void* stream);
+int zf_dev_model_terms(const double* jac_dev, const double* x_dev, const double* y_dev, int64_t n,
+                       double out3_host[3], void* stream);
+int zf_dev_momentum(double* y_out_dev, const double* x_dev, const double* x_old_dev, double beta, int64_t n,
+                    void* stream);
 
 /* ---- operator evaluations at a host point ---------------------------------
  * The callback contract of proximal_gradient.py rows f / g / jac_f /

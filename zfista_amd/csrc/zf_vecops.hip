@@ -171,6 +171,45 @@ extern "C" int zf_host_momentum(double* y_out_host, const double* x_host, const 
     return ZF_OK;
 }
 
+// ---- the same three expressions on DEVICE vectors (tensor callbacks: x0 and every callback
+// result live in HBM; nothing but three scalars crosses PCIe per trial) ---------------------
+extern "C" int zf_dev_grad_step(double* v_dev, const double* y_dev, const double* jac_dev, double lr, int64_t n,
+                                void* stream) {
+    ZF_REQUIRE(v_dev && y_dev && jac_dev && n >= 0, "zf_dev_grad_step: bad argument");
+    if (n == 0) return ZF_OK;
+    hipLaunchKernelGGL(k_grad_step, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, (hipStream_t)stream, v_dev, y_dev,
+                       jac_dev, lr, n);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+extern "C" int zf_dev_model_terms(const double* jac_dev, const double* x_dev, const double* y_dev, int64_t n,
+                                  double out3_host[3], void* stream) {
+    ZF_REQUIRE(jac_dev && x_dev && y_dev && out3_host && n >= 0, "zf_dev_model_terms: bad argument");
+    out3_host[0] = out3_host[1] = out3_host[2] = 0.0;
+    if (n == 0) return ZF_OK;
+    int rc = zf_ws_reserve(1);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = zf_grid_for(n);
+    hipLaunchKernelGGL(k_model_terms, dim3(g), dim3(ZF_BLOCK), 0, st, jac_dev, x_dev, y_dev, n, g_ws.partials);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, g_ws.partials, g, 3, 2, g_ws.out);
+    ZF_HIP(hipGetLastError());
+    ZF_HIP(hipMemcpyAsync(out3_host, g_ws.out, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+    ZF_HIP(hipStreamSynchronize(st));
+    return ZF_OK;
+}
+
+extern "C" int zf_dev_momentum(double* y_out_dev, const double* x_dev, const double* x_old_dev, double beta,
+                               int64_t n, void* stream) {
+    ZF_REQUIRE(y_out_dev && x_dev && x_old_dev && n >= 0, "zf_dev_momentum: bad argument");
+    if (n == 0) return ZF_OK;
+    hipLaunchKernelGGL(k_momentum, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, (hipStream_t)stream, y_out_dev, x_dev,
+                       x_old_dev, beta, n);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
 extern "C" int zf_eval_diag_l1(const double* x_dev, const double* d_dev, const double* c_dev, double lam,
                                int64_t n, double out2_host[2], void* stream) {
     ZF_REQUIRE(x_dev && d_dev && c_dev && out2_host && n >= 1, "zf_eval_diag_l1: bad argument");

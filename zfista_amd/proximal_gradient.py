@@ -12,6 +12,10 @@ Two execution paths, both on the GPU (there is no host fallback):
              them (host), the solver's own vector arithmetic (:148, :150-152,
              :510, :534, and the dual terms :162-173) runs in HIP kernels through
              ``zf_host_*``.
+* tensor   - ``x0`` is a float64 CUDA tensor and the callbacks are written against
+             device tensors (e.g. PyTorch on ROCm): iterates never leave HBM, the
+             solver's vector arithmetic runs through ``zf_dev_*`` on the caller's
+             stream, three scalars per trial cross PCIe (single objective).
 """
 from __future__ import annotations
 
@@ -76,6 +80,8 @@ def minimize_proximal_gradient(
     native_multi = match_native_multi(f, g, jac_f, prox_wsum_g)
     if native is not None:
         res, status = _solve_native(native, x0, opts)
+    elif _is_device_tensor(x0) and native_multi is None:
+        res, status = _solve_tensor(f, g, jac_f, prox_wsum_g, x0, opts)
     elif native_multi is not None:
         from . import multiobjective
 
@@ -264,6 +270,143 @@ class _VecOps:
         _lib.check(self.lib.zf_host_momentum(C.c_void_p(_lib.ptr(out)), C.c_void_p(_lib.ptr(x)),
                                              C.c_void_p(_lib.ptr(x_old)), float(beta), x.size))
         return out
+
+
+def _is_device_tensor(x):
+    return type(x).__module__.split(".")[0] == "torch" and getattr(x, "is_cuda", False)
+
+
+class _DevOps:
+    """The solver's vector expressions on device tensors (zf_dev_*), on torch's current stream."""
+
+    def __init__(self):
+        import torch
+
+        self.torch = torch
+        self.lib = _lib.require_gpu()
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def _v(self, t):
+        t = t.reshape(-1)
+        if t.dtype != self.torch.float64 or not t.is_cuda:
+            raise TypeError("tensor callbacks must return float64 CUDA tensors")
+        return t.contiguous()
+
+    def grad_step(self, y, jac, lr):   # :148
+        y, jac = self._v(y), self._v(jac)
+        out = self.torch.empty_like(y)
+        _lib.check(self.lib.zf_dev_grad_step(C.c_void_p(out.data_ptr()), C.c_void_p(y.data_ptr()),
+                                             C.c_void_p(jac.data_ptr()), float(lr), y.numel(), self._stream()))
+        return out
+
+    def model_terms(self, jac, x, y):   # :150-152, :510
+        jac, x, y = self._v(jac), self._v(x), self._v(y)
+        out = np.zeros(3)
+        _lib.check(self.lib.zf_dev_model_terms(C.c_void_p(jac.data_ptr()), C.c_void_p(x.data_ptr()),
+                                               C.c_void_p(y.data_ptr()), x.numel(), C.c_void_p(_lib.ptr(out)),
+                                               self._stream()))
+        return np.float64(out[0]), np.float64(out[1]), np.float64(out[2])
+
+    def momentum(self, x, x_old, beta):   # :534
+        x, x_old = self._v(x), self._v(x_old)
+        out = self.torch.empty_like(x)
+        _lib.check(self.lib.zf_dev_momentum(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(x_old.data_ptr()), float(beta), x.numel(), self._stream()))
+        return out
+
+
+def _scalar(v):
+    """A callback's objective value as a NumPy float (0-dim / 1-element tensors allowed)."""
+    if hasattr(v, "numel"):
+        if v.numel() != 1:
+            raise NotImplementedError("tensor callbacks support one objective; use NumPy callbacks for m > 1")
+        return np.float64(v.item())
+    return np.float64(v)
+
+
+def _solve_tensor(f, g, jac_f, prox, x0, o):
+    """The loop of proximal_gradient.py:463-554 for callbacks on device tensors (m = 1).
+
+    Call structure: f(y) and jac_f(y) are evaluated once per line search (y is fixed while lr
+    shrinks) and F(x_k) is the value obtained when x_k was accepted - the reference re-evaluates
+    both per trial (:140-142, :279), which returns the same numbers for deterministic callbacks."""
+    import torch
+
+    ops = _DevOps()
+    t0 = time.time()
+    if x0.dtype != torch.float64:
+        raise TypeError("x0 must be a float64 tensor (the reference is float64 throughout)")
+    res = OptimizeResult(x0=x0, tol=o["tol"], tol_internal=o["tol_internal"],
+                         nesterov=o["nesterov"], nesterov_ratio=o["nesterov_ratio"])
+    if o["verbose"]:
+        _print_header()
+    x_old = x_cur = y = x0
+    f_old = _scalar(f(x0))
+    F_old = f_old + _scalar(g(x0))
+    lr = o["lr"]
+    allvecs = allfuns = allerrs = None
+    if o["return_all"]:
+        allvecs, allfuns, allerrs = [x0], [F_old], []
+    t_state = None
+    status = _lib.ZF_MAXITER
+    nit = 0
+    for nit in range(1, o["max_iter"] + 1):
+        try:
+            f_y = f_old if y is x_old else _scalar(f(y))   # :140
+            jac = jac_f(y)                                  # :142
+            accepted = False
+            for _ in range(o["max_backtrack_iter"]):
+                x_cur = prox(lr, ops.grad_step(y, jac, lr))                  # :148
+                dot, ss, err = ops.model_terms(jac, x_cur, y)                # :150-152, :510
+                g_new = _scalar(g(x_cur))
+                fun = np.float64(dot + g_new + np.sqrt(ss) ** 2 / 2 / lr)   # :149-152
+                if not o["deprecated"]:
+                    fun = fun + (f_y - F_old)                                # :155
+                f_new = _scalar(f(x_cur))
+                F_new = f_new + g_new                                        # :295
+                if o["decay_rate"] == 1:
+                    accepted = True
+                elif o["deprecated"]:
+                    accepted = bool(f_new - f_y <= fun + o["tol_internal"])
+                else:
+                    accepted = bool(F_new - F_old <= fun + o["tol_internal"])
+                if accepted:
+                    break
+                lr *= o["decay_rate"]
+            if not accepted:
+                raise RuntimeError(_MSG_BACKTRACK)
+        except Exception as exc:   # :493-509
+            print(f"An error occurred: {exc}")
+            bad = OptimizeResult()
+            bad.update(success=False, message=f"Error: {str(exc)}", x=x_old, fun=F_old,
+                       nit=nit - 1, time=time.time() - t0,
+                       allvecs=allvecs, allfuns=allfuns, allerrs=allerrs)
+            return bad, _lib.ZF_BACKTRACK_FAILED
+        if o["verbose"]:
+            _print_row(nit, 1, err, fun, lr)
+        if o["return_all"]:
+            allvecs.append(x_cur)
+            allfuns.append(F_new)
+            allerrs.append(err)
+        if err < o["tol"]:   # :525
+            res.status, res.message, res.success = 1, _MSG_OK, True
+            status = _lib.ZF_CONVERGED
+            F_old, f_old = F_new, f_new
+            break
+        if o["nesterov"]:
+            beta, t_state = momentum_factors(1, o["nesterov_ratio"], t_state)
+            y = ops.momentum(x_cur, x_old, beta[0])
+        else:
+            y = x_cur
+        x_old = x_cur
+        F_old, f_old = F_new, f_new
+    if status == _lib.ZF_MAXITER:
+        res.status, res.message, res.success = 0, _MSG_MAXITER, False
+    res.update(x=x_cur, fun=F_old, nit=nit, allvecs=allvecs, allfuns=allfuns, allerrs=allerrs,
+               time=time.time() - t0)
+    return res, status
 
 
 def _objectives(value):
