@@ -61,7 +61,7 @@ def measured_traffic(n, sub_iters):
     return prof["hbm_bytes_per_launch"]
 
 
-def cpu_baseline(d, c, sample_n=10**7, iters=5):
+def cpu_baseline(d, c, sample_n=10**7, iters=30):
     """The oracle (NumPy restatement of the reference path) on the host cores,
     on a bounded sample of the same workload.  Reported, never a target."""
     from oracle import cpu_ref, problems_ref as P

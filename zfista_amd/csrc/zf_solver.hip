@@ -6,7 +6,10 @@
 // each) back to back on one HIP stream; acceptance, lr decay, termination and
 // buffer rotation happen in a one-workgroup decide kernel, so there is no host
 // round trip inside a chunk of steps.
+#include <map>
+#include <mutex>
 #include <new>
+#include <tuple>
 #include <vector>
 
 #include "zf_common.h"
@@ -659,6 +662,24 @@ extern "C" int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles) {
         zf_set_tiles(s, atoi(env));
     } else if (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->ntiles >= 4096) {
         // (below ~64 MB per stream the launch is latency-, not bandwidth-bound: keep T = 1)
+        // One measurement per process, device, kernel variant and size class: later solvers of
+        // the same shape reuse it (the probe costs ~30 launches).
+        static std::mutex mu;
+        static std::map<std::tuple<int, int, int, int, int>, int> cache;
+        int dev = 0;
+        ZF_HIP(hipGetDevice(&dev));
+        int size_class = 0;
+        for (int64_t t = s->ntiles; t > 1; t >>= 1) ++size_class;
+        const auto key = std::make_tuple(dev, s->sub, (int)(s->opt.nesterov != 0), (int)s->box, size_class);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            auto hit = cache.find(key);
+            if (hit != cache.end()) {
+                zf_set_tiles(s, hit->second);
+                if (chosen_tiles) *chosen_tiles = s->tiles;
+                return ZF_OK;
+            }
+        }
         const int cand[4] = {1, 2, 4, 8};
         const int ncand = s->sub >= 8 ? 4 : 3;   // long chains amortise the per-workgroup reduction
         double best = 1e300;
@@ -692,6 +713,8 @@ extern "C" int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles) {
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         zf_set_tiles(s, best_t);
+        std::lock_guard<std::mutex> lock(mu);
+        cache[key] = best_t;
     }
     if (chosen_tiles) *chosen_tiles = s->tiles;
     return ZF_OK;
