@@ -87,6 +87,9 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
 // single-workgroup finalize with dependent load rounds 0.849 / 0.098 ms.
 // ---------------------------------------------------------------------------
 constexpr int ZF_TILE_U = 4;
+#ifndef ZF_X_NT
+#define ZF_X_NT 1   // nontemporal loads of x_k, x_{k-1} in chained passes: read once per pass (tools/tune_trial.hip: -1 %)
+#endif
 #ifndef ZF_S8_UB
 #define ZF_S8_UB 4   // units per load batch of the 8-trial chain (tools/tune_trial.hip: 4 is 3 % faster than 2)
 #endif
@@ -361,9 +364,9 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 const int64_t i = base + (u0 + u) * ZF_BLOCK;
-                a[u] = xk2[i];
+                a[u] = zf_ld2<NT && (ZF_X_NT != 0) && (S > 1)>(xk2 + i);
                 o[u] = a[u];
-                if (NESTEROV) o[u] = xo2[i];
+                if (NESTEROV) o[u] = zf_ld2<NT && (ZF_X_NT != 0) && (S > 1)>(xo2 + i);
                 q[u] = zf_ld2<NT>(p02 + i);
                 cc[u] = q[u];
                 if (GRAD_INLINE) cc[u] = zf_ld2<NT>(p12 + i);
