@@ -256,6 +256,13 @@ int zf_ls_eval(const double* A_dev, const double* b_dev, int64_t m_rows, int64_t
 typedef struct zf_mo zf_mo;
 int zf_mo_create(zf_mo** out, int32_t kind, int32_t m, int64_t n, const double* l1_ratios_host,
                  const double* l1_shifts_host, double box_lo, double box_hi, void* stream);
+/* x sharded over ranks in contiguous blocks: this engine holds [offset, offset+n)
+ * of n_global features.  `fn` is called synchronously inside every call that reduces (eval_F,
+ * prepare, dual_eval, recover, post_terms) with this rank's raw totals and must replace them by
+ * the combination over all ranks - sums added in rank order, entry max_index (>= 0) a maximum -
+ * so that every rank continues with identical scalars; returns nonzero on failure. */
+typedef int (*zf_mo_exchange_fn)(void* ctx, double* vals, int32_t count, int32_t max_index);
+int zf_mo_set_shard(zf_mo* s, int64_t n_global, int64_t offset, zf_mo_exchange_fn fn, void* ctx);
 int zf_mo_destroy(zf_mo* s);
 int zf_mo_set_x0(zf_mo* s, const double* x0_host);              /* :463-465 */
 /* point selector `which`: 0 = x_k, 1 = y, 2 = x+ (trial point), 3 = x_{k-1} */

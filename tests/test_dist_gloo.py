@@ -136,3 +136,34 @@ def test_sharded_pdiag_world2_chained_passes(tmp_path, kw, sub):
     np.testing.assert_allclose(r[0]["rows"][:, _lib.TR_ERR], exp.allerrs, rtol=0, atol=0)
     np.testing.assert_allclose(r[0]["rows"][:, _lib.TR_F], exp.allfuns[1:], rtol=1e-12)
     assert int(r[0]["passes"]) < exp.nit   # fewer exchanges than iterations
+
+
+def _worker_totals(rank, world, port, outdir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    from zfista_amd.multiobjective import combine_totals
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    vals = np.array([0.1 * (rank + 1), 1e16 if rank == 0 else 1.0, -3.0 + rank, float(rank)])
+    got_sum = combine_totals(vals, -1, dist.group.WORLD)
+    got_max = combine_totals(vals, 2, dist.group.WORLD)
+    np.savez(os.path.join(outdir, f"t{rank}.npz"), s=got_sum, m=got_max)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multiobjective_totals_exchange_world3(tmp_path):
+    """C3: raw totals of a sharded multi-objective reduction are combined in rank order on every
+    rank (1e16 + 1 + 1 is order-sensitive: the result must be the rank-ordered one everywhere)."""
+    import torch.multiprocessing as mp
+
+    world = 3
+    mp.spawn(_worker_totals, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"t{k}.npz") for k in range(world)]
+    exp_sum = np.array([(0.1 + 0.2) + 0.30000000000000004, (1e16 + 1.0) + 1.0, (-3.0 + -2.0) + -1.0, (0.0 + 1.0) + 2.0])
+    for k in range(world):
+        assert np.array_equal(r[k]["s"], exp_sum)
+        assert np.array_equal(r[k]["m"], np.array([exp_sum[0], exp_sum[1], -1.0, exp_sum[3]]))

@@ -182,3 +182,82 @@ def test_sharded_lockstep_matches_oracle(kw, world):
     np.testing.assert_allclose(funs, exp.allfuns[1:], rtol=1e-10)
     for s in solvers:
         s.close()
+
+
+# ---------------------------------------------------------------------------
+# sharded multi-objective: one exchange of 2m+2 raw totals per dual evaluation
+# ---------------------------------------------------------------------------
+class _ThreadGroup:
+    """Stands in for a torch.distributed group: `world` Python threads of this process, one per
+    rank, exchange through a barrier.  (Engines are driven from the host, synchronously, so ranks
+    cannot be stepped in lockstep from one thread as the single-objective kernels are above.)"""
+
+    def __init__(self, rank, world, shared):
+        self.rank, self.world, self._s = rank, world, shared
+
+    def all_gather_host(self, arr):
+        s = self._s
+        s["slots"][self.rank] = arr
+        s["barrier"].wait()
+        parts = [np.array(a) for a in s["slots"]]
+        s["barrier"].wait()
+        return parts
+
+
+@pytest.mark.parametrize("case", ["jos1_l1", "fds_l1", "fds_box"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_multiobjective_threads(case, world, monkeypatch):
+    import threading
+
+    if case.startswith("fds"):
+        # m = 3: the library's own simplex solver (a dozen dual evaluations per trial); SciPy's
+        # trust-constr needs 1e3 - 1e5 of them here, each an exchange between the rank threads
+        monkeypatch.setenv("ZF_DUAL_SOLVER", "native")
+
+    from zfista_amd.problems import FDS, JOS1
+
+    # FDS: f_1 ~ sum k (x_k - k)^4 / n^2 grows like n^3; its cancellation noise reaches the dual
+    # gradient and SciPy's trust-constr path (tests/test_gpu_multiobjective.py uses n <= 100 too)
+    n = 1003 if case.startswith("jos1") else 103
+    mk = {
+        "jos1_l1": lambda g: JOS1(n, l1_ratios=np.arange(1, 3) / n, l1_shifts=[0, 1], group=g),
+        "fds_l1": lambda g: FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0, 1, 2], group=g),
+        "fds_box": lambda g: FDS(n, bounds=(-1.5, 1.8), group=g),
+    }[case]
+    kw = dict(lr=1.0 if case.startswith("jos1") else 1e-3, nesterov=True, tol=1e-9, max_iter=8)
+    x0 = np.random.default_rng(3).uniform(-1, 1, n)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = mk(None).minimize_proximal_gradient(x0, return_all=True, **kw)
+
+    shared = dict(slots=[None] * world, barrier=threading.Barrier(world))
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            prob = mk(_ThreadGroup(r, world, shared))
+            lo, hi = prob.shard_bounds()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                res = prob.minimize_proximal_gradient(x0[lo:hi], return_all=True, **kw)
+            out[r] = (res, prob._engine().n_exchanges, prob._engine().n_dual_evals)
+        except Exception as exc:   # pragma: no cover - reported below
+            errs.append(exc)
+            shared["barrier"].abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs, errs
+    res0 = out[0][0]
+    for res, n_ex, n_dual in out:
+        assert res.nit == res0.nit == full.nit and res.status == full.status
+        assert np.array_equal(np.asarray(res.allerrs), np.asarray(res0.allerrs)), "ranks must agree bit for bit"
+        assert np.array_equal(np.stack(res.allfuns), np.stack(res0.allfuns))
+        assert n_ex >= n_dual > 0            # one exchange per dual evaluation (+ f, g, recovery)
+    x = np.concatenate([o[0].x for o in out])
+    tol = 1e-7 if case.startswith("jos1") else 2e-5
+    assert np.linalg.norm(x - full.x) <= tol * max(1.0, np.linalg.norm(full.x))
+    np.testing.assert_allclose(np.stack(res0.allfuns), np.stack(full.allfuns), rtol=1e-6 if case.startswith("jos1") else 1e-4)

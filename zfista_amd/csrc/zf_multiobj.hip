@@ -144,8 +144,10 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_jos1_sums(const double* __restrict
     zf_block_reduce<2, 0, ZF_WAVES>(acc, maxs, lds, out);
     if (threadIdx.x < 2) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
 }
-__global__ __launch_bounds__(ZF_BLOCK) void k_jos1_jac(const double* __restrict__ x, double* __restrict__ J, int64_t n) {
-    const double dn = (double)n;
+// n: local length (J rows are n apart); ng: n_features of the whole problem (the 1/n factors)
+__global__ __launch_bounds__(ZF_BLOCK) void k_jos1_jac(const double* __restrict__ x, double* __restrict__ J, int64_t n,
+                                                       int64_t ng) {
+    const double dn = (double)ng;
     const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
     for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
         const double xv = x[j];
@@ -155,14 +157,17 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_jos1_jac(const double* __restrict_
 }
 
 // ---- FDS (problems.py:309-328): sums [0] i (x-i)^4, [1] x, [2] x^2, [3] i(n-i+1) e^{-x} -------------
-__global__ __launch_bounds__(ZF_BLOCK) void k_fds_sums(const double* __restrict__ x, int64_t n, double* partials) {
+// off: global index of local element 0 (x is a contiguous block of the decision vector)
+__global__ __launch_bounds__(ZF_BLOCK) void k_fds_sums(const double* __restrict__ x, int64_t n, int64_t ng, int64_t off,
+                                                       double* partials) {
     __shared__ double lds[ZF_WAVES * 4];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
     for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
         const double xv = x[j];
-        const double idx = (double)(j + 1);
-        const double conv = (double)((j + 1) * (n - j));   // one_to_n * one_to_n[::-1]
+        const int64_t gj = off + j;
+        const double idx = (double)(gj + 1);
+        const double conv = (double)((gj + 1) * (ng - gj));   // one_to_n * one_to_n[::-1]
         const double t = xv - idx, t2 = t * t;
         acc[0] += idx * (t2 * t2);
         acc[1] += xv;
@@ -176,16 +181,17 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_fds_sums(const double* __restrict_
 }
 // e_mean = exp(sum(x)/n) read from totals[1] (device), so no host round trip between the two passes
 __global__ __launch_bounds__(ZF_BLOCK) void k_fds_jac(const double* __restrict__ x, double* __restrict__ J, int64_t n,
-                                                      const double* __restrict__ totals) {
-    const double dn = (double)n;
+                                                      int64_t ng, int64_t off, const double* __restrict__ totals) {
+    const double dn = (double)ng;
     const double e_mean = exp(totals[1] / dn);
     const double c1 = 4 / (dn * dn);            // 4 / n**2
     const double den = dn * (dn + 1);           // n (n + 1)
     const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
     for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
         const double xv = x[j];
-        const double idx = (double)(j + 1);
-        const double conv = (double)((j + 1) * (n - j));
+        const int64_t gj = off + j;
+        const double idx = (double)(gj + 1);
+        const double conv = (double)((gj + 1) * (ng - gj));
         const double t = xv - idx;
         J[j] = c1 * idx * (t * t * t);                  // 4 / n**2 * idx * (x - idx)**3
         J[n + j] = e_mean / dn + 2 * xv;                // exp(sum/n)/n + 2 x
@@ -244,6 +250,11 @@ struct zf_mo {
     double* h_totals = nullptr;  // pinned host mirror of totals (DMA target, no staging copy)
     int grid = 1;
     double f_y[MO_MAX_M];
+    // x sharded over ranks (contiguous blocks): n is the local length
+    int64_t n_global = 0;      // n_features of the whole problem
+    int64_t offset = 0;        // global index of local element 0
+    zf_mo_exchange_fn exchange = nullptr;   // combines raw totals over the ranks, in place
+    void* exchange_ctx = nullptr;
 };
 
 static int mo_reduce_to_host(zf_mo* s, int nq, int max_index, double* host) {
@@ -253,6 +264,15 @@ static int mo_reduce_to_host(zf_mo* s, int nq, int max_index, double* host) {
     ZF_HIP(hipMemcpyAsync(s->h_totals, s->totals, sizeof(double) * nq, hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
     memcpy(host, s->h_totals, sizeof(double) * nq);
+    if (s->exchange) {
+        // C3: every rank contributes its raw totals; the callee adds them in rank order
+        // (max for quantity max_index), so all ranks continue with bitwise-identical scalars
+        if (s->exchange(s->exchange_ctx, host, nq, max_index) != 0)
+            return zf_fail(ZF_ERR_STATE, "zf_mo: the exchange callback failed");
+        // kernels that read the totals on the device (FDS: sum x) need the global values too
+        memcpy(s->h_totals, host, sizeof(double) * nq);
+        ZF_HIP(hipMemcpyAsync(s->totals, s->h_totals, sizeof(double) * nq, hipMemcpyHostToDevice, s->stream));
+    }
     return ZF_OK;
 }
 
@@ -288,6 +308,7 @@ extern "C" int zf_mo_create(zf_mo** out, int32_t kind, int32_t m, int64_t n, con
     s->kind = kind;
     s->m = m;
     s->n = n;
+    s->n_global = n;
     s->stream = (hipStream_t)stream;
     memset(&s->G, 0, sizeof(s->G));
     s->G.m = m;
@@ -319,6 +340,20 @@ extern "C" int zf_mo_create(zf_mo** out, int32_t kind, int32_t m, int64_t n, con
     return ZF_OK;
 }
 
+// x is one contiguous block [offset, offset + n) of a decision vector of n_global entries that is
+// split over ranks.  `fn(ctx, vals, count, max_index)` is called once per reduction with this
+// rank's raw totals and must replace them by the combination over all ranks (sums added in
+// rank order; entry max_index, if >= 0, is a maximum); nonzero return = failure.
+extern "C" int zf_mo_set_shard(zf_mo* s, int64_t n_global, int64_t offset, zf_mo_exchange_fn fn, void* ctx) {
+    ZF_REQUIRE(s && fn, "zf_mo_set_shard: null argument");
+    ZF_REQUIRE(offset >= 0 && offset + s->n <= n_global, "zf_mo_set_shard: block outside the vector");
+    s->n_global = n_global;
+    s->offset = offset;
+    s->exchange = fn;
+    s->exchange_ctx = ctx;
+    return ZF_OK;
+}
+
 extern "C" int zf_mo_destroy(zf_mo* s) {
     if (!s) return ZF_OK;
     (void)hipStreamSynchronize(s->stream);
@@ -343,7 +378,7 @@ extern "C" int zf_mo_set_x0(zf_mo* s, const double* x0_host) {
 }
 
 static int mo_builtin_f(zf_mo* s, const double* x, double* f_out) {
-    const double dn = (double)s->n;
+    const double dn = (double)s->n_global;
     double t[4];
     if (s->kind == ZF_MO_JOS1) {
         hipLaunchKernelGGL(k_jos1_sums, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->n, s->partials);
@@ -355,7 +390,8 @@ static int mo_builtin_f(zf_mo* s, const double* x, double* f_out) {
         return ZF_OK;
     }
     if (s->kind == ZF_MO_FDS) {
-        hipLaunchKernelGGL(k_fds_sums, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->n, s->partials);
+        hipLaunchKernelGGL(k_fds_sums, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->n, s->n_global, s->offset,
+                           s->partials);
         int rc = mo_reduce_to_host(s, 4, -1, t);
         if (rc) return rc;
         const double nx = sqrt(t[2]);
@@ -400,9 +436,10 @@ extern "C" int zf_mo_prepare(zf_mo* s, double* f_y_out) {
     int rc = mo_builtin_f(s, s->y, f_y_out);   // leaves the raw sums in s->totals (FDS needs sum x)
     if (rc) return rc;
     if (s->kind == ZF_MO_JOS1)
-        hipLaunchKernelGGL(k_jos1_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n);
+        hipLaunchKernelGGL(k_jos1_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n, s->n_global);
     else
-        hipLaunchKernelGGL(k_fds_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n, s->totals);
+        hipLaunchKernelGGL(k_fds_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n, s->n_global,
+                           s->offset, s->totals);
     ZF_HIP(hipGetLastError());
     return ZF_OK;
 }

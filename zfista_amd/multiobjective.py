@@ -23,12 +23,47 @@ from .engine import momentum_factors
 X_K, Y, X_NEW, X_OLD = 0, 1, 2, 3
 
 
-class MoEngine:
-    """ctypes wrapper of one ``zf_mo`` object."""
+def combine_totals(vals, max_index, group):
+    """C3: the one exchange of a sharded multi-objective reduction.  Every rank's raw
+    totals are all-gathered and combined in RANK ORDER (sums added rank 0, 1, ...; entry
+    ``max_index`` a maximum), so all ranks continue with bitwise-identical scalars and the host
+    dual solver takes identical steps everywhere.  ``group``: a ``torch.distributed`` process
+    group (gloo: CPU tensors; nccl = RCCL: device tensors) or any object with
+    ``all_gather_host(np.ndarray) -> [np.ndarray per rank]`` (tests)."""
+    vals = np.asarray(vals, dtype=np.float64)
+    if hasattr(group, "all_gather_host"):
+        parts = group.all_gather_host(vals.copy())
+    else:
+        import torch
+        import torch.distributed as dist
 
-    def __init__(self, kind, m, n, l1_ratios=None, l1_shifts=None, bounds=None):
+        world = dist.get_world_size(group)
+        on_gpu = dist.get_backend(group) == "nccl"
+        mine = torch.from_numpy(vals.copy())
+        if on_gpu:
+            mine = mine.cuda()
+        out = torch.empty(world * vals.size, dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(out, mine, group=group)
+        parts = list(out.cpu().numpy().reshape(world, vals.size))
+    total = np.array(parts[0], dtype=np.float64)
+    for p in parts[1:]:
+        for k in range(total.size):
+            total[k] = max(total[k], p[k]) if k == max_index else total[k] + p[k]
+    return total
+
+
+_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32)
+
+
+class MoEngine:
+    """ctypes wrapper of one ``zf_mo`` object.  ``group`` / ``n_global`` / ``offset``: x is this
+    rank's contiguous block of a decision vector sharded over the ranks of ``group``."""
+
+    def __init__(self, kind, m, n, l1_ratios=None, l1_shifts=None, bounds=None, group=None, n_global=None,
+                 offset=0):
         self.lib = _lib.require_gpu()
         self.kind, self.m, self.n = kind, int(m), int(n)
+        self.group = group
         ratios = None if l1_ratios is None else np.ascontiguousarray(l1_ratios, dtype=np.float64)
         shifts = np.zeros(m) if l1_shifts is None else np.ascontiguousarray(l1_shifts, dtype=np.float64)
         if ratios is not None and ratios.size != m:
@@ -49,6 +84,21 @@ class MoEngine:
             C.c_void_p(_lib.ptr(shifts)), lo, hi, C.c_void_p(stream)), "zf_mo_create")
         self.h = h
         self.n_dual_evals = 0
+        self.n_exchanges = 0
+        self._cb = None
+        if group is not None:
+            def exchange(_ctx, vals, count, max_index):
+                try:
+                    arr = np.ctypeslib.as_array(vals, shape=(count,))
+                    arr[:] = combine_totals(arr, int(max_index), group)
+                    self.n_exchanges += 1
+                    return 0
+                except Exception as exc:   # never let an exception cross the C boundary
+                    self._exchange_error = exc
+                    return 1
+
+            self._cb = _EXCHANGE_FN(exchange)   # keep alive as long as the engine
+            _lib.check(self.lib.zf_mo_set_shard(h, int(n_global), int(offset), self._cb, None), "zf_mo_set_shard")
 
     def _vec(self, a):
         a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))

@@ -223,7 +223,10 @@ class Problem:
 
     _kind = _lib.ZF_MO_GENERIC
 
-    def __init__(self, n_features, n_objectives, l1_ratios=None, l1_shifts=None, bounds=None):
+    def __init__(self, n_features, n_objectives, l1_ratios=None, l1_shifts=None, bounds=None, group=None):
+        # group (torch.distributed): the decision vector is split over its ranks in contiguous
+        # blocks; n_features stays the length of the WHOLE vector, x0 / res.x are this rank's block
+        self.group = group
         self.n_features = int(n_features)
         self.n_objectives = int(n_objectives)
         self.l1_ratios = None if l1_ratios is None else np.array(l1_ratios, dtype=np.float64)
@@ -247,12 +250,26 @@ class Problem:
         from .multiobjective import MoEngine
 
         if self._eng is None or self._eng.h is None:
-            self._eng = MoEngine(self._kind, self.n_objectives, self.n_features, self.l1_ratios,
-                                 self.l1_shifts, self.bounds)
+            lo, hi = self.shard_bounds()
+            self._eng = MoEngine(self._kind, self.n_objectives, hi - lo, self.l1_ratios,
+                                 self.l1_shifts, self.bounds, group=self.group, n_global=self.n_features, offset=lo)
         return self._eng
 
+    def shard_bounds(self):
+        """[lo, hi): this rank's block of the decision vector (the whole vector without a group)."""
+        if self.group is None:
+            return 0, self.n_features
+        if hasattr(self.group, "all_gather_host"):   # in-process stand-in (tests)
+            rank, world = self.group.rank, self.group.world
+        else:
+            import torch.distributed as dist
+
+            rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        return rank * self.n_features // world, (rank + 1) * self.n_features // world
+
     def _check_len(self, x):
-        if self.n_features != len(x):
+        lo, hi = self.shard_bounds()
+        if hi - lo != len(x):
             raise ValueError(f"len(x) should be equal to n_features, got {x}.")   # problems.py:102-103
 
     def g(self, x):
@@ -303,8 +320,8 @@ class JOS1(_BuiltinProblem):
 
     _kind = _lib.ZF_MO_JOS1
 
-    def __init__(self, n_features=5, l1_ratios=None, l1_shifts=None, bounds=None):
-        super().__init__(n_features, 2, l1_ratios, l1_shifts, bounds)
+    def __init__(self, n_features=5, l1_ratios=None, l1_shifts=None, bounds=None, group=None):
+        super().__init__(n_features, 2, l1_ratios, l1_shifts, bounds, group=group)
 
 
 class FDS(_BuiltinProblem):
@@ -312,8 +329,8 @@ class FDS(_BuiltinProblem):
 
     _kind = _lib.ZF_MO_FDS
 
-    def __init__(self, n_features=10, l1_ratios=None, l1_shifts=None, bounds=None):
-        super().__init__(n_features, 3, l1_ratios, l1_shifts, bounds)
+    def __init__(self, n_features=10, l1_ratios=None, l1_shifts=None, bounds=None, group=None):
+        super().__init__(n_features, 3, l1_ratios, l1_shifts, bounds, group=group)
 
 
 # The remaining families of zfista/problems.py have n_features between 3 and 30: their f / jac_f
