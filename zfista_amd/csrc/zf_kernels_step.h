@@ -75,11 +75,11 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
 //   * all 16 loads of a thread are issued before the first use;
 //   * d, c are read once per trial and x+ is written once: nontemporal (nt)
 //     loads / stores keep them from displacing x_k in the caches (+8 %).
-// Reduction: every workgroup stores its six partials with plain stores and retires
-// (no per-workgroup hand-off); a second, tiny launch - zf_finalize_kernel, ZF_FIN_WGS
-// workgroups of 1024 threads, every load independent - adds them in index order, its
+// Reduction: every workgroup stores its 6 S partials with plain stores and retires
+// (no per-workgroup hand-off); a second, tiny launch - zf_finalize_kernel, up to ZF_FIN_WGS
+// workgroups of 256 threads, every load independent - adds them in index order, its
 // last-arriving workgroup (one ticket per finalize workgroup, guide Guideline 16 R1
-// counter form) builds the scalar pack and runs the decide step.  Measured per step in
+// counter form) builds the scalar packs and runs the decide pass.  Measured per step (S = 1) in
 // loops of 20 launches (tools/tune_trial.hip, one box): streaming + finalize 0.675 ms
 // (n = 1e8) / 0.069 ms (1e7); a fused single launch with per-workgroup tickets and a
 // two-level in-launch reduction 0.686 / 0.078 ms at one tile per workgroup, and
@@ -149,7 +149,7 @@ struct zf_finalize_args {
 
 // Second launch of a step.  The trial kernel left S x 6 partial rows per workgroup (S = trials
 // of the chain).  Every finalize workgroup adds its slice of them (thread t takes workgroups
-// t, t+1024, ... of the slice: index order; the loads of one index are independent), publishes
+// t, t+256, ... of the slice: index order; the loads of one index are independent), publishes
 // the slice totals write-through and takes a ticket; the last arriver's wave 0 adds the <= 48
 // slices lane-parallel in slice order, builds the S packs and (decide) runs zf_decide_pass:
 // model value, acceptance, lr decay, failure, termination, buffer hand-over, trace rows
