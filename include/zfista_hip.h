@@ -205,6 +205,12 @@ int zf_solver_x_dev(zf_solver* s, const double** x_dev);
 int zf_solver_get_x(zf_solver* s, double* x_host);
 /* average duration (ms) of the trial kernel over the launches since the last
  * call, measured with HIP events on the solver's stream; resets the window */
+/* checkpoint / resume: zf_solver_poll + zf_solver_get_x + zf_solver_get_x_prev are the state of a
+ * solve (x_k, x_{k-1}, control block); zf_solver_restore puts it into a freshly created solver
+ * instead of zf_solver_enqueue_init(+_commit), after which the host re-uploads the momentum
+ * factors from accepted count `nit` on.  The resumed solve continues bit for bit. */
+int zf_solver_get_x_prev(zf_solver* s, double* x_host);
+int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev, const zf_control* saved);
 int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches);
 int zf_solver_set_timing(zf_solver* s, int32_t enabled);
 

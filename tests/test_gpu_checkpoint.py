@@ -1,0 +1,101 @@
+"""GPU: checkpoint / resume of a device-resident solve.  The state is
+(x_k, x_{k-1}, control block); a solve resumed from it - in a new solver object, through a file,
+with the same or another chain length - continues bit for bit like the uninterrupted one."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(lr=1, tol=1e-5, tol_internal=1e-12, max_iter=1000000, max_iter_internal=100000, max_backtrack_iter=100,
+            warm_start=False, decay_rate=0.5, nesterov=False, nesterov_ratio=(0, 0.25), return_all=False, verbose=False,
+            deprecated=False)
+
+
+def _drain(run, chunk=3):
+    from zfista_amd import _lib
+
+    rows = [np.zeros((0, _lib.ZF_TRACE_COLS))]
+    while run.status == _lib.ZF_RUNNING:
+        rows.append(run.advance(chunk))
+    return np.concatenate(rows)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(lr=0.45, nesterov=True, tol=0.0, max_iter=61),
+    dict(lr=64.0, nesterov=True, tol=0.0, max_iter=45),          # snapshots land inside the backtracking phase
+    dict(lr=3.0, nesterov=True, nesterov_ratio=(0.5, 0.25), decay_rate=0.9, tol=1e-9, max_iter=300),
+    dict(lr=0.45, nesterov=False, tol=1e-8, max_iter=200),
+])
+@pytest.mark.parametrize("stop_after", [1, 2, 5])
+def test_resume_diag_is_bit_identical(kw, stop_after, tmp_path):
+    from oracle import problems_ref as P
+    from zfista_amd import _lib
+    from zfista_amd.problems import DiagQuadL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    n = 20011
+    d, c, lam = P.make_pdiag(n, seed=8)
+    prob = DiagQuadL1(d, c, lam)
+    x0 = np.random.default_rng(1).standard_normal(n)
+    o = BASE | kw
+    ref_run = NativeRun(prob, x0, o)
+    ref_rows = _drain(ref_run)
+    ref_x, ref_ctl = ref_run.solver.get_x(), ref_run.solver.ctl
+    ref = (int(ref_ctl.nit), int(ref_ctl.status), ref_ctl.lr, int(ref_ctl.total_trials))
+    ref_run.solver.close()
+
+    first = NativeRun(prob, x0, o)
+    head = [first.advance(1) for _ in range(stop_after)]          # passes, not iterations
+    state = first.snapshot()
+    first.solver.close()
+    np.savez(tmp_path / "ckpt.npz", **state)                       # through a file
+    state = dict(np.load(tmp_path / "ckpt.npz"))
+    for sub in (0, 1, 4):                                          # same chain length, or another
+        run = NativeRun.from_snapshot(prob, state, o | dict(sub_iters=sub))
+        rows = np.concatenate(head + [_drain(run)])
+        ctl = run.solver.ctl
+        assert (int(ctl.nit), int(ctl.status), ctl.lr, int(ctl.total_trials)) == ref, sub
+        assert np.array_equal(rows, ref_rows), sub
+        assert np.array_equal(run.solver.get_x(), ref_x), sub
+        run.solver.close()
+
+
+def test_resume_with_a_larger_max_iter_continues_a_finished_solve():
+    from oracle import problems_ref as P
+    from zfista_amd import _lib
+    from zfista_amd.problems import DiagQuadL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    n = 5003
+    d, c, lam = P.make_pdiag(n, seed=2)
+    prob = DiagQuadL1(d, c, lam)
+    o = BASE | dict(lr=0.45, nesterov=True, tol=0.0)
+    full = NativeRun(prob, np.zeros(n), o | dict(max_iter=50))
+    rows_full = _drain(full)
+    part = NativeRun(prob, np.zeros(n), o | dict(max_iter=20))
+    rows_a = _drain(part)
+    assert part.status == _lib.ZF_MAXITER
+    cont = NativeRun.from_snapshot(prob, part.snapshot(), o | dict(max_iter=50))
+    assert cont.status == _lib.ZF_RUNNING and cont.nit_seen == 20
+    rows_b = _drain(cont)
+    assert np.array_equal(np.concatenate([rows_a, rows_b]), rows_full)
+    assert np.array_equal(cont.solver.get_x(), full.solver.get_x())
+
+
+@pytest.mark.parametrize("nesterov", [False, True])
+def test_resume_least_squares_is_bit_identical(nesterov):
+    from oracle import problems_ref as P
+    from zfista_amd.problems import LeastSquaresL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    A, b, lam = P.make_plasso(96, 200, seed=4)
+    prob = LeastSquaresL1(A, b, lam)
+    o = BASE | dict(lr=1.0, nesterov=nesterov, tol=0.0, max_iter=40)
+    ref_run = NativeRun(prob, np.zeros(200), o)
+    ref_rows, ref_x = _drain(ref_run), ref_run.solver.get_x()
+    first = NativeRun(prob, np.zeros(200), o)
+    head = first.advance(17)
+    run = NativeRun.from_snapshot(prob, first.snapshot(), o)
+    rows = np.concatenate([head, _drain(run)])
+    assert np.array_equal(rows, ref_rows)
+    assert np.array_equal(run.solver.get_x(), ref_x)

@@ -103,6 +103,8 @@ SIGNATURES = {
     "zf_solver_poll": (C.c_int, [_P, C.POINTER(Control), _P]),
     "zf_solver_x_dev": (C.c_int, [_P, C.POINTER(_P)]),
     "zf_solver_get_x": (C.c_int, [_P, _P]),
+    "zf_solver_get_x_prev": (C.c_int, [_P, _P]),
+    "zf_solver_restore": (C.c_int, [_P, _P, _P, C.POINTER(Control)]),
     "zf_solver_trial_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "zf_solver_set_timing": (C.c_int, [_P, C.c_int32]),
     "zf_host_grad_step": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64]),

@@ -563,6 +563,80 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
     return ZF_OK;
 }
 
+// Resume a solve from a saved state: x_k, x_{k-1} (device, n each) and the
+// control block zf_solver_poll() returned when the state was taken.  Counters, lr, F(x_k), status
+// continue from the saved values; buffer indices and the chain geometry are this solver's; a
+// pending plan is kept when the chain length is the same and dropped otherwise (the next pass then
+// simply rediscovers what the plan recorded).  The momentum ring is NOT part of the state: the
+// host re-uploads the factors from accepted count `nit` on (zf_solver_set_beta), which also
+// resolves beta_next.  Least squares: A x_k and A x_{k-1} are recomputed by the same kernel that
+// produced them (unsharded only).
+extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev,
+                                 const zf_control* saved) {
+    ZF_REQUIRE(s && xk_dev && xprev_dev && saved, "zf_solver_restore: null argument");
+    const zf_problem_desc& d = s->desc;
+    ZF_REQUIRE(d.kind == ZF_PROBLEM_DIAG_QUAD_L1 || d.world == 1,
+               "zf_solver_restore: sharded least squares is not supported");
+    ZF_REQUIRE(saved->nit >= 0 && saved->lr > 0.0, "zf_solver_restore: implausible control block");
+    const int64_t n = d.n;
+    ZF_HIP(hipMemcpyAsync(s->xb[0], xk_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream));
+    ZF_HIP(hipMemcpyAsync(s->xb[s->ring - 1], xprev_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream));
+    zf_control c = *saved;
+    c.tol = s->opt.tol;
+    c.tol_internal = s->opt.tol_internal;
+    c.decay_rate = s->opt.decay_rate;
+    c.max_iter = s->opt.max_iter;
+    c.max_backtrack = s->opt.max_backtrack_iter;
+    c.nesterov = s->opt.nesterov;
+    c.deprecated = s->opt.deprecated;
+    c.cur = 0;
+    c.prev = s->ring - 1;
+    c.ring_size = s->ring;
+    c.world = d.world;
+    c.need_grad = 1;
+    if (saved->sub_iters != s->sub) {
+        c.plan_n = s->sub;
+        c.cut_at = -1;
+        c.ncuts = 0;
+    }
+    c.sub_iters = s->sub;
+    if (c.status == ZF_MAXITER && c.nit < c.max_iter) c.status = ZF_RUNNING;   // a larger max_iter continues (:539)
+    ZF_HIP(hipMemcpyAsync(s->ctl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));   // `c` is a stack object
+    if (d.kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
+        const int64_t m = d.m_rows;
+        const int V = (n % 2 == 0) ? 2 : 1;
+        int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
+        if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
+        const int at[2] = {0, 2};   // A x_k -> sring[cur], A x_{k-1} -> sring[(cur + 2) % 3]
+        for (int k = 0; k < 2; ++k) {
+            double* xsrc = s->xb[at[k]];
+            double* dst = s->sring.p[at[k]];
+            zf_ring3 xr = {{xsrc, xsrc, xsrc}};
+            zf_ring3 so = {{dst, dst, dst}};
+            if (V == 2)
+                hipLaunchKernelGGL(zf_gemv_rows_kernel<2>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
+                                   so, -1, m, n);
+            else
+                hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
+                                   so, -1, m, n);
+        }
+        ZF_HIP(hipGetLastError());
+    }
+    s->initialised = true;
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_get_x_prev(zf_solver* s, double* x_host) {
+    ZF_REQUIRE(s && x_host, "zf_solver_get_x_prev: null argument");
+    zf_control c;
+    ZF_HIP(hipMemcpyAsync(&c, s->ctl, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    ZF_HIP(hipMemcpyAsync(x_host, s->xb[c.prev], sizeof(double) * s->desc.n, hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    return ZF_OK;
+}
+
 // sharded least squares, second half of the initialisation: s0 = sum of the gathered parts
 extern "C" int zf_solver_enqueue_init_finish(zf_solver* s) {
     ZF_REQUIRE(s, "zf_solver_enqueue_init_finish: null solver");

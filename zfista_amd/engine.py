@@ -172,6 +172,21 @@ class DeviceSolver:
             self._gather()
             self.enqueue_decide()
 
+    def get_x_prev(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        _lib.check(self.lib.zf_solver_get_x_prev(self.handle, C.c_void_p(_lib.ptr(out))), "get_x_prev")
+        return out
+
+    def restore(self, xk_dev_ptr: int, xprev_dev_ptr: int, ctl):
+        """Instead of init(): continue from a saved (x_k, x_{k-1}, control block)."""
+        _lib.check(self.lib.zf_solver_restore(self.handle, C.c_void_p(xk_dev_ptr), C.c_void_p(xprev_dev_ptr),
+                                              C.byref(ctl)), "restore")
+        self.tiles_per_wg = 1
+        if os.environ.get("ZF_AUTOTUNE", "1") != "0":
+            t = C.c_int32(1)
+            _lib.check(self.lib.zf_solver_autotune(self.handle, C.byref(t)), "autotune")
+            self.tiles_per_wg = int(t.value)
+
     def set_max_iter(self, max_iter: int):
         _lib.check(self.lib.zf_solver_set_max_iter(self.handle, int(max_iter)), "set_max_iter")
 

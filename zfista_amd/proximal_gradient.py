@@ -100,7 +100,7 @@ class NativeRun:
     """A device-resident solve that can be advanced in chunks (used by bench.py
     to time exactly K iterations with the inputs already resident in HBM)."""
 
-    def __init__(self, problem, x0, opts, timing=False, solver_factory=None):
+    def __init__(self, problem, x0, opts, timing=False, solver_factory=None, _snapshot=None):
         self.problem = problem
         self.opts = opts
         fields, keep = problem._descriptor()
@@ -125,7 +125,12 @@ class NativeRun:
             if x0_dev.numel() != problem.n_features:
                 raise ValueError(f"len(x) should be equal to n_features, got {x0}.")
             self.solver = DeviceSolver(fields, options, keepalive=keep, group=problem.group, timing=timing)
-            self.solver.init(x0_dev.data_ptr())
+            if _snapshot is None:
+                self.solver.init(x0_dev.data_ptr())
+            else:
+                xp = torch.from_numpy(np.ascontiguousarray(_snapshot["x_prev"], dtype=np.float64)).cuda()
+                ctl = _lib.Control.from_buffer_copy(np.ascontiguousarray(_snapshot["control"]).tobytes())
+                self.solver.restore(x0_dev.data_ptr(), xp.data_ptr(), ctl)
             self._x0_dev = x0_dev
         # iterations one pass may accept (temporal blocking of separable f; csrc/zf_kernels_step.h)
         self.sub_iters = int(getattr(self.solver, "sub_iters", 1))
@@ -137,6 +142,28 @@ class NativeRun:
         ctl, _ = self.solver.poll()
         self.F0 = ctl.F_old
         self.status = ctl.status
+        if _snapshot is not None:
+            # the momentum recursion is replayed up to the saved iteration count (scalar work); the
+            # factors from there on are uploaded by the next advance()
+            self.nit_seen = int(ctl.nit)
+            if opts["nesterov"] and self.nit_seen > 0:
+                if self.nit_seen > 1:
+                    _, self._t_state = momentum_factors(self.nit_seen - 1, self.ratio, None)
+                self._beta_filled = self.nit_seen
+                self._fill_beta(self.nit_seen + 1)
+
+    def snapshot(self):
+        """The state of the solve after the last advance(): x_k, x_{k-1} and the control block
+        (host arrays; ``np.savez(path, **state)`` makes it a checkpoint file)."""
+        ctl, _ = self.solver.poll()
+        return dict(x=self.solver.get_x(), x_prev=self.solver.get_x_prev(),
+                    control=np.frombuffer(bytes(ctl), dtype=np.uint8).copy())
+
+    @classmethod
+    def from_snapshot(cls, problem, state, opts, timing=False):
+        """Continue a solve from ``snapshot()`` (possibly in another process, with another
+        max_iter or chain length).  The continuation is bit-identical to the uninterrupted solve."""
+        return cls(problem, np.asarray(state["x"]), opts, timing=timing, _snapshot=state)
 
     def _fill_beta(self, upto):
         """Upload momentum factors for accepted-iteration counts < upto."""
