@@ -110,3 +110,41 @@ def test_tensor_callbacks_error_and_warning_shapes(capsys):
         minimize_proximal_gradient(lambda x: torch.stack([f(x), f(x)]), g, jac_f, prox, x0)
     with pytest.raises(TypeError):
         minimize_proximal_gradient(f, g, jac_f, prox, x0.float())
+
+
+def test_operator_form_lasso_example_matches_numpy_callbacks():
+    """The deblurring workload of the reference's cameraman notebook (operator-form LASSO: blur and
+    Haar transform as callbacks) with tensor callbacks against the oracle driven by the same
+    operators in NumPy / SciPy (examples/deblur_operator_lasso.py)."""
+    import importlib.util
+    import os
+
+    import torch
+    from scipy.signal import correlate2d
+
+    from conftest import ROOT
+    from oracle import cpu_ref
+    from zfista_amd import minimize_proximal_gradient
+
+    spec = importlib.util.spec_from_file_location("deblur_example", os.path.join(ROOT, "examples",
+                                                                                 "deblur_operator_lasso.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    size = 64
+    kernel = ex.gaussian_kernel()
+    observed = correlate2d(ex.synthetic_image(size), kernel, mode="same", boundary="symm") \
+        + np.random.default_rng(1).standard_normal((size, size)) * 1e-3
+    cbs_np, dwt_np, idwt_np = ex.numpy_problem(kernel, observed)
+    cbs_t, dwt_t, idwt_t = ex.tensor_problem(kernel, observed)
+    x0 = dwt_np(observed)
+    assert np.allclose(idwt_np(x0), observed, atol=1e-14)                       # orthonormal Haar level
+    assert np.array_equal(dwt_t(torch.from_numpy(observed).cuda()).cpu().numpy(), x0)
+    kw = dict(lr=1 / (2 * kernel.sum() ** 2), decay_rate=1, nesterov=True, tol=0.0, max_iter=25, return_all=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize_proximal_gradient(*cbs_t, torch.from_numpy(x0).cuda(), **kw)
+        exp = cpu_ref.minimize_proximal_gradient(*cbs_np, x0, **kw)
+    assert res.nit == exp.nit == 25
+    for a, e in zip(res.allvecs, exp.allvecs):
+        assert rel_err(a.cpu().numpy(), e) <= 1e-10
+    np.testing.assert_allclose(np.asarray(res.allfuns, float).ravel(), np.asarray(exp.allfuns, float).ravel(), rtol=1e-10)
