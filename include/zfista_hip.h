@@ -230,6 +230,8 @@ int zf_host_momentum(double* y_out_host, const double* x_host, const double* x_o
 int zf_dev_grad_step(double* v_dev, const double* y_dev, const double* jac_dev, double lr, int64_t n, void* stream);
 int zf_dev_model_terms(const double* jac_dev, const double* x_dev, const double* y_dev, int64_t n,
                        double out3_host[3], void* stream);
+int zf_dev_model_terms_async(const double* jac_dev, const double* x_dev, const double* y_dev, int64_t n,
+                             double* out3_dev, void* stream);   /* no synchronisation; scalars stay on the device */
 int zf_dev_momentum(double* y_out_dev, const double* x_dev, const double* x_old_dev, double beta, int64_t n,
                     void* stream);
 

@@ -200,6 +200,21 @@ extern "C" int zf_dev_model_terms(const double* jac_dev, const double* x_dev, co
     return ZF_OK;
 }
 
+// as zf_dev_model_terms, but the three scalars stay on the device (out3_dev) and nothing is
+// synchronised: the caller fetches them together with its own scalars in one transfer
+extern "C" int zf_dev_model_terms_async(const double* jac_dev, const double* x_dev, const double* y_dev, int64_t n,
+                                        double* out3_dev, void* stream) {
+    ZF_REQUIRE(jac_dev && x_dev && y_dev && out3_dev && n >= 1, "zf_dev_model_terms_async: bad argument");
+    int rc = zf_ws_reserve(1);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = zf_grid_for(n);
+    hipLaunchKernelGGL(k_model_terms, dim3(g), dim3(ZF_BLOCK), 0, st, jac_dev, x_dev, y_dev, n, g_ws.partials);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, g_ws.partials, g, 3, 2, out3_dev);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
 extern "C" int zf_dev_momentum(double* y_out_dev, const double* x_dev, const double* x_old_dev, double beta,
                                int64_t n, void* stream) {
     ZF_REQUIRE(y_out_dev && x_dev && x_old_dev && n >= 0, "zf_dev_momentum: bad argument");

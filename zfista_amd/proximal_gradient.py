@@ -336,6 +336,15 @@ class _DevOps:
                                                self._stream()))
         return np.float64(out[0]), np.float64(out[1]), np.float64(out[2])
 
+    def model_terms_dev(self, jac, x, y):
+        """The same three scalars left on the device (a 3-vector tensor), nothing synchronised."""
+        jac, x, y = self._v(jac), self._v(x), self._v(y)
+        out = self.torch.empty(3, dtype=self.torch.float64, device=x.device)
+        _lib.check(self.lib.zf_dev_model_terms_async(C.c_void_p(jac.data_ptr()), C.c_void_p(x.data_ptr()),
+                                                     C.c_void_p(y.data_ptr()), x.numel(), C.c_void_p(out.data_ptr()),
+                                                     self._stream()))
+        return out
+
     def momentum(self, x, x_old, beta):   # :534
         x, x_old = self._v(x), self._v(x_old)
         out = self.torch.empty_like(x)
@@ -386,12 +395,19 @@ def _solve_tensor(f, g, jac_f, prox, x0, o):
             accepted = False
             for _ in range(o["max_backtrack_iter"]):
                 x_cur = prox(lr, ops.grad_step(y, jac, lr))                  # :148
-                dot, ss, err = ops.model_terms(jac, x_cur, y)                # :150-152, :510
-                g_new = _scalar(g(x_cur))
+                terms = ops.model_terms_dev(jac, x_cur, y)                   # :150-152, :510 (device)
+                g_val, f_val = g(x_cur), f(x_cur)
+                if _is_device_tensor(g_val) and _is_device_tensor(f_val) and g_val.numel() == 1 == f_val.numel():
+                    # one transfer for all five scalars of the trial
+                    five = torch.cat([terms, g_val.reshape(1).to(torch.float64),
+                                      f_val.reshape(1).to(torch.float64)]).cpu().numpy()
+                    dot, ss, err, g_new, f_new = (np.float64(v) for v in five)
+                else:
+                    dot, ss, err = (np.float64(v) for v in terms.cpu().numpy())
+                    g_new, f_new = _scalar(g_val), _scalar(f_val)
                 fun = np.float64(dot + g_new + np.sqrt(ss) ** 2 / 2 / lr)   # :149-152
                 if not o["deprecated"]:
                     fun = fun + (f_y - F_old)                                # :155
-                f_new = _scalar(f(x_cur))
                 F_new = f_new + g_new                                        # :295
                 if o["decay_rate"] == 1:
                     accepted = True
