@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=N_PER_GPU, help="elements per GPU (default 1e8)")
+    ap.add_argument("--total-n", type=int, default=0,
+                    help="strong scaling: total length of x, split evenly over the GPUs (e.g. 800000000, "
+                         "BASELINE cfg5); overrides --n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket every trial kernel with HIP events (roofline becomes null); "
@@ -128,6 +131,8 @@ def main():
     from zfista_amd.proximal_gradient import NativeRun
 
     n = args.n
+    if args.total_n:
+        n = args.total_n * (rank + 1) // world - args.total_n * rank // world   # this rank's block
     K, W = args.steps, args.warmup
     d, c = make_inputs(n, seed=1 + rank, device="cuda")
     prob = DiagQuadL1(d, c, LAM, group=group)
@@ -179,15 +184,18 @@ def main():
         achieved = alg_bytes / (ker_ms * 1e-3) / 1e9
         pass_bytes = (PASS_BYTES_PER_ELEM if S > 1 else ALG_BYTES_PER_ELEM) * n
         line = {
-            "metric": "fista_iterations_per_sec_n1e8_per_gpu_shard",
-            "value": world * K / dt * (n / N_PER_GPU),
+            "metric": f"fista_iterations_per_sec_n{args.total_n:.0e}_total" if args.total_n
+                      else "fista_iterations_per_sec_n1e8_per_gpu_shard",
+            # weak: iterations/s in units of one 1e8-element shard, summed over the GPUs;
+            # strong (--total-n): iterations/s of the one fixed-size problem
+            "value": (K / dt) if args.total_n else world * K / dt * (n / N_PER_GPU),
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
             "ms_per_step": dt / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_n else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -195,7 +203,7 @@ def main():
                 "workload": "P-diag l1-regularised diagonal quadratic, fused grad+soft-threshold+momentum, "
                             f"n={n:.0e} per GPU, FISTA (a,b)=(0,0.25), lr=0.45, lam=0.1",
                 "n_per_gpu": n,
-                "n_total": n * world,
+                "n_total": args.total_n if args.total_n else n * world,
                 "iters_per_sec_full_problem": K / dt,
                 "temporal_blocking_chain": S,
                 "passes": ker_n,
