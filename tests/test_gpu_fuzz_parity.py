@@ -10,9 +10,13 @@ import pytest
 
 from conftest import rel_err
 
+import os
+
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
+# ZF_FUZZ_SCALE=10 runs ten times as many random cases (one-off soak; the default keeps the suite short)
+SCALE = int(os.environ.get("ZF_FUZZ_SCALE", "1"))
 
 
 def _options(rng):
@@ -38,6 +42,17 @@ def _compare(prob, ref, x0, o):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, return_all=True, **o)
+        # Once F stops changing at double resolution the acceptance test (:303) compares rounding
+        # residues: its outcome then depends on the summation order, for the reference (NumPy's
+        # pairwise sums) as for any other implementation.  The sweep stays below that
+        # point: the run is cut one iteration before F first stagnates.
+        F = np.asarray(exp.allfuns, dtype=np.float64)
+        stalled = np.flatnonzero(np.abs(np.diff(F)) <= 64 * np.finfo(float).eps * np.maximum(1.0, np.abs(F[1:])))
+        if stalled.size and stalled[0] + 1 <= exp.nit:
+            if stalled[0] < 1:
+                pytest.skip("x0 is already at the resolution limit of the acceptance test")
+            o = dict(o, max_iter=int(stalled[0]))
+            exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, return_all=True, **o)
         res = minimize_proximal_gradient(*prob.callbacks(), x0, return_all=True, **o)       # S = 1
         res8 = minimize_proximal_gradient(*prob.callbacks(), x0, return_all=False, **o)     # chains
     for r in (res, res8):
@@ -49,7 +64,9 @@ def _compare(prob, ref, x0, o):
         np.testing.assert_allclose(r.fun, exp.fun, rtol=TOL, atol=0)
     assert np.array_equal(res8.x, res.x), "chained passes must not change the iterate"
     if exp.allerrs is not None and len(exp.allerrs):
-        np.testing.assert_allclose(res.allerrs, exp.allerrs, rtol=1e-9, atol=1e-300)
+        # err = max|x+ - y| is a difference of iterates that agree to 1e-10 of their size
+        np.testing.assert_allclose(res.allerrs, exp.allerrs, rtol=1e-9,
+                                   atol=TOL * max(1e-300, float(np.max(np.abs(np.stack(exp.allvecs))))))
         np.testing.assert_allclose(res.allfuns, exp.allfuns, rtol=TOL)
     # lr / trial-count sequence of the chained run (trace ring) against the oracle's
     full = dict(max_iter_internal=100000, warm_start=False, verbose=False, return_all=False) | o
@@ -65,7 +82,7 @@ def _compare(prob, ref, x0, o):
     run.solver.close()
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * SCALE))
 def test_fuzz_diag_quad_l1(seed):
     from oracle import problems_ref as P
     from zfista_amd.problems import DiagQuadL1
@@ -79,7 +96,7 @@ def test_fuzz_diag_quad_l1(seed):
     _compare(DiagQuadL1(d, c, lam), P.DiagQuadL1Ref(d, c, lam), x0, o)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_fuzz_least_squares_l1(seed):
     from oracle import problems_ref as P
     from zfista_amd.problems import LeastSquaresL1
