@@ -387,7 +387,22 @@ def solve_native(problem, x0, o):
                          nesterov=o["nesterov"], nesterov_ratio=o["nesterov_ratio"])
     if o["verbose"]:
         _print_header()
-    f0, g0 = eng.eval_F(X_K)
+    host_f = bool(getattr(problem, "_host_f", False))   # f / jac_f are host NumPy (n <= 30 families)
+
+    def eval_F(which):
+        if not host_f:
+            return eng.eval_F(which)
+        _, g_val = eng.eval_F(which, builtin_f=False)
+        return np.asarray(problem.f(eng.get(which)), dtype=np.float64), g_val
+
+    def prepare():
+        if not host_f:
+            return eng.prepare()
+        y = eng.get(Y)
+        eng.set_jac(problem.jac_f(y))
+        return np.asarray(problem.f(y), dtype=np.float64)
+
+    f0, g0 = eval_F(X_K)
     F_old = f0 + g0                     # F(x_k); cached between iterations instead of recomputed (:279)
     w0 = np.ones(m) / m
     lr = o["lr"]
@@ -399,14 +414,14 @@ def solve_native(problem, x0, o):
     nit = 0
     for nit in range(1, o["max_iter"] + 1):
         try:
-            f_y = eng.prepare()         # f(y_k), J = jac_f(y_k): once per line search (y_k is fixed)
+            f_y = prepare()             # f(y_k), J = jac_f(y_k): once per line search (y_k is fixed)
             accepted = False
             for _ in range(o["max_backtrack_iter"]):
                 dual = device_dual(eng, lr, f_y, F_old, o["deprecated"])
                 weight, dual_fun, nit_int = solve_dual(dual, m, w0, o["tol_internal"], o["max_iter_internal"])
                 err = eng.recover(lr, weight)          # x+ and max|x+ - y|   (:206, :510)
                 fun = -dual_fun                         # (:207)
-                f_x, g_x = eng.eval_F(X_NEW)
+                f_x, g_x = eval_F(X_NEW)
                 F_new = f_x + g_x                       # (:295)
                 if o["warm_start"]:
                     w0 = weight

@@ -298,6 +298,8 @@ class Problem:
 
 
 class _BuiltinProblem(Problem):
+    _host_f = False
+
     def f(self, x):
         self._check_len(x)
         eng = self._engine()
@@ -338,6 +340,10 @@ class FDS(_BuiltinProblem):
 # the arithmetic); g, prox_wsum_g and the solver's own vector work run on the GPU like for every
 # Problem.  Each follows the reference's CODE where it differs from its docstring.
 class _HostProblem(Problem):
+    # f / jac_f are host NumPy; g, prox and every O(n) expression of the dual run in the device
+    # engine (multiobjective.solve_native), one host round trip per dual evaluation
+    _host_f = True
+
     def _x(self, x):
         self._check_len(x)
         return np.asarray(x, dtype=np.float64)
@@ -438,7 +444,7 @@ class LinearFunctionRank1(_HostProblem):
 def match_native_multi(f, g, jac_f, prox_wsum_g):
     """The built-in multi-objective Problem whose four bound methods these are, else None."""
     owner = getattr(f, "__self__", None)
-    if not isinstance(owner, _BuiltinProblem):
+    if not isinstance(owner, (_BuiltinProblem, _HostProblem)):
         return None
     for cb, name in zip((f, g, jac_f, prox_wsum_g), ("f", "g", "jac_f", "prox_wsum_g")):
         if getattr(cb, "__self__", None) is not owner:
