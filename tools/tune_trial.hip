@@ -450,7 +450,11 @@ template <bool NT, int S> void run_lib_loop(const Bufs& B, int T) {
         hipLaunchKernelGGL(zf_finalize_kernel<S>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, 0, F); } }, 5);
     double ms_f = time_ms([&] { for (int k = 0; k < K; ++k)
         hipLaunchKernelGGL(zf_finalize_kernel<S>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, 0, F); }, 5);
-    printf("        finalize alone S=%d T=%d (%d workgroups over %d partial rows): %7.1f us per launch\n", S, T, wgs, grid, ms_f / K * 1e3);
+    F.decide = 0;
+    double ms_r = time_ms([&] { for (int k = 0; k < K; ++k)
+        hipLaunchKernelGGL(zf_finalize_kernel<S>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, 0, F); }, 5);
+    F.decide = 1;
+    printf("        finalize alone S=%d T=%d (%d workgroups over %d partial rows): %7.1f us per launch (%.1f without the decide pass)\n", S, T, wgs, grid, ms_f / K * 1e3, ms_r / K * 1e3);
     printf("LIBRARY trial + finalize  S=%d T=%d nt=%d : %7.3f ms per pass = %7.3f ms per iteration (loop of %d)\n",
            S, T, (int)NT, ms / K, ms / K / S, K);
     for (int k = 2; k < RINGSZ - 1; ++k) CK(hipFree(extra[k]));

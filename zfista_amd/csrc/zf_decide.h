@@ -150,10 +150,18 @@ ZF_HD inline bool zf_apply_trial(zf_control* c, const zf_trial_eval* e, double* 
     c->fun = e->fun;
     c->trial = 0;
     c->need_grad = 1;
-    if (beta_ring) c->beta_next = beta_ring[nit % ZF_RING];   // y_{k+1} = x_k + beta (x_k - x_{k-1})  :533-534
+    // (beta of the next trial: resolved once per pass by the caller - zf_resolve_beta - because each
+    //  load of the momentum ring is a dependent global-memory round trip)
+    (void)beta_ring;
     if (e->err < c->tol) c->status = ZF_CONVERGED;            // :525
     else if (nit >= c->max_iter) c->status = ZF_MAXITER;      // :539
     return c->status == ZF_RUNNING;
+}
+
+// y_{k+1} = x_k + beta (x_k - x_{k-1})  (:533-534): the factor of the trial that follows the
+// accepted-iteration count now in the block
+ZF_HD inline void zf_resolve_beta(zf_control* c, const double* beta_ring) {
+    if (beta_ring) c->beta_next = beta_ring[c->nit % ZF_RING];
 }
 
 // One trial against the control block *c (buffer indices are not touched: the caller commits
@@ -171,6 +179,14 @@ ZF_HD inline bool zf_decide_step(zf_control* c, const double* packs, double* tra
     zf_trial_eval e;
     zf_eval_trial(c, c->F_old, c->lr, pk, &e);
     return zf_apply_trial(c, &e, trace, beta_ring);
+}
+
+// single-trial form with the momentum factor resolved (host tests, experiments)
+ZF_HD inline bool zf_decide_one(zf_control* c, const double* packs, double* trace, const double* beta_ring = nullptr) {
+    const int64_t before = c->nit;
+    const bool go = zf_decide_step(c, packs, trace, beta_ring);
+    if (c->nit > before) zf_resolve_beta(c, beta_ring);
+    return go;
 }
 
 // All trials of one pass.  packs: world x sub_iters x ZF_PACK_LEN (rank-major), pack j of a
@@ -216,6 +232,7 @@ ZF_HD inline void zf_decide_pass(zf_control* ctl, const double* packs, double* t
             c.prev = first;
             c.cur = second;
         }
+        zf_resolve_beta(&c, beta_ring);
         *ctl = c;
         return;
     }

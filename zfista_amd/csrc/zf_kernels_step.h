@@ -162,6 +162,7 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     __shared__ double lds[NW * NQ];
     __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
     __shared__ double s_pack[ZF_MAX_SUB_ITERS * ZF_PACK_LEN];
+    __shared__ double s_single[NQ];
     __shared__ int s_last;
     if (F.ctl->status != ZF_RUNNING) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -203,14 +204,19 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
         }
     }
     __syncthreads();
+    const bool single = (gridDim.x == 1);   // small problems: one finalize workgroup, no hand-over needed
     if (threadIdx.x < 64) {
         if (threadIdx.x < NQ) {
             const int k = threadIdx.x;
             double r = lds[k];
             for (int w = 1; w < NW; ++w)
                 r = (k % ZF_NPART == ZF_NPART - 1) ? fmax(r, lds[w * NQ + k]) : r + lds[w * NQ + k];
-            zf_publish(F.slice_part + (int64_t)k * ZF_FIN_WGS + blockIdx.x, r);
+            if (single) s_single[k] = r;
+            else zf_publish(F.slice_part + (int64_t)k * ZF_FIN_WGS + blockIdx.x, r);
         }
+        if (single) {
+            if (threadIdx.x == 0) s_last = 1;
+        } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
             const unsigned t = __hip_atomic_fetch_add(F.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             s_last = last;
         }
+        }
     }
     __syncthreads();
     if (!s_last || wave != 0) return;
@@ -231,7 +238,8 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     double tot[NQ];   // all 6 S loads in flight at once: one round trip
 #pragma unroll
     for (int k = 0; k < NQ; ++k)
-        tot[k] = (lane < nsl) ? zf_consume(F.slice_part + (int64_t)k * ZF_FIN_WGS + lane) : 0.0;
+        tot[k] = single ? (lane == 0 ? s_single[k] : 0.0)
+                        : (lane < nsl) ? zf_consume(F.slice_part + (int64_t)k * ZF_FIN_WGS + lane) : 0.0;
     // one transposing butterfly for all 6 S totals (same pairing as a shuffle tree per quantity):
     // the totals of trial j end in lane j * (64 / S), which builds, keeps and stores pack j
     constexpr int LSTR = 64 >> GH;
