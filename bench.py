@@ -66,6 +66,7 @@ def cpu_baseline(d, c, sample_n=10**7, iters=30):
     on a bounded sample of the same workload.  Reported, never a target."""
     from oracle import cpu_ref, problems_ref as P
 
+    sample_n = min(sample_n, d.numel())
     ds = d[:sample_n].cpu().numpy()
     cs = c[:sample_n].cpu().numpy()
     ref = P.DiagQuadL1Ref(ds, cs, LAM)

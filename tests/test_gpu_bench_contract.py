@@ -1,0 +1,49 @@
+"""GPU: bench.py keeps the driver's contract - exactly one JSON line on stdout with the agreed
+keys, exactly K timed iterations, a roofline block and (N = 1) a CPU baseline block."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "2000000", "--steps", "21",
+                          "--warmup", "5", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must hold exactly one line, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def test_bench_json_line():
+    d = _run()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["dtype"], d["data"]) == (1, 21, 5, "weak", "f64",
+                                                                                         "synthetic")
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # 21 iterations in chains of 8: at least 3 passes; iterations per pass never above the chain length
+    assert d["config"]["passes"] >= 3 and d["config"]["iterations_per_pass"] <= d["config"]["temporal_blocking_chain"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["ms_per_step"] * d["steps"] / 1e3 - d["steps"] / d["value"] * (2000000 / 1e8)) < 1e-9
+
+
+def test_bench_flags():
+    d = _run("--no-cpu-baseline", "--no-kernel-events")
+    assert "cpu_baseline" not in d and d["steps"] == 21
+    d = _run("--no-cpu-baseline", "--total-n", "3000000")
+    assert d["scaling"] == "strong" and d["config"]["n_total"] == 3000000
