@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=N_PER_GPU, help="elements per GPU (default 1e8)")
+    ap.add_argument("--n", "--elements", dest="n", type=int, default=N_PER_GPU, help="elements per GPU (default 1e8)")
     ap.add_argument("--total-n", type=int, default=0,
                     help="strong scaling: total length of x, split evenly over the GPUs (e.g. 800000000, "
                          "BASELINE cfg5); overrides --n")
@@ -119,12 +119,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    # ZF_BENCH_BACKEND=gloo rehearses the multi-process path with all ranks on ONE GPU (RCCL needs
+    # a device per rank); the driver's runs use nccl = RCCL, one GPU per rank
+    backend = os.environ.get("ZF_BENCH_BACKEND", "nccl")
+    device = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     group = None
     use_pg = world > 1 or (os.environ.get("ZF_FORCE_SPLIT") == "1" and "RANK" in os.environ)
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     from zfista_amd import _lib

@@ -47,3 +47,27 @@ def test_bench_flags():
     assert "cpu_baseline" not in d and d["steps"] == 21
     d = _run("--no-cpu-baseline", "--total-n", "3000000")
     assert d["scaling"] == "strong" and d["config"]["n_total"] == 3000000
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """The N > 1 flow of bench.py end to end - one process per rank, sharded solver, per-pass pack
+    exchange, barrier-bracketed timing, max over ranks, one JSON line from rank 0 - rehearsed with
+    two ranks on this one GPU (ZF_BENCH_BACKEND=gloo; the driver's runs use RCCL, one GPU per rank)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ZF_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--elements", "2000000", "--steps", "24", "--warmup", "8"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert (d["n_gpus"], d["steps"], d["scaling"]) == (2, 24, "weak") and "cpu_baseline" not in d
+    assert d["config"]["n_total"] == 4000000 and d["config"]["passes"] >= 3
+    # whole-job aggregate: two shards' worth of iterations per unit time
+    assert abs(d["value"] - 2 * 24 / (d["ms_per_step"] * 24 / 1e3) * (2000000 / 1e8)) < 1e-6 * d["value"]

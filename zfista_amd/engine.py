@@ -42,6 +42,13 @@ def gather_packs(pack_all, pack_local, group):
     "nccl") and on gloo for the CPU tests."""
     import torch.distributed as dist
 
+    if pack_local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the multi-process path on one GPU (several ranks cannot share a device
+        # under RCCL): stage the few hundred bytes through the host
+        host = pack_all.cpu()
+        dist.all_gather_into_tensor(host, pack_local.cpu(), group=group)
+        pack_all.copy_(host)
+        return
     dist.all_gather_into_tensor(pack_all, pack_local, group=group)
 
 
