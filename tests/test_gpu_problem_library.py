@@ -73,3 +73,32 @@ def test_library_problem_g_and_prox_on_device(tag):
     assert np.array_equal(prob.prox_wsum_g(w, x), r.prox_wsum_g(w, x))
     if prob.bounds is not None:
         assert np.all(np.isinf(prob.g(np.full(prob.n_features, -10.0))))
+
+
+@pytest.mark.parametrize("m", [5, 6, 8])
+def test_more_than_four_objectives(m):
+    """The device engine handles up to 8 objectives (LinearFunctionRank1 takes n_objectives):
+    against the oracle run live with the same SciPy dual search."""
+    from oracle import cpu_ref, problems_ref as P
+    from zfista_amd import problems as Z
+
+    n = 12
+    kw = dict(l1_ratios=(np.arange(m) + 1) / (10 * n), l1_shifts=np.arange(m) / 10)
+    x0 = np.random.default_rng(m).uniform(-0.05, 0.05, n)
+    o = dict(lr=2e-5, nesterov=True, tol=1e-7, max_iter=6, return_all=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = Z.LinearFunctionRank1(n, m, **kw).minimize_proximal_gradient(x0, **o)
+        exp = cpu_ref.minimize_proximal_gradient(*P.LinearFunctionRank1Ref(n, m, **kw).callbacks(), x0, **o)
+    assert res.nit == exp.nit and len(res.fun) == m
+    for a, b in zip(res.allvecs, exp.allvecs):
+        assert np.linalg.norm(a - b) <= 1e-6 * max(1.0, np.linalg.norm(b))
+    np.testing.assert_allclose(np.stack(res.allfuns), np.stack(exp.allfuns), rtol=1e-5, atol=1e-9)
+
+
+def test_nine_objectives_are_rejected():
+    from zfista_amd import _lib
+    from zfista_amd import problems as Z
+
+    with pytest.raises(_lib.ZfError, match="n_objectives"):
+        Z.LinearFunctionRank1(12, 9).g(np.zeros(12))

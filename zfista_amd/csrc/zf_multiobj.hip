@@ -220,16 +220,17 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_commit(double* __restrict__ y, con
 constexpr int MO_RED_WAVES = 16;
 __global__ __launch_bounds__(64 * MO_RED_WAVES) void k_mo_reduce(const double* __restrict__ partials, int nblocks,
                                                                  int nq, int max_index, double* out) {
-    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
-    if (k >= nq) return;
-    const bool is_max = (k == max_index);
-    double v = 0.0;
-    for (int b = lane; b < nblocks; b += 64) {
-        const double p = partials[(int64_t)k * nblocks + b];
-        v = is_max ? fmax(v, p) : v + p;
+    const int lane = threadIdx.x & 63;
+    for (int k = threadIdx.x >> 6; k < nq; k += MO_RED_WAVES) {   // (nq = 2m + 2 <= 18)
+        const bool is_max = (k == max_index);
+        double v = 0.0;
+        for (int b = lane; b < nblocks; b += 64) {
+            const double p = partials[(int64_t)k * nblocks + b];
+            v = is_max ? fmax(v, p) : v + p;
+        }
+        v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
+        if (lane == 0) out[k] = v;
     }
-    v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
-    if (lane == 0) out[k] = v;
 }
 
 }  // namespace
@@ -256,6 +257,21 @@ struct zf_mo {
     zf_mo_exchange_fn exchange = nullptr;   // combines raw totals over the ranks, in place
     void* exchange_ctx = nullptr;
 };
+
+
+// launch KERNEL<m> for m = 2 .. MO_MAX_M
+#define MO_LAUNCH(KERNEL, m, ...)                                                                              \
+    do {                                                                                                        \
+        switch (m) {                                                                                            \
+            case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, __VA_ARGS__); break; \
+            case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, __VA_ARGS__); break; \
+            case 5: hipLaunchKernelGGL(KERNEL<5>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, __VA_ARGS__); break; \
+            case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, __VA_ARGS__); break; \
+            case 7: hipLaunchKernelGGL(KERNEL<7>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL(KERNEL<8>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, __VA_ARGS__); break; \
+        }                                                                                                       \
+    } while (0)
 
 static int mo_reduce_to_host(zf_mo* s, int nq, int max_index, double* host) {
     hipLaunchKernelGGL(k_mo_reduce, dim3(1), dim3(64 * MO_RED_WAVES), 0, s->stream, s->partials, s->grid, nq, max_index,
@@ -300,7 +316,7 @@ static void mo_fill_w(const zf_mo* s, double lr, const double* w, mo_w* W) {
 extern "C" int zf_mo_create(zf_mo** out, int32_t kind, int32_t m, int64_t n, const double* l1_ratios,
                             const double* l1_shifts, double box_lo, double box_hi, void* stream) {
     ZF_REQUIRE(out && n >= 1, "zf_mo_create: bad argument");
-    ZF_REQUIRE(m >= 2 && m <= 4, "zf_mo_create: 2 <= n_objectives <= 4 supported");
+    ZF_REQUIRE(m >= 2 && m <= MO_MAX_M, "zf_mo_create: 2 <= n_objectives <= 8 supported");
     ZF_REQUIRE(kind == ZF_MO_GENERIC || (kind == ZF_MO_JOS1 && m == 2) || (kind == ZF_MO_FDS && m == 3),
                "zf_mo_create: kind / n_objectives mismatch");
     zf_mo* s = new (std::nothrow) zf_mo();
@@ -406,9 +422,7 @@ static int mo_builtin_f(zf_mo* s, const double* x, double* f_out) {
 static int mo_g_values(zf_mo* s, const double* x, double* g_out) {
     double t[MO_MAX_M + 1];
     const int m = s->m;
-    if (m == 2) hipLaunchKernelGGL(k_g_terms<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->G, s->n, s->partials);
-    else if (m == 3) hipLaunchKernelGGL(k_g_terms<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->G, s->n, s->partials);
-    else hipLaunchKernelGGL(k_g_terms<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->G, s->n, s->partials);
+    MO_LAUNCH(k_g_terms, m, x, s->G, s->n, s->partials);
     int rc = mo_reduce_to_host(s, m + 1, -1, t);
     if (rc) return rc;
     for (int i = 0; i < m; ++i) {
@@ -458,9 +472,7 @@ extern "C" int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double
     mo_w W;
     mo_fill_w(s, lr, w_host, &W);
     const int m = s->m;
-    if (m == 2) hipLaunchKernelGGL(k_dual_eval<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials);
-    else if (m == 3) hipLaunchKernelGGL(k_dual_eval<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials);
-    else hipLaunchKernelGGL(k_dual_eval<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials);
+    MO_LAUNCH(k_dual_eval, m, s->J, s->y, s->G, W, s->n, s->partials);
     int rc = mo_reduce_to_host(s, 2 * m + 2, -1, out);
     if (rc) return rc;
     for (int i = 0; i < m; ++i) out[i] = s->G.has_l1 ? s->G.ratio[i] * out[i] : 0.0;
@@ -474,9 +486,7 @@ extern "C" int zf_mo_recover(zf_mo* s, double lr, const double* w_host, double* 
     mo_fill_w(s, lr, w_host, &W);
     double* xn = s->xb[(s->cur + 1) % 3];
     const int m = s->m;
-    if (m == 2) hipLaunchKernelGGL(k_recover<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, xn, s->G, W, s->n, s->partials);
-    else if (m == 3) hipLaunchKernelGGL(k_recover<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, xn, s->G, W, s->n, s->partials);
-    else hipLaunchKernelGGL(k_recover<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, xn, s->G, W, s->n, s->partials);
+    MO_LAUNCH(k_recover, m, s->J, s->y, xn, s->G, W, s->n, s->partials);
     return mo_reduce_to_host(s, 1, 0, err_out);
 }
 
@@ -571,8 +581,6 @@ extern "C" int zf_mo_post_terms(zf_mo* s, double lr, const double* w_host, const
     double* pd = s->xb[(s->cur + 1) % 3];
     ZF_HIP(hipMemcpyAsync(pd, p_host, sizeof(double) * s->n, hipMemcpyHostToDevice, s->stream));
     const int m = s->m;
-    if (m == 2) hipLaunchKernelGGL(k_post_terms<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, pd, W, s->n, s->partials);
-    else if (m == 3) hipLaunchKernelGGL(k_post_terms<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, pd, W, s->n, s->partials);
-    else hipLaunchKernelGGL(k_post_terms<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, pd, W, s->n, s->partials);
+    MO_LAUNCH(k_post_terms, m, s->J, s->y, pd, W, s->n, s->partials);
     return mo_reduce_to_host(s, m + 1, -1, out);
 }
