@@ -271,6 +271,8 @@ int zf_mo_create(zf_mo** out, int32_t kind, int32_t m, int64_t n, const double* 
  * so that every rank continues with identical scalars; returns nonzero on failure. */
 typedef int (*zf_mo_exchange_fn)(void* ctx, double* vals, int32_t count, int32_t max_index);
 int zf_mo_set_shard(zf_mo* s, int64_t n_global, int64_t offset, zf_mo_exchange_fn fn, void* ctx);
+/* per-coordinate box bounds (host arrays of n) instead of the scalar pair given at creation */
+int zf_mo_set_bounds(zf_mo* s, const double* lo_host, const double* hi_host);
 int zf_mo_destroy(zf_mo* s);
 int zf_mo_set_x0(zf_mo* s, const double* x0_host);              /* :463-465 */
 /* point selector `which`: 0 = x_k, 1 = y, 2 = x+ (trial point), 3 = x_{k-1} */

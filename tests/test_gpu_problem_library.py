@@ -102,3 +102,37 @@ def test_nine_objectives_are_rejected():
 
     with pytest.raises(_lib.ZfError, match="n_objectives"):
         Z.LinearFunctionRank1(12, 9).g(np.zeros(12))
+
+
+@pytest.mark.parametrize("cls", ["JOS1", "FDS"])
+def test_per_coordinate_bounds(cls):
+    """bounds given as arrays (zfista/problems.py:69-70,104-106,137): g's feasibility check and the
+    prox's clip per coordinate, against the oracle."""
+    from oracle import cpu_ref, problems_ref as P
+    from zfista_amd import problems as Z
+
+    n = 40
+    rng = np.random.default_rng(5)
+    lo, hi = -rng.uniform(0.2, 1.5, n), rng.uniform(0.2, 2.0, n)
+    m = 2 if cls == "JOS1" else 3
+    kw = dict(l1_ratios=(np.arange(m) + 1) / n, l1_shifts=np.arange(m) / 4.0)
+    prob = getattr(Z, cls)(n, bounds=(lo, hi), **kw)
+    ref = getattr(P, cls + "Ref")(n, bounds=(lo, hi), **kw)
+    x = rng.uniform(-0.1, 0.1, n)
+    w = rng.uniform(0.1, 1, m)
+    far = rng.uniform(-3, 3, n)
+    assert np.array_equal(prob.prox_wsum_g(w, far), ref.prox_wsum_g(w, far))
+    np.testing.assert_allclose(prob.g(x), ref.g(x), rtol=1e-13)
+    assert np.all(np.isinf(prob.g(far))) and np.all(np.isinf(ref.g(far)))
+    mixed = getattr(Z, cls)(n, bounds=(lo, 1.0), **kw)          # array / scalar mix broadcasts
+    assert np.array_equal(mixed.prox_wsum_g(w, far), np.minimum(np.maximum(ref.__class__(n, bounds=(lo, 1.0), **kw)
+                                                                             .prox_wsum_g(w, far), lo), 1.0))
+    o = dict(lr=1.0 if cls == "JOS1" else 0.02, nesterov=True, tol=1e-8, max_iter=8, return_all=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = prob.minimize_proximal_gradient(x, **o)
+        exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x, **o)
+    assert res.nit == exp.nit
+    tol = 1e-7 if m == 2 else 1e-6
+    assert np.linalg.norm(res.x - exp.x) <= tol * max(1.0, np.linalg.norm(exp.x))
+    assert np.all(res.x >= lo) and np.all(res.x <= hi)

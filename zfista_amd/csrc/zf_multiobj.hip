@@ -27,16 +27,18 @@ struct mo_g {             // g / prox descriptor, passed by value
     double ratio[MO_MAX_M];
     double shift[MO_MAX_M];
     double lo, hi;
+    const double* lo_v;   // per-coordinate bounds (device, n each) or NULL: bounds given as arrays
+    const double* hi_v;   // (zfista/problems.py:69-70 allows either)
 };
 
 // prox_wsum_g(weight, x), problems.py:126-138; coef = weight * l1_ratios
-__device__ __forceinline__ double mo_prox(const mo_g& G, const double* coef, double tail_sum, double x) {
+__device__ __forceinline__ double mo_prox(const mo_g& G, const double* coef, double tail_sum, double x, int64_t j) {
     if (G.has_l1) {
         // stage 0: prox_lasso(x + sum(coef[1:]) - s0 + s0, coef[0])
         x = zf_soft_threshold(x + tail_sum - G.shift[0] + G.shift[0], coef[0]);
         for (int i = 1; i < G.m; ++i) x = zf_soft_threshold(x - coef[i] - G.shift[i], coef[i]) + G.shift[i];
     }
-    if (G.has_box) x = zf_clip(x, G.lo, G.hi);
+    if (G.has_box) x = zf_clip(x, G.lo_v ? G.lo_v[j] : G.lo, G.hi_v ? G.hi_v[j] : G.hi);
     return x;
 }
 
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_dual_eval(const double* __restrict
         }
         const double yj = y[j];
         const double v = yj - W.lr * wJ;
-        const double p = mo_prox(G, W.coef, W.tail_sum, v);
+        const double p = mo_prox(G, W.coef, W.tail_sum, v, j);
 #pragma unroll
         for (int i = 0; i < M; ++i) acc[i] += fabs(p - G.shift[i]);
         const double dv = p - v;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_recover(const double* __restrict__
 #pragma unroll
         for (int i = 0; i < M; ++i) wJ += W.w[i] * J[(int64_t)i * n + j];
         const double yj = y[j];
-        const double p = mo_prox(G, W.coef, W.tail_sum, yj - W.lr * wJ);
+        const double p = mo_prox(G, W.coef, W.tail_sum, yj - W.lr * wJ, j);
         xn[j] = p;
         mx = fmax(mx, fabs(p - yj));
     }
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_g_terms(const double* __restrict__
         const double xv = x[j];
 #pragma unroll
         for (int i = 0; i < M; ++i) acc[i] += fabs(xv - G.shift[i]);
-        if (G.has_box) acc[M] += (xv < G.lo || xv > G.hi) ? 1.0 : 0.0;
+        if (G.has_box) acc[M] += (xv < (G.lo_v ? G.lo_v[j] : G.lo) || xv > (G.hi_v ? G.hi_v[j] : G.hi)) ? 1.0 : 0.0;
     }
     const double maxs[1] = {0.0};
     double out = 0.0;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_fds_jac(const double* __restrict__
 __global__ __launch_bounds__(ZF_BLOCK) void k_prox_only(double* x, mo_g G, mo_w W, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
     for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride)
-        x[j] = mo_prox(G, W.coef, W.tail_sum, x[j]);
+        x[j] = mo_prox(G, W.coef, W.tail_sum, x[j], j);
 }
 
 __global__ __launch_bounds__(ZF_BLOCK) void k_commit(double* __restrict__ y, const double* __restrict__ xk,
@@ -254,6 +256,7 @@ struct zf_mo {
     // x sharded over ranks (contiguous blocks): n is the local length
     int64_t n_global = 0;      // n_features of the whole problem
     int64_t offset = 0;        // global index of local element 0
+    double* bounds_v = nullptr;             // 2 n: per-coordinate lower, upper bounds (optional)
     zf_mo_exchange_fn exchange = nullptr;   // combines raw totals over the ranks, in place
     void* exchange_ctx = nullptr;
 };
@@ -370,9 +373,23 @@ extern "C" int zf_mo_set_shard(zf_mo* s, int64_t n_global, int64_t offset, zf_mo
     return ZF_OK;
 }
 
+// Per-coordinate box (arrays of n; this rank's block when sharded): replaces the scalar bounds.
+extern "C" int zf_mo_set_bounds(zf_mo* s, const double* lo_host, const double* hi_host) {
+    ZF_REQUIRE(s && lo_host && hi_host, "zf_mo_set_bounds: null argument");
+    if (!s->bounds_v) ZF_HIP(hipMalloc(&s->bounds_v, sizeof(double) * 2 * s->n));
+    ZF_HIP(hipMemcpyAsync(s->bounds_v, lo_host, sizeof(double) * s->n, hipMemcpyHostToDevice, s->stream));
+    ZF_HIP(hipMemcpyAsync(s->bounds_v + s->n, hi_host, sizeof(double) * s->n, hipMemcpyHostToDevice, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    s->G.has_box = 1;
+    s->G.lo_v = s->bounds_v;
+    s->G.hi_v = s->bounds_v + s->n;
+    return ZF_OK;
+}
+
 extern "C" int zf_mo_destroy(zf_mo* s) {
     if (!s) return ZF_OK;
     (void)hipStreamSynchronize(s->stream);
+    if (s->bounds_v) (void)hipFree(s->bounds_v);
     (void)hipFree(s->buf);
     (void)hipFree(s->partials);
     (void)hipFree(s->totals);

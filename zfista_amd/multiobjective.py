@@ -100,6 +100,14 @@ class MoEngine:
             self._cb = _EXCHANGE_FN(exchange)   # keep alive as long as the engine
             _lib.check(self.lib.zf_mo_set_shard(h, int(n_global), int(offset), self._cb, None), "zf_mo_set_shard")
 
+    def set_bounds(self, lo, hi):
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        if lo.size != self.n or hi.size != self.n:
+            raise ValueError("bounds arrays must have n_features entries")
+        _lib.check(self.lib.zf_mo_set_bounds(self.h, C.c_void_p(_lib.ptr(lo)), C.c_void_p(_lib.ptr(hi))),
+                   "zf_mo_set_bounds")
+
     def _vec(self, a):
         a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
         if a.size != self.n:

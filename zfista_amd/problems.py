@@ -231,9 +231,7 @@ class Problem:
         self.n_objectives = int(n_objectives)
         self.l1_ratios = None if l1_ratios is None else np.array(l1_ratios, dtype=np.float64)
         self.l1_shifts = np.zeros(n_objectives) if l1_shifts is None else np.array(l1_shifts, dtype=np.float64)
-        self.bounds = bounds
-        if bounds is not None and (np.ndim(bounds[0]) or np.ndim(bounds[1])):
-            raise NotImplementedError("array-valued bounds are not supported by the device prox")
+        self.bounds = bounds   # scalars or per-coordinate arrays of n_features (problems.py:69-70)
         self.name = self._generate_name()
         self._eng = None
 
@@ -251,8 +249,13 @@ class Problem:
 
         if self._eng is None or self._eng.h is None:
             lo, hi = self.shard_bounds()
+            arrays = self.bounds is not None and (np.ndim(self.bounds[0]) > 0 or np.ndim(self.bounds[1]) > 0)
             self._eng = MoEngine(self._kind, self.n_objectives, hi - lo, self.l1_ratios,
-                                 self.l1_shifts, self.bounds, group=self.group, n_global=self.n_features, offset=lo)
+                                 self.l1_shifts, None if arrays else self.bounds, group=self.group,
+                                 n_global=self.n_features, offset=lo)
+            if arrays:   # per-coordinate box: this rank's block of each bound vector
+                full = [np.broadcast_to(np.asarray(b, dtype=np.float64), (self.n_features,)) for b in self.bounds]
+                self._eng.set_bounds(full[0][lo:hi], full[1][lo:hi])
         return self._eng
 
     def shard_bounds(self):
