@@ -59,11 +59,11 @@ def test_product_fails_loudly_without_gpu():
         minimize_proximal_gradient(*cb, np.ones(3))
 
 
-def test_hot_kernels_use_no_scratch_memory(tmp_path):
+def test_kernels_use_no_scratch_memory(tmp_path):
     """Register-resident by construction: a compiler decision to spill the reduction arrays of
     the fused kernels to scratch once cost 17 KiB of extra HBM writes per workgroup (found with
-    rocprofv3 --pmc WRITE_SIZE).  Compiles the solver's device code to assembly (no GPU needed)
-    and checks the private segment of every trial / finalize / decide kernel is empty."""
+    rocprofv3 --pmc WRITE_SIZE).  Compiles the device code of every source to assembly (no GPU
+    needed) and checks that no kernel has a private segment."""
     import re
     import shutil
     import subprocess
@@ -71,17 +71,14 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(_lib.CSRC, "zf_solver.hip")
-    out = tmp_path / "zf_solver.s"
-    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-                    "-S", "--cuda-device-only", src, "-o", str(out)], check=True, capture_output=True)
-    text = out.read_text()
     seen = 0
-    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
-        name, body = m.group(1), m.group(2)
-        if not any(k in name for k in ("zf_trial_kernel", "zf_finalize_kernel", "zf_decide_kernel")):
-            continue
-        seen += 1
-        size = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
-        assert size == 0, f"{name} uses {size} B of scratch per thread"
-    assert seen >= 10
+    for name in ("zf_solver.hip", "zf_vecops.hip", "zf_multiobj.hip"):
+        out = tmp_path / (name + ".s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                        "-S", "--cuda-device-only", os.path.join(_lib.CSRC, name), "-o", str(out)], check=True,
+                       capture_output=True)
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", out.read_text(), re.S):
+            seen += 1
+            size = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+            assert size == 0, f"{m.group(1)} uses {size} B of scratch per thread"
+    assert seen >= 60
