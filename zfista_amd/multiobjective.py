@@ -86,6 +86,7 @@ class MoEngine:
         self.n_dual_evals = 0
         self.n_exchanges = 0
         self._cb = None
+        self._exchange_error = None
         if group is not None:
             def exchange(_ctx, vals, count, max_index):
                 try:
@@ -99,6 +100,14 @@ class MoEngine:
 
             self._cb = _EXCHANGE_FN(exchange)   # keep alive as long as the engine
             _lib.check(self.lib.zf_mo_set_shard(h, int(n_global), int(offset), self._cb, None), "zf_mo_set_shard")
+
+    def _check(self, rc, what):
+        """_lib.check, but an exception raised inside the exchange callback (it cannot cross the
+        C boundary) is re-raised here as the cause."""
+        if rc != _lib.ZF_OK and self._exchange_error is not None:
+            exc, self._exchange_error = self._exchange_error, None
+            raise _lib.ZfError(f"{what}: the exchange between ranks failed") from exc
+        _lib.check(rc, what)
 
     def set_bounds(self, lo, hi):
         lo = np.ascontiguousarray(lo, dtype=np.float64)
@@ -121,13 +130,13 @@ class MoEngine:
     def eval_F(self, which, builtin_f=True):
         f = np.zeros(self.m)
         g = np.zeros(self.m)
-        _lib.check(self.lib.zf_mo_eval_F(self.h, which, C.c_void_p(_lib.ptr(f)) if builtin_f else None,
+        self._check(self.lib.zf_mo_eval_F(self.h, which, C.c_void_p(_lib.ptr(f)) if builtin_f else None,
                                          C.c_void_p(_lib.ptr(g))), "zf_mo_eval_F")
         return (f if builtin_f else None), g
 
     def prepare(self):
         f_y = np.zeros(self.m)
-        _lib.check(self.lib.zf_mo_prepare(self.h, C.c_void_p(_lib.ptr(f_y))), "zf_mo_prepare")
+        self._check(self.lib.zf_mo_prepare(self.h, C.c_void_p(_lib.ptr(f_y))), "zf_mo_prepare")
         return f_y
 
     def set_jac(self, J):
@@ -139,8 +148,7 @@ class MoEngine:
     def dual_eval(self, lr, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
         out = np.zeros(2 * self.m + 2)
-        _lib.check(self.lib.zf_mo_dual_eval(self.h, float(lr), C.c_void_p(_lib.ptr(w)), C.c_void_p(_lib.ptr(out))),
-                   "zf_mo_dual_eval")
+        self._check(self.lib.zf_mo_dual_eval(self.h, float(lr), C.c_void_p(_lib.ptr(w)), C.c_void_p(_lib.ptr(out))), "zf_mo_dual_eval")
         self.n_dual_evals += 1
         m = self.m
         return out[:m], out[m], out[m + 1], out[m + 2:]
@@ -148,7 +156,7 @@ class MoEngine:
     def recover(self, lr, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
         err = C.c_double(0.0)
-        _lib.check(self.lib.zf_mo_recover(self.h, float(lr), C.c_void_p(_lib.ptr(w)), C.byref(err)), "zf_mo_recover")
+        self._check(self.lib.zf_mo_recover(self.h, float(lr), C.c_void_p(_lib.ptr(w)), C.byref(err)), "zf_mo_recover")
         return np.float64(err.value)
 
     def commit(self, beta, nesterov):
@@ -182,7 +190,7 @@ class MoEngine:
         w = np.ascontiguousarray(w, dtype=np.float64)
         p = self._vec(p)
         out = np.zeros(self.m + 1)
-        _lib.check(self.lib.zf_mo_post_terms(self.h, float(lr), C.c_void_p(_lib.ptr(w)), C.c_void_p(_lib.ptr(p)),
+        self._check(self.lib.zf_mo_post_terms(self.h, float(lr), C.c_void_p(_lib.ptr(w)), C.c_void_p(_lib.ptr(p)),
                                              C.c_void_p(_lib.ptr(out))), "zf_mo_post_terms")
         return out[:self.m], out[self.m]
 
