@@ -169,6 +169,10 @@ class NativeRun:
         """Upload momentum factors for accepted-iteration counts < upto."""
         if not self.opts["nesterov"] or upto <= self._beta_filled:
             return
+        # refill as far ahead as the ring allows (slot of count nit_seen + ZF_RING would alias the
+        # pending one), bounded by what the solve can still use: one upload per ~1000 iterations
+        ahead = self.nit_seen + _lib.ZF_RING - 1
+        upto = max(upto, min(ahead, int(self.opts["max_iter"]) + 1))
         first = self._beta_filled
         count = upto - first
         betas = np.zeros(count)
@@ -202,6 +206,7 @@ class NativeRun:
         self.opts = dict(self.opts, max_iter=int(max_iter))
         ctl, _ = self.solver.poll()
         self.status = int(ctl.status)
+        self._fill_beta(self.nit_seen + 1)   # momentum factors for the extended range, as far as the ring allows
 
     def collect(self):
         ctl, trace = self.solver.poll()
