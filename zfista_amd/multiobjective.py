@@ -146,11 +146,19 @@ class MoEngine:
         _lib.check(self.lib.zf_mo_set_jac(self.h, C.c_void_p(_lib.ptr(J))), "zf_mo_set_jac")
 
     def dual_eval(self, lr, w):
-        w = np.ascontiguousarray(w, dtype=np.float64)
-        out = np.zeros(2 * self.m + 2)
-        self._check(self.lib.zf_mo_dual_eval(self.h, float(lr), C.c_void_p(_lib.ptr(w)), C.c_void_p(_lib.ptr(out))), "zf_mo_dual_eval")
+        # (called 10 - 1e5 times per outer iteration: buffers and their ctypes pointers are kept)
+        bufs = self.__dict__.get("_dual_bufs")
+        if bufs is None:
+            wb, ob = np.zeros(self.m), np.zeros(2 * self.m + 2)
+            bufs = self._dual_bufs = (wb, ob, C.c_void_p(_lib.ptr(wb)), C.c_void_p(_lib.ptr(ob)))
+        wb, ob, wp, op_ = bufs
+        wb[:] = w
+        rc = self.lib.zf_mo_dual_eval(self.h, float(lr), wp, op_)
+        if rc != _lib.ZF_OK:
+            self._check(rc, "zf_mo_dual_eval")
         self.n_dual_evals += 1
         m = self.m
+        out = ob.copy()
         return out[:m], out[m], out[m + 1], out[m + 2:]
 
     def recover(self, lr, w):
