@@ -37,3 +37,16 @@ def test_integration_md_stub_runs_as_written():
     assert np.array_equal(x, exp.x)
     assert int((trace[:, 2] > 0).sum()) == 40
     np.testing.assert_allclose(trace[:40, 1], exp.allfuns[1:], rtol=1e-10)
+
+
+def test_quickstart_example_runs():
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "quickstart.py")], capture_output=True,
+                         text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 5 and "Optimization terminated successfully" in lines[0]
+    assert float(lines[0].split("|x - x*|_inf=")[1].split()[0]) < 1e-6
+    assert float(lines[2].split("|dx|=")[1]) < 1e-8
