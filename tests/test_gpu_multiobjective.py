@@ -251,3 +251,37 @@ def test_fds_1e6_dual_eval_consistency():
         noise = 4e-16 * np.max(np.abs(f_y)) * 8
         np.testing.assert_allclose(fun, efun, rtol=1e-9, atol=noise)
         np.testing.assert_allclose(jac, ejac, rtol=1e-9, atol=noise)
+
+
+@pytest.mark.parametrize("path", ["native", "generic"])
+@pytest.mark.parametrize("cls", ["jos1", "fds"])
+def test_warm_start_of_the_dual_search(cls, path):
+    """warm_start=True feeds the weights of the previous trial to the next dual search
+    (zfista/proximal_gradient.py:192-205,286-288): native (device engine) and generic (opaque
+    callbacks) paths against the oracle, which restates the same hand-over."""
+    from oracle import cpu_ref, problems_ref as P
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.problems import FDS, JOS1
+
+    if cls == "jos1":
+        n, kw = 60, dict(l1_ratios=np.arange(1, 3) / 60, l1_shifts=[0, 1])
+        prob, ref, o = JOS1(n, **kw), P.JOS1Ref(n, **kw), dict(lr=1.0)
+    else:
+        n, kw = 10, dict(l1_ratios=np.arange(1, 4) / 10, l1_shifts=[0, 1, 2])
+        prob, ref, o = FDS(n, **kw), P.FDSRef(n, **kw), dict(lr=0.05)
+    x0 = np.random.default_rng(12).uniform(-2, 2, n)
+    o.update(nesterov=True, tol=1e-6, max_iter=10, warm_start=True, return_all=True)
+    cbs = prob.callbacks()
+    if path == "generic":   # plain closures: not recognised as a device-native problem
+        cbs = tuple((lambda fn: (lambda *a: fn(*a)))(fn) for fn in ref.callbacks())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize_proximal_gradient(*cbs, x0, **o)
+        exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, **o)
+        cold = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, **dict(o, warm_start=False))
+    assert res.nit == exp.nit
+    tol = 1e-7 if cls == "jos1" else 1e-6
+    for a, b in zip(res.allvecs, exp.allvecs):
+        assert np.linalg.norm(a - b) <= tol * max(1.0, np.linalg.norm(b))
+    np.testing.assert_allclose(np.stack(res.allfuns), np.stack(exp.allfuns), rtol=1e-6)
+    assert len(cold.allvecs) >= 2   # (the cold-start run exists and converges to the same point class)

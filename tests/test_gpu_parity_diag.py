@@ -208,3 +208,25 @@ def test_diag_n1e8_properties():
         exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), np.zeros(idx.size), lr=0.45, nesterov=True,
                                                  tol=0.0, max_iter=K)
     assert np.array_equal(xK[idx], exp.x)
+
+
+def test_verbose_prints_a_row_per_iteration(capsys):
+    """verbose=True: the header of proximal_gradient.py:24-30 and one five-column row per outer
+    iteration (the reference's formatter raises IndexError at :511-520 - documented deviation),
+    on the device-resident path with chained passes, the one-trial path and the generic path."""
+    from oracle import problems_ref as P
+    from zfista_amd import minimize_proximal_gradient
+
+    prob, ref = _problem(3001, seed=2)
+    for cbs, extra in ((prob.callbacks(), {}), (prob.callbacks(), dict(return_all=True)),
+                       (tuple((lambda fn: (lambda *a: fn(*a)))(fn) for fn in ref.callbacks()), {})):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = minimize_proximal_gradient(*cbs, np.zeros(3001), lr=0.45, nesterov=True, tol=0.0, max_iter=11,
+                                             verbose=True, **extra)
+        out = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("|")]
+        assert "niter" in out[0] and "learning rate" in out[0] and set(out[1]) <= set("|-")
+        rows = out[2:]
+        assert len(rows) == res.nit == 11
+        assert [int(r.split("|")[1]) for r in rows] == list(range(1, 12))
+        assert all(len(r.split("|")) == 7 for r in rows)
