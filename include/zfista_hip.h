@@ -281,6 +281,13 @@ int zf_mo_prepare(zf_mo* s, double* f_y_out /* m */);           /* J = jac_f(y),
 int zf_mo_set_jac(zf_mo* s, const double* J_host);              /* generic kind         :142 */
 /* out[0..m) = g_i(p), out[m] = |p-v|^2, out[m+1] = |w@J|^2, out[m+2..2m+2) = J_i.(p-y)   :162-173 */
 int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double* out);
+/* the whole dual search of one trial inside the library (opt-in replacement of the two SciPy
+ * calls :179-205): m = 2 bracketing root finder on the monotone derivative, m >= 3 projected
+ * Newton on the simplex; every evaluation is one zf_mo_dual_eval.  *ok_out = 0: not attempted
+ * (non-finite start), fall back to the reference's calls. */
+int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
+                     const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
+                     int64_t* nit_out, int32_t* ok_out, int64_t* evals_out);
 int zf_mo_recover(zf_mo* s, double lr, const double* w_host, double* err_out);   /* :206, :510 */
 int zf_mo_commit(zf_mo* s, double beta, int32_t nesterov);      /* :530-538 */
 int zf_mo_get(zf_mo* s, int32_t which, double* host);

@@ -285,3 +285,30 @@ def test_warm_start_of_the_dual_search(cls, path):
         assert np.linalg.norm(a - b) <= tol * max(1.0, np.linalg.norm(b))
     np.testing.assert_allclose(np.stack(res.allfuns), np.stack(exp.allfuns), rtol=1e-6)
     assert len(cold.allvecs) >= 2   # (the cold-start run exists and converges to the same point class)
+
+
+@pytest.mark.parametrize("tag", ["jos1_n50_l1", "jos1_n1000_l1", "fds_n10", "fds_n10_l1", "fds_n100_l1", "fds_n10_pos"])
+def test_library_dual_solver_matches_the_python_one(tag, golden):
+    """zf_mo_solve_dual (C++, no Python between evaluations) against
+    multiobjective.solve_dual_native (the same algorithm in Python) on the same engine state."""
+    from zfista_amd.multiobjective import Y, device_dual, solve_dual_native
+
+    G = golden("g4_multiobjective.npz")
+    p = _cases()[tag][0]()
+    eng = p._engine()
+    eng.set_x0(G(f"{tag}.x0"))
+    eng.put(Y, G(f"{tag}.sub.y"))
+    f0, g0 = eng.eval_F(0)
+    F_old = f0 + g0
+    f_y = eng.prepare()
+    lr = float(G(f"{tag}.sub.lr"))
+    m = p.n_objectives
+    for deprecated in (False, True):
+        got = eng.solve_dual(lr, f_y, F_old, deprecated, None, 1e-12, 100000)
+        exp = solve_dual_native(device_dual(eng, lr, f_y, F_old, deprecated), m, np.ones(m) / m, 1e-12, 100000)
+        assert got is not None and exp is not None
+        np.testing.assert_allclose(got[0], exp[0], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(got[1], exp[1], rtol=1e-12, atol=1e-12 * max(1.0, abs(exp[1])))
+        assert abs(got[0].sum() - 1.0) < 1e-12 and np.all(got[0] >= 0)
+    # not attempted when F(x_k) is not finite
+    assert eng.solve_dual(lr, f_y, np.full(m, np.inf), False, None, 1e-12, 100) is None

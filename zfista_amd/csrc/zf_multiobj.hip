@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "zf_common.h"
+#include "zf_dual_native.h"
 
 namespace {
 
@@ -493,6 +494,68 @@ extern "C" int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double
     int rc = mo_reduce_to_host(s, 2 * m + 2, -1, out);
     if (rc) return rc;
     for (int i = 0; i < m; ++i) out[i] = s->G.has_l1 ? s->G.ratio[i] * out[i] : 0.0;
+    return ZF_OK;
+}
+
+// ---- the dual of one trial solved inside the library (ZF_DUAL_SOLVER=native) -------------------
+// D(w) and its gradient from one fused evaluation, as zfista/proximal_gradient.py:161-177 composes
+// them:  fun = -<w, g(p)> - |p - v|^2 / 2 / lr + lr / 2 |w@J|^2 (+ <w, F_old - f_y>),
+//        jac = -g(p) - J (p - y) (+ F_old - f_y).
+namespace {
+struct mo_dual_ctx {
+    zf_mo* s;
+    double lr;
+    const double* f_y;
+    const double* F_old;
+    int deprecated;
+};
+int mo_dual_fn(void* vctx, const double* w, double* fun, double* jac) {
+    mo_dual_ctx* c = static_cast<mo_dual_ctx*>(vctx);
+    const int m = c->s->m;
+    double out[2 * MO_MAX_M + 2];
+    int rc = zf_mo_dual_eval(c->s, c->lr, w, out);
+    if (rc) return rc;
+    const double* g_p = out;
+    const double ss_pv = out[m], ss_wJ = out[m + 1];
+    const double* dots = out + m + 2;
+    double inner = 0.0;
+    for (int i = 0; i < m; ++i) inner += w[i] * g_p[i];
+    const double n_pv = sqrt(ss_pv), n_wJ = sqrt(ss_wJ);
+    double f = -inner - n_pv * n_pv / 2 / c->lr + c->lr / 2 * (n_wJ * n_wJ);
+    for (int i = 0; i < m; ++i) jac[i] = -g_p[i] - dots[i];
+    if (!c->deprecated) {
+        double corr = 0.0;
+        for (int i = 0; i < m; ++i) {
+            const double dF = c->F_old[i] - c->f_y[i];
+            corr += w[i] * dF;
+            jac[i] += dF;
+        }
+        f += corr;
+    }
+    *fun = f;
+    return 0;
+}
+}  // namespace
+
+// w0 may be NULL (uniform start).  *ok_out = 0: the start point is not finite (e.g. F(x_k) = inf
+// outside the box) - nothing was solved, use the reference's SciPy calls.  *evals_out counts the
+// dual evaluations spent.
+extern "C" int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
+                                const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
+                                int64_t* nit_out, int32_t* ok_out, int64_t* evals_out) {
+    ZF_REQUIRE(s && f_y && F_old && w_out && fun_out && nit_out && ok_out, "zf_mo_solve_dual: null argument");
+    ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_solve_dual: lr must be > 0 and max_iter >= 1");
+    mo_dual_ctx ctx = {s, lr, f_y, F_old, (int)deprecated};
+    zf_dual::evaluator E = {mo_dual_fn, &ctx, 0};
+    long nit = 0;
+    int ok = 1;
+    double fun = 0.0;
+    const int rc = zf_dual::solve(E, s->m, w0, tol, (long)max_iter, w_out, &fun, &nit, &ok);
+    if (evals_out) *evals_out = E.evals;
+    if (rc) return ZF_ERR_STATE;   // (the failing evaluation left its message)
+    *fun_out = fun;
+    *nit_out = nit;
+    *ok_out = ok;
     return ZF_OK;
 }
 

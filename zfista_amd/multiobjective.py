@@ -161,6 +161,25 @@ class MoEngine:
         out = ob.copy()
         return out[:m], out[m], out[m + 1], out[m + 2:]
 
+    def solve_dual(self, lr, f_y, F_old, deprecated, w0, tol, max_iter):
+        """The whole dual search of a trial inside the library (zf_mo_solve_dual; opt-in,
+        ZF_DUAL_SOLVER=native).  Returns (weight, fun, nit) or None when it was not attempted
+        (non-finite start: the caller uses the reference's SciPy calls)."""
+        f_y = np.ascontiguousarray(f_y, dtype=np.float64)
+        F_old = np.ascontiguousarray(F_old, dtype=np.float64)
+        w0 = None if w0 is None else np.ascontiguousarray(w0, dtype=np.float64)
+        w = np.zeros(self.m)
+        fun, nit, ok, evals = C.c_double(0.0), C.c_int64(0), C.c_int32(0), C.c_int64(0)
+        rc = self.lib.zf_mo_solve_dual(self.h, float(lr), C.c_void_p(_lib.ptr(f_y)), C.c_void_p(_lib.ptr(F_old)),
+                                       int(bool(deprecated)), None if w0 is None else C.c_void_p(_lib.ptr(w0)),
+                                       float(tol), int(max_iter), C.c_void_p(_lib.ptr(w)), C.byref(fun),
+                                       C.byref(nit), C.byref(ok), C.byref(evals))
+        self.n_dual_evals += int(evals.value)
+        self._check(rc, "zf_mo_solve_dual")
+        if not ok.value:
+            return None
+        return w, np.float64(fun.value), int(nit.value)
+
     def recover(self, lr, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
         err = C.c_double(0.0)
@@ -411,6 +430,9 @@ def solve_native(problem, x0, o):
                          nesterov=o["nesterov"], nesterov_ratio=o["nesterov_ratio"])
     if o["verbose"]:
         _print_header()
+    import os
+
+    use_native = os.environ.get("ZF_DUAL_SOLVER", DUAL_SOLVER) == "native"
     host_f = bool(getattr(problem, "_host_f", False))   # f / jac_f are host NumPy (n <= 30 families)
 
     def eval_F(which):
@@ -441,8 +463,14 @@ def solve_native(problem, x0, o):
             f_y = prepare()             # f(y_k), J = jac_f(y_k): once per line search (y_k is fixed)
             accepted = False
             for _ in range(o["max_backtrack_iter"]):
-                dual = device_dual(eng, lr, f_y, F_old, o["deprecated"])
-                weight, dual_fun, nit_int = solve_dual(dual, m, w0, o["tol_internal"], o["max_iter_internal"])
+                out = None
+                if use_native:   # the library's own dual solver: no Python between the evaluations
+                    out = eng.solve_dual(lr, f_y, F_old, o["deprecated"], w0, o["tol_internal"],
+                                         o["max_iter_internal"])
+                if out is None:
+                    dual = device_dual(eng, lr, f_y, F_old, o["deprecated"])
+                    out = solve_dual(dual, m, w0, o["tol_internal"], o["max_iter_internal"])
+                weight, dual_fun, nit_int = out
                 err = eng.recover(lr, weight)          # x+ and max|x+ - y|   (:206, :510)
                 fun = -dual_fun                         # (:207)
                 f_x, g_x = eval_F(X_NEW)
