@@ -1,0 +1,50 @@
+// Host-only harness around zfista_amd/csrc/zf_dual_native.h (plain C++, no HIP): minimises
+//   D(w) = 1/2 w'Qw + q'w + sum_i kink_i * max(w_i - knot_i, 0)^2      over the unit simplex
+// - convex, C^1, piecewise quadratic like the dual of a multi-objective trial - so that the
+// library's dual solver can be checked on a machine without a GPU (tests/test_dual_native_cpp.py).
+#include "../../zfista_amd/csrc/zf_dual_native.h"
+
+namespace {
+struct problem {
+    int m;
+    const double* Q;   // m x m row-major, symmetric positive semidefinite
+    const double* q;
+    const double* kink;
+    const double* knot;
+};
+int eval(void* ctx, const double* w, double* fun, double* jac) {
+    const problem* p = static_cast<const problem*>(ctx);
+    double f = 0.0;
+    for (int i = 0; i < p->m; ++i) {
+        double t = 0.0;
+        for (int j = 0; j < p->m; ++j) t += p->Q[i * p->m + j] * w[j];
+        jac[i] = t + p->q[i];
+        f += 0.5 * w[i] * t + p->q[i] * w[i];
+        const double e = w[i] - p->knot[i];
+        if (e > 0.0) {
+            f += p->kink[i] * e * e;
+            jac[i] += 2.0 * p->kink[i] * e;
+        }
+    }
+    *fun = f;
+    return 0;
+}
+}  // namespace
+
+extern "C" int dual_native_solve(int m, const double* Q, const double* q, const double* kink, const double* knot,
+                                 const double* w0, double tol, long max_iter, double* w, double* fun, long* nit,
+                                 int* evals) {
+    problem p = {m, Q, q, kink, knot};
+    zf_dual::evaluator E = {eval, &p, 0};
+    int ok = 1;
+    const int rc = zf_dual::solve(E, m, w0, tol, max_iter, w, fun, nit, &ok);
+    *evals = E.evals;
+    return rc ? rc : (ok ? 0 : 1);
+}
+
+extern "C" double dual_native_min_eig(int m, const double* Q) {
+    double A[zf_dual::MAXM][zf_dual::MAXM];
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) A[i][j] = Q[i * m + j];
+    return zf_dual::min_eigenvalue(m, A);
+}
