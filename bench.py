@@ -5,21 +5,41 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1
 the driver launches one rank per GPU with torch.distributed.run.  A "step" is one
 FISTA iteration (one accepted line-search trial) over this rank's 10^8-element
 shard of the decision vector.  Inputs are generated on the device and are resident in
-HBM before the timed region; exactly W iterations are run untimed, then exactly K timed
-(max_iter is raised from W to W + K; the device stops on it).  One launch ("pass") of the
-fused kernel carries a chain of up to S = 8 iterations (temporal blocking), so
-K iterations take about K / S passes.  Rank 0 prints ONE JSON line.
+HBM before the timed region.
+
+One timed BLOCK = a fresh solve from x0 = 0: exactly W iterations untimed, then exactly K
+iterations timed between barrier + synchronize on both sides (max_iter is raised from W to
+W + K on the live solve; the device stops on it).  A block lasts a few milliseconds, in which
+the GPU still runs at its boost clock; a long solve does not (the kernel is power-limited,
+DESIGN.md 4.1).  So the block is REPEATED - same workload, same iterations 1..W+K, back to back -
+until at least ``--min-seconds`` (default 0.6 s) of timed work has run (at most ``--max-blocks``),
+and ``value`` / ``ms_per_step`` are the MEDIAN block: the sustained rate on a warm device.  The
+first and last block are reported beside it.
+
+One launch ("pass") of the fused kernel carries a chain of up to S = 8 iterations (temporal
+blocking), so K iterations take about K / S passes.  Rank 0 prints ONE JSON line.
 
 value = (N * K) / t : iterations per second in units of one 10^8-element shard.
 At N = 1 that is exactly BASELINE.json's metric (FISTA it/s at n = 10^8); for
 N > 1 (weak scaling: n = N x 10^8) the full-problem rate K / t is reported beside
 it as ``config.iters_per_sec_full_problem``.
+
+roofline (dominant kernel: zf_trial_kernel, full-chain passes only, HIP events on the solver's
+stream):  ``achieved`` = HBM bytes one pass MOVES (48 B x n for a chain: four streams read, two
+iterates written; 40 B x n for S = 1; checked against the PMC counters in profiles/) / mean
+duration; ``frac`` = achieved / 8 TB/s <= 1.  The fp64 VALU roof of the same kernel is reported
+beside it (instructions per element and trial from the ISA, profiles/r02_isa_mix_*.json);
+``bound`` names the larger of the two fractions.  SURVEY 8d's per-iteration figure (40 B per
+element and ITERATION) divided by the same duration is ``equivalent_one_iteration_GBps``: what a
+one-iteration-per-pass kernel would have to sustain to match - it exceeds the HBM peak because
+the chain avoids that traffic, it is not a bandwidth.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 import warnings
@@ -33,7 +53,13 @@ N_PER_GPU = 10**8
 ALG_BYTES_PER_ELEM = 40          # per ITERATION: read x_k, x_{k-1}, d, c ; write x+   
 PASS_BYTES_PER_ELEM = 48         # per PASS with S > 1: the same four reads, two iterates written
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# fp64 vector roof: 256 CUs x 4 SIMDs x 16 lanes per cycle (a wave64 fp64 instruction issues in 4
+# cycles; 78.6 TFLOP/s = this x 2 flops per FMA x 2.4 GHz)
+FP64_LANES_PER_CYCLE = 256 * 4 * 16
+CLOCK_GHZ = 2.4
 LR, LAM = 0.45, 0.1
+PMC_PROFILE = "r02_pmc_traffic.json"
+ISA_PROFILE = "r02_isa_mix_trial_kernel_s{S}.json"
 
 
 def make_inputs(n, seed, device):
@@ -45,32 +71,38 @@ def make_inputs(n, seed, device):
     return d, c
 
 
-def measured_traffic(n, sub_iters):
-    """HBM bytes per trial-kernel launch from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
-    runs of this same command, gfx950 corrections applied).  None when no profile
-    for this n and chain length is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def _profile(name):
     try:
-        with open(path) as fh:
-            prof = json.load(fh)
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            return json.load(fh)
     except OSError:
         return None
-    if prof.get("n") != n or prof.get("sub_iters", 1) != sub_iters:
+
+
+def measured_traffic(n, sub_iters):
+    """HBM bytes per full-chain launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this same command, gfx950 corrections applied;
+    tools/profile_bench.sh).  None when no profile for this n and chain length is committed."""
+    prof = _profile(PMC_PROFILE)
+    if not prof or prof.get("n") != n or prof.get("sub_iters", 1) != sub_iters:
         return None
     return prof["hbm_bytes_per_launch"]
 
 
-def cpu_baseline(d, c, sample_n=10**7, iters=30):
-    """The oracle (NumPy restatement of the reference path) on the host cores,
-    on a bounded sample of the same workload.  Reported, never a target."""
+def valu_per_element_trial(sub_iters):
+    prof = _profile(ISA_PROFILE.format(S=sub_iters))
+    return None if not prof else prof.get("valu_per_element_trial")
+
+
+def cpu_baseline(d, c, iters=3):
+    """The oracle (NumPy restatement of the reference path) on the host cores, on the FULL
+    vectors of this workload (n = 1e8, 3 iterations).  Reported, never a target."""
     from oracle import cpu_ref, problems_ref as P
 
-    sample_n = min(sample_n, d.numel())
-    ds = d[:sample_n].cpu().numpy()
-    cs = c[:sample_n].cpu().numpy()
+    n = d.numel()
+    ds, cs = d.cpu().numpy(), c.cpu().numpy()
     ref = P.DiagQuadL1Ref(ds, cs, LAM)
-    x0 = np.zeros(sample_n)
+    x0 = np.zeros(n)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         t0 = time.perf_counter()
@@ -78,15 +110,13 @@ def cpu_baseline(d, c, sample_n=10**7, iters=30):
                                                  max_iter=iters)
         dt = time.perf_counter() - t0
     assert res.nit == iters
-    its = iters / dt
     return {
-        "value": its * sample_n / N_PER_GPU,
+        "value": iters / dt * (n / N_PER_GPU),
         "unit": "iterations/s (n=1e8)",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {sample_n:.0e} of 1e8 elements, {iters} FISTA iterations in {dt:.1f} s "
-                  f"({its:.3f} it/s at n={sample_n:.0e}), scaled by n to 1e8; elementwise NumPy is "
-                  f"single-threaded (host has {os.cpu_count()} cores)",
+        "sample": f"the same d, c (all {n:.0e} elements), first {iters} FISTA iterations from x0 = 0 in {dt:.1f} s; "
+                  f"elementwise NumPy is single-threaded (host has {os.cpu_count()} cores)",
     }
 
 
@@ -99,6 +129,10 @@ def main():
     ap.add_argument("--total-n", type=int, default=0,
                     help="strong scaling: total length of x, split evenly over the GPUs (e.g. 800000000, "
                          "BASELINE cfg5); overrides --n")
+    ap.add_argument("--min-seconds", type=float, default=0.6,
+                    help="repeat the W + K block until this much timed work has run (sustained clocks)")
+    ap.add_argument("--max-blocks", type=int, default=400)
+    ap.add_argument("--sub-iters", type=int, default=0, help="chain length S (0 = library default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket every trial kernel with HIP events (roofline becomes null); "
@@ -145,8 +179,9 @@ def main():
     d, c = make_inputs(n, seed=1 + rank, device="cuda")
     prob = DiagQuadL1(d, c, LAM, group=group)
     opts = dict(lr=LR, tol=0.0, tol_internal=1e-12, max_iter=max(W, 1), max_backtrack_iter=100, decay_rate=0.5,
-                nesterov=True, nesterov_ratio=(0, 0.25), deprecated=False)
-    run = NativeRun(prob, torch.zeros(n, dtype=torch.float64, device="cuda"), opts, timing=not args.no_kernel_events)
+                nesterov=True, nesterov_ratio=(0, 0.25), deprecated=False, sub_iters=args.sub_iters)
+    x0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    timing = not args.no_kernel_events
 
     def sync_all():
         torch.cuda.synchronize()
@@ -154,43 +189,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = NativeRun(prob, x0, opts, timing=timing)
     S = run.sub_iters
-    while W > 0 and run.status == _lib.ZF_RUNNING:   # warm-up: exactly W iterations, then MAXITER
-        run.advance((W - run.nit_seen + S - 1) // S)
-    run.solver.trial_kernel_ms()          # reset the event window after warm-up
-    nit0 = run.nit_seen
-    run.set_max_iter(nit0 + K)
-    sync_all()
-    t0 = time.perf_counter()
-    while run.status == _lib.ZF_RUNNING:   # a broken chain (rejected trial, lr halves :305) costs extra passes
-        # exactly the passes the remaining iterations need if no chain breaks (so that every
-        # launch counted below is a real pass); broken chains cost further rounds
-        run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S)
-        run.collect()
-    sync_all()
-    dt = time.perf_counter() - t0
-    assert run.status == _lib.ZF_MAXITER and run.nit_seen - nit0 == K, \
-        f"expected {K} accepted iterations, got {run.nit_seen - nit0} (status {run.status})"
-    ker_ms, ker_n = run.solver.trial_kernel_ms()
-    if args.no_kernel_events:
-        ker_ms, ker_n = float("nan"), None
-    iters_per_pass = None if ker_n is None else K / ker_n
-
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    blocks, full_ms, full_n, part_ms, part_n, passes = [], 0.0, 0, 0.0, 0, 0
+    timed = 0.0
+    while True:
+        while W > 0 and run.status == _lib.ZF_RUNNING:   # warm-up: exactly W iterations, then MAXITER
+            run.advance((W - run.nit_seen + S - 1) // S)
+        if timing:
+            run.solver.pass_stats()                      # reset the event window after warm-up
+        nit0 = run.nit_seen
+        run.set_max_iter(nit0 + K)
+        sync_all()
+        t0 = time.perf_counter()
+        while run.status == _lib.ZF_RUNNING:
+            # exactly the passes the remaining iterations need if no chain breaks; a rejected trial
+            # (lr halves, :305) costs further rounds
+            run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S)
+            run.collect()
+        sync_all()
+        dt = time.perf_counter() - t0
+        assert run.status == _lib.ZF_MAXITER and run.nit_seen - nit0 == K, \
+            f"expected {K} accepted iterations, got {run.nit_seen - nit0} (status {run.status})"
+        if timing:
+            (fm, fn), (pm, pn) = run.solver.pass_stats()
+            full_ms, full_n, part_ms, part_n = full_ms + fm * fn, full_n + fn, part_ms + pm * pn, part_n + pn
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        blocks.append(dt)
+        timed += dt
+        tiles = getattr(run.solver, "tiles_per_wg", None)
+        if timed >= args.min_seconds or len(blocks) >= args.max_blocks:   # (dt is the max over ranks: same decision everywhere)
+            break
+        run.solver.close()
+        run = NativeRun(prob, x0, opts, timing=timing)   # the same workload again, on a warmer device
+    dt = statistics.median(blocks)
+    passes = full_n + part_n
 
     if rank == 0:
-        # roofline.achieved, as SURVEY 8d defines it: ALGORITHMIC bytes of the iterations a launch
-        # completes (40 B per element and iteration) over the launch duration.  A pass that chains
-        # S iterations moves fewer bytes than that, so the figure can exceed the HBM peak; the
-        # bytes the pass really moves (48 B per element, PMC-checked) are reported beside it.
-        if iters_per_pass is None:
-            iters_per_pass = float("nan")
-        alg_bytes = ALG_BYTES_PER_ELEM * n * iters_per_pass
-        achieved = alg_bytes / (ker_ms * 1e-3) / 1e9
-        pass_bytes = (PASS_BYTES_PER_ELEM if S > 1 else ALG_BYTES_PER_ELEM) * n
         line = {
             "metric": f"fista_iterations_per_sec_n{args.total_n:.0e}_total" if args.total_n
                       else "fista_iterations_per_sec_n1e8_per_gpu_shard",
@@ -213,32 +251,63 @@ def main():
                 "n_per_gpu": n,
                 "n_total": args.total_n if args.total_n else n * world,
                 "iters_per_sec_full_problem": K / dt,
+                "timing": f"median of {len(blocks)} back-to-back blocks of W={W} untimed + K={K} timed iterations "
+                          f"(fresh solve each), {timed:.2f} s timed in total",
+                "blocks": len(blocks),
+                "ms_per_step_first_block": blocks[0] / K * 1e3,
+                "ms_per_step_median_block": dt / K * 1e3,
+                "ms_per_step_last_block": blocks[-1] / K * 1e3,
+                "ms_per_step_min_block": min(blocks) / K * 1e3,
                 "temporal_blocking_chain": S,
-                "passes": ker_n,
-                "iterations_per_pass": iters_per_pass,
-                "tiles_per_workgroup_autotuned": getattr(run.solver, "tiles_per_wg", None),
+                "passes_per_block": passes / len(blocks) if timing else None,
+                "full_chain_passes": full_n if timing else None,
+                "other_passes": part_n if timing else None,
+                "tiles_per_workgroup": tiles,
                 "parallelism": f"x sharded over {world} GPU(s); per-pass scalar pack all-gather"
                                if world > 1 else "single GPU",
             },
-            "roofline": {
-                "bound": "hbm",
+        }
+        if timing and (full_n or part_n):
+            # the dominant kernel on full-chain passes (every pass when S = 1)
+            ker_ms = full_ms / full_n if full_n else part_ms / part_n
+            pass_bytes = (PASS_BYTES_PER_ELEM if S > 1 else ALG_BYTES_PER_ELEM) * n
+            traffic = measured_traffic(n, S)
+            achieved = pass_bytes / (ker_ms * 1e-3) / 1e9
+            hbm_frac = achieved / HBM_PEAK_GBS
+            vpe = valu_per_element_trial(S)
+            valu_ms = valu_frac = None
+            if vpe:
+                valu_ms = vpe * n * S / (FP64_LANES_PER_CYCLE * CLOCK_GHZ * 1e9) * 1e3
+                valu_frac = valu_ms / ker_ms
+            bound = "hbm" if valu_frac is None or hbm_frac >= valu_frac else "fp64_valu"
+            line["roofline"] = {
+                "bound": bound,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n, S),
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                  "separate passes, bytes per launch)",
+                "frac": hbm_frac,
+                "traffic": traffic,
+                "traffic_source": f"profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                  "passes, bytes per full-chain launch)" if traffic else None,
                 "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}>",
                 "kernel_avg_ms": ker_ms,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_bytes_note": "40 B x n x iterations completed per launch (SURVEY 8d); "
-                                          "frac > 1 = the chain avoids HBM traffic the one-iteration pass needs",
-                "hbm_bytes_per_launch_model": pass_bytes,
-                "hbm_achieved": pass_bytes / (ker_ms * 1e-3) / 1e9,
-                "hbm_frac": pass_bytes / (ker_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            },
-        }
+                "kernel_launches_timed": full_n if full_n else part_n,
+                "bytes_per_launch": pass_bytes,
+                "bytes_note": "HBM bytes a full-chain pass moves: 4 streams read + 2 iterates written = 48 B per "
+                              "element (S > 1), 40 B for S = 1",
+                "fp64_valu": None if vpe is None else {
+                    "valu_instructions_per_element_trial": vpe,
+                    "source": "profiles/" + ISA_PROFILE.format(S=S),
+                    "min_ms_at_2.4GHz": valu_ms,
+                    "frac": valu_frac,
+                    "note": "VALU issue time of the chain at the nominal clock / measured duration; the clock "
+                            "drops under this load (power limit), so the real VALU fraction is higher",
+                },
+                "other_passes_avg_ms": part_ms / part_n if part_n else None,
+                "equivalent_one_iteration_GBps": ALG_BYTES_PER_ELEM * n * S / (ker_ms * 1e-3) / 1e9,
+                "equivalent_note": "40 B x n x S (SURVEY 8d's per-iteration bytes x iterations per pass) / duration: "
+                                   "not a bandwidth - the chain does not move those bytes",
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, c)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())

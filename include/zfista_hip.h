@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ZF_ABI_VERSION 1
+#define ZF_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------ */
 #define ZF_OK 0
@@ -46,6 +46,8 @@ extern "C" {
 
 #define ZF_PACK_LEN 8    /* doubles in one per-trial scalar pack */
 #define ZF_MAX_SUB_ITERS 8 /* packs per pass: a rank's pack buffer holds sub_iters x ZF_PACK_LEN doubles */
+#define ZF_MAX_LAG (2 * ZF_MAX_SUB_ITERS - 2) /* accepted iterations a solve may run ahead of its stored iterates */
+#define ZF_PEND_FLUSH (-1) /* zf_control.pend_status: materialise the lagging iterates, then keep running */
 #define ZF_TRACE_COLS 8  /* doubles per accepted iteration in the trace ring */
 #define ZF_RING 1024     /* capacity (iterations) of the trace and momentum rings */
 
@@ -82,12 +84,19 @@ typedef struct zf_control {
     int32_t ring_size;    /* x buffers: 3 (one iteration per pass) or 4                */
     int32_t sub_iters;    /* S: trials one pass chains in registers (temporal blocking) */
     int32_t prev;         /* which x buffer holds x_{k-1}                             */
-    /* plan of the next pass (written by the decide step, read by the trial kernel):
-     * plan_n trials chained on acceptance; from trial index cut_at on (cut_at >= 0) the step
-     * size is lr * decay_rate^ncuts - ncuts rejections already observed at that position */
-    int32_t plan_n;
-    int32_t cut_at;
-    int32_t ncuts;
+    /* Deferred materialisation (temporal blocking, csrc/zf_decide.h).  A pass stores only the last two
+     * iterates of its chain.  When a chain of fresh trials breaks after `a` acceptances (a rejection
+     * or a termination in the middle), those a iterations ARE accepted - counters, F_old, trace rows
+     * move on - but their iterates exist in no buffer: `lag` counts them, lag_lr[] keeps the step
+     * size each was accepted with, and the buffers `cur` / `prev` hold x_{nit-lag}, x_{nit-lag-1}.
+     * The next pass recomputes the lagging iterates element-wise in registers (no reductions: their
+     * decisions are known) and chains its fresh trials behind them.  pend_status != 0: the next
+     * pass only materialises (no fresh trials); afterwards status = pend_status (a final status
+     * reached while iterates were lagging) or, for ZF_PEND_FLUSH, the solve simply continues. */
+    int32_t lag;
+    int32_t pend_status;
+    int32_t reserved0;
+    double lag_lr[ZF_MAX_LAG];
 } zf_control;
 
 typedef struct zf_problem_desc {
@@ -156,8 +165,9 @@ int zf_decide_host(zf_control* ctl, const double* packs, double* trace);
  *   finalize      : fixed-order reduction of the partials -> one pack per trial
  *   decide        : per trial, in order: model value, acceptance, lr decay, termination,
  *                   trace row (:149-155,:298-305,:525); a chain that holds is committed
- *                   (buffer hand-over), one that breaks after >= 1 accepted trials is
- *                   planned again (zf_control.plan_n / cut_at / ncuts; csrc/zf_decide.h)
+ *                   (buffer hand-over); one that breaks after >= 1 accepted trials leaves those
+ *                   iterations accepted but not stored (zf_control.lag; csrc/zf_decide.h) and
+ *                   the next pass recomputes them in registers ahead of its fresh trials
  */
 int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, const zf_options* opt,
                      void* stream);
@@ -171,10 +181,14 @@ int zf_solver_set_beta(zf_solver* s, int64_t first, const double* beta_host, int
 /* world == 1: enqueue `steps` complete steps (trial+finalize+decide), no host sync; a step accepts
  * between 0 and sub_iters iterations, so poll before the device can be ZF_RING iterations ahead */
 int zf_solver_enqueue_steps(zf_solver* s, int64_t steps);
-/* after initialisation: time the trial kernel with 1, 2, 4 interleaved tiles per workgroup on
- * this device (dry runs: no control-block or iterate is modified) and keep the fastest; the
- * ranking is device-dependent.  ZF_TILES_PER_WG=<n> in the environment pins it instead. */
+/* after initialisation: fix the launch geometry (interleaved tiles per workgroup) of the trial
+ * kernel.  It is a function of n only - never of a timing measurement, the chain length or the
+ * device - because it decides the rounding of the reduced sums: the same problem takes the same
+ * decisions in every process.  ZF_TILES_PER_WG=<n> overrides it (experiments). */
 int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles);
+/* make the next step materialise iterates that lag behind the accepted count (zf_control.lag),
+ * so that buffers cur / prev hold x_k, x_{k-1} afterwards; stream-ordered, no-op without lag */
+int zf_solver_flush(zf_solver* s);
 /* world > 1: the two halves of a step; the caller gathers pack_local -> pack_all between them */
 int zf_solver_enqueue_trial(zf_solver* s);
 int zf_solver_enqueue_decide(zf_solver* s);
@@ -212,6 +226,10 @@ int zf_solver_get_x(zf_solver* s, double* x_host);
 int zf_solver_get_x_prev(zf_solver* s, double* x_host);
 int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev, const zf_control* saved);
 int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches);
+/* the same window split by the shape of the pass, which the kernel logs itself: out[0], out[1] = mean
+ * ms and count of full chains (sub_iters fresh trials, nothing replayed); out[2], out[3] = every other
+ * pass (shorter chains, replays, materialise-only).  Resets the window. */
+int zf_solver_pass_stats(zf_solver* s, double out4[4]);
 int zf_solver_set_timing(zf_solver* s, int32_t enabled);
 
 /* ---- vector kernels for opaque (Python) callbacks ------------------------

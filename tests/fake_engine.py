@@ -32,9 +32,9 @@ class FakeProblem:
 
 
 class FakeSolver:
-    """``options["sub_iters"] = S > 1`` makes a pass chain S trials the way the temporally
-    blocked kernel does (csrc/zf_kernels_step.h): same plan fields, same buffer hand-over,
-    only the last two iterates of a chain are kept."""
+    """``options["sub_iters"] = S > 1`` makes a pass chain S fresh trials the way the temporally
+    blocked kernel does (csrc/zf_kernels_step.h): lagging iterations are replayed first (no
+    sums), same buffer hand-over, only the last two iterates of a chain are kept."""
 
     def __init__(self, fields, options, problem, x0):
         self.lib = _lib.load()
@@ -51,7 +51,7 @@ class FakeSolver:
         c.nesterov, c.deprecated = options["nesterov"], options["deprecated"]
         c.need_grad, c.world, c.cur = 1, self.world, 0
         c.ring_size, c.sub_iters, c.prev = ring, sub, ring - 1
-        c.plan_n, c.cut_at, c.ncuts = sub, -1, 0
+        c.lag, c.pend_status = 0, 0
         self.ctl = c
         self.trace = np.zeros((_lib.ZF_RING, _lib.ZF_TRACE_COLS))
         self.beta = np.zeros(_lib.ZF_RING)
@@ -83,19 +83,31 @@ class FakeSolver:
         c.max_iter = max_iter
         if c.status == _lib.ZF_MAXITER and c.nit < max_iter:
             c.status = _lib.ZF_RUNNING
+        if c.pend_status == _lib.ZF_MAXITER and c.nit < max_iter:
+            c.pend_status = 0
+
+    def _fresh_len(self):
+        c = self.ctl
+        if c.pend_status != 0:
+            return 0
+        return max(1, min(self.sub_iters, 2 * self.sub_iters - 1 - c.lag, c.max_iter - c.nit))
 
     def _chain_packs(self):
-        """One pass: the planned chain of trials from (x_k, x_{k-1}); returns sub x 8 packs."""
+        """One pass: replay of the lagging iterations, then the fresh trials, from the stored
+        (x_{nit-lag}, x_{nit-lag-1}); returns sub x 8 packs (fresh trials only)."""
         c, p = self.ctl, self.p
         ref = P.DiagQuadL1Ref(p.d, p.c, p.lam)
-        n = max(1, min(c.plan_n if c.plan_n > 0 else 1, c.max_iter - c.nit))
-        lr_cut = c.lr
-        for _ in range(c.ncuts):
-            lr_cut = lr_cut * c.decay_rate
+        lag, nf = c.lag, self._fresh_len()
+        base = c.nit - lag
         xk, xo = self.xb[c.cur], self.xb[c.prev]
+        for i in range(lag):
+            beta = self.beta[(base + i) % _lib.ZF_RING] if c.nesterov else 0.0
+            y = xk + beta * (xk - xo) if c.nesterov else xk
+            xn = ref.prox_wsum_g(c.lag_lr[i], y - c.lag_lr[i] * ref.jac_f(y))
+            xo, xk = xk, xn
         packs = np.zeros((self.sub_iters, _lib.ZF_PACK_LEN))
-        for j in range(n):
-            lr = lr_cut if (c.cut_at >= 0 and j >= c.cut_at) else c.lr
+        for j in range(nf):
+            lr = c.lr
             beta = self.beta[(c.nit + j) % _lib.ZF_RING] if c.nesterov else 0.0
             y = xk + beta * (xk - xo) if c.nesterov else xk
             grad = ref.jac_f(y)
@@ -105,11 +117,17 @@ class FakeSolver:
                         np.max(np.abs(dx)) if dx.size else 0.0, 0.0, 0.0]
             xo, xk = xk, xn
         free = [i for i in range(c.ring_size) if i not in (c.cur, c.prev)]
-        if n == 1:
+        if lag + nf == 1:
             self.xb[free[0]] = xk
-        else:
+        elif lag + nf >= 2:
             self.xb[free[0]], self.xb[free[1]] = xo, xk
         return packs.reshape(-1)
+
+    def flush(self):
+        c = self.ctl
+        if c.status == _lib.ZF_RUNNING and c.lag > 0 and c.pend_status == 0:
+            c.pend_status = _lib.ZF_PEND_FLUSH
+        self.enqueue(1)
 
     def enqueue(self, steps):
         for _ in range(steps):

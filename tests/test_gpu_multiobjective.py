@@ -199,7 +199,7 @@ def test_generic_multiobjective_golden(m, golden):
 
 
 @pytest.mark.parametrize("tag", ["jos1_n1000_l1", "fds_n10_l1", "fds_n100_l1", "fds_n10_pos"])
-def test_native_dual_solver_full_solve(tag, golden, monkeypatch):
+def test_native_dual_solver_full_solve(tag, golden):
     """Opt-in native dual solver: same outer iteration count as the
     reference run and iterates within the accuracy of the reference's own dual solves."""
     from zfista_amd import minimize_proximal_gradient
@@ -207,11 +207,10 @@ def test_native_dual_solver_full_solve(tag, golden, monkeypatch):
     G = golden("g4_multiobjective.npz")
     make, _, kw = _cases()[tag]
     p = make()
-    monkeypatch.setenv("ZF_DUAL_SOLVER", "native")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         res = minimize_proximal_gradient(*p.callbacks(), G(f"{tag}.x0"), nesterov=True, tol=1e-5, max_iter=12,
-                                         return_all=True, **kw)
+                                         return_all=True, dual_solver="native", **kw)
     assert res.nit == int(G(f"{tag}.fista.nit"))
     for a, b in zip(res.allvecs, G(f"{tag}.fista.vecs")):
         assert rel_err(a, b) <= 2e-5

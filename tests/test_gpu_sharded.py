@@ -206,13 +206,12 @@ class _ThreadGroup:
 
 @pytest.mark.parametrize("case", ["jos1_l1", "fds_l1", "fds_box"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_multiobjective_threads(case, world, monkeypatch):
+def test_sharded_multiobjective_threads(case, world):
     import threading
 
-    if case.startswith("fds"):
-        # m = 3: the library's own simplex solver (a dozen dual evaluations per trial); SciPy's
-        # trust-constr needs 1e3 - 1e5 of them here, each an exchange between the rank threads
-        monkeypatch.setenv("ZF_DUAL_SOLVER", "native")
+    # m = 3: the library's own simplex solver (a dozen dual evaluations per trial); SciPy's
+    # trust-constr needs 1e3 - 1e5 of them here, each an exchange between the rank threads
+    solver = "native" if case.startswith("fds") else "scipy"
 
     from zfista_amd.problems import FDS, JOS1
 
@@ -224,7 +223,7 @@ def test_sharded_multiobjective_threads(case, world, monkeypatch):
         "fds_l1": lambda g: FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0, 1, 2], group=g),
         "fds_box": lambda g: FDS(n, bounds=(-1.5, 1.8), group=g),
     }[case]
-    kw = dict(lr=1.0 if case.startswith("jos1") else 1e-3, nesterov=True, tol=1e-9, max_iter=8)
+    kw = dict(lr=1.0 if case.startswith("jos1") else 1e-3, nesterov=True, tol=1e-9, max_iter=8, dual_solver=solver)
     x0 = np.random.default_rng(3).uniform(-1, 1, n)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

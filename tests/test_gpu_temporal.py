@@ -156,3 +156,22 @@ def test_set_max_iter_resumes_a_solve():
     assert np.array_equal(np.concatenate(rows), ref["rows"])
     assert np.array_equal(run.solver.get_x(), ref["x"])
     run.solver.close()
+
+
+def test_large_n_geometry_is_a_function_of_n_only():
+    """Above 4096 tiles the kernel runs several tiles per workgroup.  That geometry fixes the
+    rounding of the reduced sums, so it must not depend on the chain length (or on a timing
+    measurement, as it did in round 1): S = 1 and S = 8 give identical trace rows and iterates at
+    n = 9e6 too, and a second solve of the same problem repeats the first bit for bit."""
+    n = 9_000_001
+    prob = _pdiag(n, seed=4)
+    x0 = np.zeros(n)
+    opts = dict(lr=3.0, nesterov=True, tol=0.0, max_iter=29)   # backtracks first, then chains
+    ref = _run(prob, x0, opts, 1, chunk=64)
+    again = _run(prob, x0, opts, 8, chunk=64)
+    third = _run(prob, x0, opts, 8, chunk=3)
+    for r in (again, third):
+        assert (r["nit"], r["status"], r["lr"], r["F"], r["trials"]) == \
+            (ref["nit"], ref["status"], ref["lr"], ref["F"], ref["trials"])
+        assert np.array_equal(r["rows"], ref["rows"])
+        assert np.array_equal(r["x"], ref["x"])

@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--cfg", type=int, required=True)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dual-solver", default=os.environ.get("ZF_DUAL_SOLVER", "scipy"))
     a = ap.parse_args()
     import torch
 
@@ -127,17 +128,19 @@ def main():
         n = 10**6
         prob = FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0, 1, 2])
         x0 = np.random.default_rng(1).uniform(-2, 2, n)
-        native = os.environ.get("ZF_DUAL_SOLVER") == "native"
+        native = a.dual_solver in ("native", "device")
         K = a.steps if native else min(a.steps, 10)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            minimize_proximal_gradient(*prob.callbacks(), x0, lr=1e-7, nesterov=True, tol=0.0, max_iter=2)  # warm-up
+            minimize_proximal_gradient(*prob.callbacks(), x0, lr=1e-7, nesterov=True, tol=0.0, max_iter=2,
+                                       dual_solver=a.dual_solver)  # warm-up
             prob._engine().n_dual_evals = 0
             t0 = time.perf_counter()
-            res = minimize_proximal_gradient(*prob.callbacks(), x0, lr=1e-7, nesterov=True, tol=0.0, max_iter=K)
+            res = minimize_proximal_gradient(*prob.callbacks(), x0, lr=1e-7, nesterov=True, tol=0.0, max_iter=K,
+                                             dual_solver=a.dual_solver)
             dt = time.perf_counter() - t0
         ev = prob._engine().n_dual_evals
-        r = dict(workload="cfg4 FDS m=3 n=1e6 + l1, lr=1e-7, dual solver: " + ("native simplex Newton" if native else
+        r = dict(workload="cfg4 FDS m=3 n=1e6 + l1, lr=1e-7, dual solver: " + (a.dual_solver + " (library simplex Newton)" if native else
                                                                                    "SciPy trust-constr (reference)"),
                  iterations=int(res.nit), seconds=dt,
                  it_per_s=res.nit / dt, dual_evals=ev, dual_evals_per_s=ev / dt,

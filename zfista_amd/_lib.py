@@ -14,13 +14,17 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libzfista_hip.so")
+# ZF_LIB_PATH: load another build of the same sources (kernel-variant experiments, tools/)
+LIB_PATH = os.environ.get("ZF_LIB_PATH") or os.path.join(CSRC, "libzfista_hip.so")
 
 ZF_OK = 0
 ZF_RUNNING, ZF_CONVERGED, ZF_MAXITER, ZF_BACKTRACK_FAILED = 0, 1, 2, 3
 ZF_PROBLEM_DIAG_QUAD_L1, ZF_PROBLEM_LEAST_SQUARES_L1 = 1, 2
 ZF_MO_GENERIC, ZF_MO_JOS1, ZF_MO_FDS = 0, 1, 2
 ZF_PACK_LEN, ZF_TRACE_COLS, ZF_RING = 8, 8, 1024
+ZF_MAX_SUB_ITERS = 8
+ZF_MAX_LAG = 2 * ZF_MAX_SUB_ITERS - 2
+ZF_PEND_FLUSH = -1
 TR_ERR, TR_F, TR_LR, TR_FUN, TR_TRIALS, TR_FX, TR_GX, TR_FY = range(8)
 PK_FY, PK_DOT, PK_SS, PK_GX, PK_FX, PK_ERR = range(6)
 
@@ -46,7 +50,8 @@ class Control(C.Structure):
         ("deprecated", C.c_int32), ("need_grad", C.c_int32), ("world", C.c_int32),
         ("beta_next", C.c_double),
         ("ring_size", C.c_int32), ("sub_iters", C.c_int32), ("prev", C.c_int32),
-        ("plan_n", C.c_int32), ("cut_at", C.c_int32), ("ncuts", C.c_int32),
+        ("lag", C.c_int32), ("pend_status", C.c_int32), ("reserved0", C.c_int32),
+        ("lag_lr", C.c_double * ZF_MAX_LAG),
     ]
 
 
@@ -90,6 +95,7 @@ SIGNATURES = {
     "zf_solver_set_beta": (C.c_int, [_P, C.c_int64, _P, C.c_int64]),
     "zf_solver_enqueue_steps": (C.c_int, [_P, C.c_int64]),
     "zf_solver_autotune": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "zf_solver_flush": (C.c_int, [_P]),
     "zf_solver_enqueue_trial": (C.c_int, [_P]),
     "zf_solver_enqueue_decide": (C.c_int, [_P]),
     "zf_solver_sub_iters": (C.c_int, [_P, C.POINTER(C.c_int32)]),
@@ -107,6 +113,7 @@ SIGNATURES = {
     "zf_solver_restore": (C.c_int, [_P, _P, _P, C.POINTER(Control)]),
     "zf_solver_trial_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "zf_solver_set_timing": (C.c_int, [_P, C.c_int32]),
+    "zf_solver_pass_stats": (C.c_int, [_P, _P]),
     "zf_host_grad_step": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64]),
     "zf_host_model_terms": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "zf_host_momentum": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64]),

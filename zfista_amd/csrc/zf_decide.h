@@ -12,21 +12,23 @@
 // is built with -ffp-contract=off) so the branch decisions are the ones NumPy
 // scalars would take on the same reduced sums.
 //
-// Temporal blocking (separable f): one pass of the trial kernel chains up to S trials in
-// registers, each assuming the previous one was accepted, and stores only the last two
-// iterates of the chain.  zf_decide_pass() examines the S packs in order on a COPY of the
-// control block.  If the whole chain holds, the copy is committed.  If the chain breaks at
-// trial a (a rejection, or a termination before the last trial):
-//   a == 0  -> nothing of the chain was accepted: the rejection itself (lr decay, trial
-//              counters, possibly failure) is committed;
-//   a  > 0  -> the a accepted iterates were never stored, so nothing is committed; the PLAN of
-//              the next pass is set instead: the same a trials again (same inputs, same sums,
-//              same decisions), followed - after a rejection - by trials at the reduced step
-//              size, or - after a termination - by nothing.
-// Either way every committed state is one the one-trial-per-pass loop passes through, with the
-// same sums: results do not depend on S.
+// Temporal blocking (separable f): one pass of the trial kernel chains up to S FRESH trials in
+// registers, each assuming the previous one was accepted, and stores only the last two iterates
+// of the chain.  zf_decide_pass() examines the fresh packs in order.  If the whole chain holds,
+// the stored pair becomes (x_k, x_{k-1}).  If the chain breaks after `a` acceptances (a
+// rejection, or a termination before the last fresh trial), the a iterations are accepted all
+// the same - counters, F_old, lr, trace rows advance exactly as in the one-trial-per-pass loop -
+// but their iterates were not stored: ctl->lag += a and ctl->lag_lr[] records the step size of
+// each.  The next pass REPLAYS the lagging iterations element-wise (no reductions, their
+// decisions are known; 11 flops per element instead of 20) and chains its fresh trials behind
+// them, so a broken chain costs some arithmetic in the next pass, not a pass over the data.
+// A final status reached while iterates lag is held back in ctl->pend_status for one
+// replay-only pass that materialises x_k.  lag + fresh <= 2 S - 1 bounds every chain.
+// Every decision is taken on exactly the sums a one-trial pass would have produced: results do
+// not depend on S.
 #pragma once
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/zfista_hip.h"
@@ -68,22 +70,18 @@ ZF_HD inline void zf_free_bufs(int cur, int prev, int ring, int* first, int* sec
     *second = (m > 1) ? f[1] : f[0];
 }
 
-// trials of the next pass: the plan, bounded by the iterations left (:539)
-ZF_HD inline int zf_plan_len(const zf_control* c) {
-    int64_t n = c->plan_n > 0 ? c->plan_n : 1;
+// FRESH trials of the next pass: S, bounded by the chain capacity 2 S - 1 (lagging iterations are
+// replayed in front of them), by the iterations left (:539), and 0 for a materialise-only pass
+ZF_HD inline int zf_fresh_len(const zf_control* c) {
+    if (c->pend_status != 0) return 0;
+    const int sub = c->sub_iters > 0 ? c->sub_iters : 1;
+    int64_t n = sub;
+    const int64_t cap = (int64_t)(2 * sub - 1) - c->lag;
+    if (n > cap) n = cap;
     const int64_t left = c->max_iter - c->nit;
     if (n > left) n = left;
     if (n < 1) n = 1;
     return (int)n;
-}
-
-// a rejection observed by an earlier pass at this position of the chain (:305-307)
-ZF_HD inline void zf_apply_known_reject(zf_control* c) {
-    c->trial += 1;
-    c->total_trials += 1;
-    c->lr = c->lr * c->decay_rate;
-    c->need_grad = 0;
-    if (c->trial >= c->max_backtrack) c->status = ZF_BACKTRACK_FAILED;
 }
 
 // The floating-point part of one trial: model value, F(x+) and the acceptance test for a given
@@ -160,8 +158,9 @@ ZF_HD inline bool zf_apply_trial(zf_control* c, const zf_trial_eval* e, double* 
 
 // y_{k+1} = x_k + beta (x_k - x_{k-1})  (:533-534): the factor of the trial that follows the
 // accepted-iteration count now in the block
+// (with lagging iterations the first trial of the next pass is the replay of iteration nit - lag + 1)
 ZF_HD inline void zf_resolve_beta(zf_control* c, const double* beta_ring) {
-    if (beta_ring) c->beta_next = beta_ring[c->nit % ZF_RING];
+    if (beta_ring) c->beta_next = beta_ring[(c->nit - c->lag) % ZF_RING];
 }
 
 // One trial against the control block *c (buffer indices are not touched: the caller commits
@@ -189,80 +188,76 @@ ZF_HD inline bool zf_decide_one(zf_control* c, const double* packs, double* trac
     return go;
 }
 
+// write back a control block examined on a copy: everything but lag_lr[], whose entries are
+// written in place (indexing the copy dynamically would push the whole block to scratch memory)
+ZF_HD inline void zf_store_head(zf_control* dst, const zf_control* src) {
+    __builtin_memcpy(dst, src, offsetof(zf_control, lag_lr));
+}
+
+// the stored pair of a chain of `ntr` trials run from (cur0, prev0) becomes (x_k, x_{k-1}) (:538)
+ZF_HD inline void zf_commit_chain(zf_control* c, int cur0, int prev0, int ring, int ntr) {
+    int first, second;
+    zf_free_bufs(cur0, prev0, ring, &first, &second);
+    if (ntr == 1) {
+        c->prev = cur0;
+        c->cur = first;
+    } else {
+        c->prev = first;
+        c->cur = second;
+    }
+}
+
 // All trials of one pass.  packs: world x sub_iters x ZF_PACK_LEN (rank-major), pack j of a
-// rank = trial j of the chain.
-// `pre` (optional): sub_iters evaluations made in advance, one per trial of the chain.
+// rank = FRESH trial j of the chain (the replayed trials in front of them emit nothing).
+// `pre` (optional): sub_iters evaluations made in advance, one per fresh trial.
 ZF_HD inline void zf_decide_pass(zf_control* ctl, const double* packs, double* trace,
                                  const double* beta_ring = nullptr, const zf_trial_eval* pre = nullptr) {
     if (ctl->status != ZF_RUNNING) return;
     const int sub = ctl->sub_iters > 0 ? ctl->sub_iters : 1;
     const int ring = ctl->ring_size > 0 ? ctl->ring_size : 3;
     const int stride = sub * ZF_PACK_LEN;
-    const int n = zf_plan_len(ctl);
-    const int cut_at = ctl->cut_at, ncuts = ctl->ncuts;
-
-    zf_control c = *ctl;   // the chain is examined on a copy
+    const int lag = ctl->lag;
+    zf_control c = *ctl;   // examined on a copy, written back once
+    if (ctl->pend_status != 0) {
+        // the pass only materialised the lagging iterates: they are x_k, x_{k-1} now
+        if (lag > 0) zf_commit_chain(&c, ctl->cur, ctl->prev, ring, lag);
+        c.lag = 0;
+        if (c.pend_status > 0) c.status = c.pend_status;
+        c.pend_status = 0;
+        zf_resolve_beta(&c, beta_ring);
+        zf_store_head(ctl, &c);
+        return;
+    }
+    const int nf = zf_fresh_len(ctl);
     int accepted = 0;
-    bool rejected = false;
-    for (int j = 0; j < n; ++j) {
-        if (j == cut_at) {
-            for (int r = 0; r < ncuts && c.status == ZF_RUNNING; ++r) zf_apply_known_reject(&c);
-            if (c.status != ZF_RUNNING) break;
-        }
+    for (int j = 0; j < nf; ++j) {
         const int64_t before = c.nit;
+        const double lr_used = c.lr;
         const bool go = zf_decide_step(&c, packs + j * ZF_PACK_LEN, trace, beta_ring, stride, pre ? pre + j : nullptr);
-        if (c.nit > before) accepted += 1;
-        else rejected = true;
+        if (c.nit > before) {
+            if (lag + accepted < ZF_MAX_LAG) ctl->lag_lr[lag + accepted] = lr_used;
+            accepted += 1;
+        }
         if (!go) break;
     }
-
-    c.plan_n = sub;
-    c.cut_at = -1;
-    c.ncuts = 0;
-    if (accepted == n) {
-        // the whole chain holds: its last two iterates are what the pass stored (:538)
-        if (cut_at >= n && c.status == ZF_RUNNING)
-            for (int r = 0; r < ncuts && c.status == ZF_RUNNING; ++r) zf_apply_known_reject(&c);
-        int first, second;
-        zf_free_bufs(ctl->cur, ctl->prev, ring, &first, &second);
-        if (n == 1) {
-            c.prev = ctl->cur;
-            c.cur = first;
-        } else {
-            c.prev = first;
-            c.cur = second;
+    if (accepted == nf) {
+        // the whole chain holds: its last two iterates are what the pass stored
+        zf_commit_chain(&c, ctl->cur, ctl->prev, ring, lag + nf);
+        c.lag = 0;
+    } else {
+        // broken after `accepted` fresh trials: accepted, not stored
+        c.lag = lag + accepted;
+        if (c.status != ZF_RUNNING && c.lag > 0) {   // final status: first materialise x_k
+            c.pend_status = c.status;
+            c.status = ZF_RUNNING;
         }
-        zf_resolve_beta(&c, beta_ring);
-        *ctl = c;
-        return;
     }
-    if (accepted == 0) {
-        // the first trial of the chain failed: x_k, x_{k-1} unchanged, the rejection stands
-        *ctl = c;
-        return;
-    }
-    // 0 < accepted < n: the accepted iterates exist in no buffer.  Plan the pass again.
-    const bool keep_cut = (cut_at >= 0 && cut_at < accepted);
-    int plan_n = accepted, new_cut = keep_cut ? cut_at : -1, new_ncuts = keep_cut ? ncuts : 0;
-    if (rejected && c.status == ZF_RUNNING) {
-        if (cut_at == accepted) {            // rejected again at the same position
-            plan_n = sub;
-            new_cut = accepted;
-            new_ncuts = ncuts + 1;
-        } else if (!keep_cut) {              // first rejection of this chain
-            plan_n = sub;
-            new_cut = accepted;
-            new_ncuts = 1;
-        }
-        // else: a second cut position - stop exactly before it; the next pass meets it as trial 0
-    }
-    ctl->plan_n = plan_n;
-    ctl->cut_at = new_cut;
-    ctl->ncuts = new_ncuts;
+    zf_resolve_beta(&c, beta_ring);
+    zf_store_head(ctl, &c);
 }
 
 #if defined(__HIPCC__)
-// Device: the decide pass of one wave.  Trial j of the chain is evaluated by lane j * lstr
+// Device: the decide pass of one wave.  Fresh trial j of the chain is evaluated by lane j * lstr
 // (sqrt, divisions and the acceptance test cost a few thousand cycles on a single lane; the S of
 // them run side by side) and left in LDS; lane 0 then walks the chain with the evaluations at hand.
 // `pk`: the pack of this lane's trial, already reduced over ranks (other lanes: ignored);
@@ -274,10 +269,7 @@ __device__ __forceinline__ void zf_decide_pass_wave(zf_control* ctl, const doubl
                                                     zf_trial_eval* lds_pre) {
     if (ctl->status != ZF_RUNNING) return;
     const int trial = lane / lstr;
-    const int cut_at = ctl->cut_at, ncuts = ctl->ncuts;
-    double lr = ctl->lr;
-    if (cut_at >= 0 && trial >= cut_at)
-        for (int r = 0; r < ncuts; ++r) lr = lr * ctl->decay_rate;   // :305 per known rejection
+    const double lr = ctl->lr;   // every fresh trial of a chain assumes the current step size
     const double F_x_mine = pk[ZF_PK_FX] + pk[ZF_PK_GX];               // :295
     const double F_x_prev = __shfl_up(F_x_mine, lstr, 64);
     const double F_old = (trial == 0) ? ctl->F_old : F_x_prev;

@@ -26,6 +26,14 @@ struct zf_elem_acc {
 };
 
 // --- element bodies --------------------------------------------------------
+// The ITERATE arithmetic (y, grad, v, x+) is NumPy's, operation by operation, never contracted:
+// x+ is bit-identical to the reference expression.  The six REDUCTIONS feed only the scalar
+// decisions; their terms are accumulated with fused multiply-adds (one rounding instead of two
+// per term - at least as accurate as the NumPy sums, whose order they do not share anyway):
+//   f(y)  = 1/2 sum (d r) r   with grad = d r already at hand      (NumPy: d * (r * r))
+//   f(x+) = 1/2 sum (d rn) rn  - the same formula, so f(y_{k+1}) == f(x_{k+1}) bit for bit
+//           whenever y_{k+1} == x_{k+1} (no momentum), as with one f callback
+// 20 fp64 operations per element and trial (25 unfused).
 template <bool NESTEROV, bool BOX>
 __device__ __forceinline__ double zf_elem_diag(double xk, double xo, double d, double c, double beta,
                                                double lr, double tau, double lo, double hi,
@@ -34,17 +42,31 @@ __device__ __forceinline__ double zf_elem_diag(double xk, double xo, double d, d
     if (NESTEROV) y = xk + beta * (xk - xo);
     const double r = y - c;
     const double grad = d * r;          // jac_f = d * (y - c)
-    a.fy += d * (r * r);                // f = 0.5 * sum(d * (r*r))
+    a.fy = __builtin_fma(grad, r, a.fy);
     const double v = y - lr * grad;
     double xn = zf_soft_threshold_nn(v, tau);
     if (BOX) xn = zf_clip(xn, lo, hi);
     const double dx = xn - y;
-    a.dot += grad * dx;
-    a.ss += dx * dx;
+    a.dot = __builtin_fma(grad, dx, a.dot);
+    a.ss = __builtin_fma(dx, dx, a.ss);
     a.l1 += fabs(xn);
     const double rn = xn - c;
-    a.fx += d * (rn * rn);
+    a.fx = __builtin_fma(d * rn, rn, a.fx);
     a.mx = fmax(a.mx, fabs(dx));
+    return xn;
+}
+
+// the same iterate arithmetic without the reductions: an iteration whose decision is already
+// known is recomputed ("replayed") in registers - 11 fp64 operations
+template <bool NESTEROV, bool BOX>
+__device__ __forceinline__ double zf_elem_diag_replay(double xk, double xo, double d, double c, double beta,
+                                                      double lr, double tau, double lo, double hi) {
+    double y = xk;
+    if (NESTEROV) y = xk + beta * (xk - xo);
+    const double grad = d * (y - c);
+    const double v = y - lr * grad;
+    double xn = zf_soft_threshold_nn(v, tau);
+    if (BOX) xn = zf_clip(xn, lo, hi);
     return xn;
 }
 
@@ -57,8 +79,8 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
     double xn = zf_soft_threshold_nn(v, tau);
     if (BOX) xn = zf_clip(xn, lo, hi);
     const double dx = xn - y;
-    a.dot += grad * dx;
-    a.ss += dx * dx;
+    a.dot = __builtin_fma(grad, dx, a.dot);
+    a.ss = __builtin_fma(dx, dx, a.ss);
     a.l1 += fabs(xn);
     a.mx = fmax(a.mx, fabs(dx));
     return xn;
@@ -128,6 +150,8 @@ struct zf_step_args {
     int64_t n;
     int tiles_per_wg;         // interleaved tiles per workgroup (1 .. ZF_MAX_TILES_PER_WG)
     double* blk_part;         // (S * ZF_NPART) x gridDim.x per-workgroup partials, quantity-major
+    int* pass_log;            // timing only (else NULL): slot pass_slot receives (lag << 8) | fresh trials
+    int pass_slot;
 };
 
 struct zf_finalize_args {
@@ -276,46 +300,41 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 // GRAD_INLINE: true  -> separable quadratic, gradient computed from d, c
 //              false -> gradient vector read from HBM (least squares; S = 1 only)
 // NT: nontemporal policy for the once-touched streams (p0, p1 loads, x+ stores)
-// S:  trials chained per pass (temporal blocking).  For a separable f the whole recursion
+// S:  FRESH trials chained per pass (temporal blocking).  For a separable f the whole recursion
 //     x_{k+1} = prox(y_k - lr grad f(y_k)), y_{k+1} = x_{k+1} + beta_{k+1} (x_{k+1} - x_k)
 //     is elementwise, so one pass over x_k, x_{k-1}, d, c can run the next S iterations of an
 //     element in registers (each assuming the one before was accepted), emit the six reductions
 //     of EVERY trial and store only the last two iterates of the chain: 48 bytes per element
 //     for S iterations instead of 40 S.  zf_decide_pass (zf_decide.h) then examines the S
 //     acceptance / termination tests in order on exactly the sums a one-trial pass would have
-//     produced; a chain that breaks in the middle is planned again up to the break (ctl->plan_n)
-//     and continued at the reduced step size (ctl->cut_at, ctl->ncuts), so iterates, traces and
-//     decisions are bit-identical to S = 1 (tests/test_gpu_temporal.py).
-// FULL: the chain is S trials long (known at compile time: no per-trial branch); otherwise the
-// planned length ctl->plan_n < S is honoured trial by trial (replays, the last pass before max_iter)
+//     produced.  Iterations accepted by an earlier pass whose iterates were not stored (a chain
+//     that broke in the middle: ctl->lag of them, step sizes ctl->lag_lr[]) are REPLAYED first,
+//     without reductions, and the fresh trials follow at the current step size; iterates, traces
+//     and decisions are bit-identical to S = 1 (tests/test_gpu_temporal.py).
+// FULL: no lagging iterations and S fresh trials (known at compile time: no per-trial branch);
+// otherwise `lag` replayed + `nf` < = S fresh trials, trial by trial
 template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool FULL>
-__device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds, const int ntr) {
+__device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds, const int lag, const int nf) {
     const int cur = A.ctl->cur;
     const int prev = A.ctl->prev;
     const int ring = A.ctl->ring_size;
     const double lr = A.ctl->lr;
-    double beta[S], lrj[S], tau[S];
-    beta[0] = NESTEROV ? A.ctl->beta_next : 0.0;   // same cache line as status / cur / lr
-    lrj[0] = lr;
-    if (S > 1) {
-        const int64_t nit = A.ctl->nit;
-        const int cut_at = A.ctl->cut_at, ncuts = A.ctl->ncuts;
-        double lr_cut = lr;
-        for (int r = 0; r < ncuts; ++r) lr_cut = lr_cut * A.ctl->decay_rate;   // :305, once per known rejection
+    const int ntr = FULL ? S : lag + nf;   // chain length: iterates x_{b+1} .. x_{b+ntr} from (x_b, x_{b-1})
+    double beta[S];
+    const int64_t nit = A.ctl->nit;
+    const int64_t base = nit - lag;        // iteration count the stored iterates belong to
+    // momentum factor of the trial that produces iteration i + 1: ring[i % ZF_RING]; that of the
+    // first trial of the pass was resolved into the control block by the previous decide step
+    beta[0] = NESTEROV ? ((FULL || lag == 0) ? A.ctl->beta_next : A.beta_ring[nit % ZF_RING]) : 0.0;
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
-            if (j > 0) beta[j] = NESTEROV ? A.beta_ring[(nit + j) % ZF_RING] : 0.0;
-            lrj[j] = (cut_at >= 0 && j >= cut_at) ? lr_cut : lr;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < S; ++j) tau[j] = A.lam * lrj[j];   // oracle: soft_threshold(x, lam * weight)
+    for (int j = 1; j < S; ++j) beta[j] = NESTEROV ? A.beta_ring[(nit + j) % ZF_RING] : 0.0;
+    const double tau = A.lam * lr;   // oracle: soft_threshold(x, lam * weight)
     int first, second;
     zf_free_bufs(cur, prev, ring, &first, &second);
     const double* __restrict__ xk = A.xb[cur];
     const double* __restrict__ xo = A.xb[prev];
-    double* __restrict__ out_last = A.xb[ntr == 1 ? first : second];   // x_{k+ntr}
-    double* __restrict__ out_prev = A.xb[first];                       // x_{k+ntr-1} when ntr >= 2
+    double* __restrict__ out_last = A.xb[ntr == 1 ? first : second];   // x_{b+ntr}
+    double* __restrict__ out_prev = A.xb[first];                       // x_{b+ntr-1} when ntr >= 2
     const double* __restrict__ p0 = A.p0;
     const double* __restrict__ p1 = A.p1;
     const int64_t n = A.n;
@@ -329,18 +348,18 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     const zf_d2* __restrict__ p02 = reinterpret_cast<const zf_d2*>(p0);
     const zf_d2* __restrict__ p12 = reinterpret_cast<const zf_d2*>(p1);
 
-    // one 16-byte unit through the chain (a = x_k, o = x_{k-1} on entry)
+    // one 16-byte unit through the fresh trials (a = x_nit, o = x_{nit-1} on entry)
     auto advance = [&](zf_d2 a, zf_d2 o, zf_d2 q, zf_d2 cc, int64_t i) {
 #pragma unroll
         for (int j = 0; j < S; ++j) {
-            if (FULL || j < ntr) {
+            if (FULL || j < nf) {
                 zf_d2 r;
                 if (GRAD_INLINE) {
-                    r.x = zf_elem_diag<NESTEROV, BOX>(a.x, o.x, q.x, cc.x, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
-                    r.y = zf_elem_diag<NESTEROV, BOX>(a.y, o.y, q.y, cc.y, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
+                    r.x = zf_elem_diag<NESTEROV, BOX>(a.x, o.x, q.x, cc.x, beta[j], lr, tau, A.lo, A.hi, acc[j]);
+                    r.y = zf_elem_diag<NESTEROV, BOX>(a.y, o.y, q.y, cc.y, beta[j], lr, tau, A.lo, A.hi, acc[j]);
                 } else {
-                    r.x = zf_elem_vec<NESTEROV, BOX>(a.x, o.x, q.x, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
-                    r.y = zf_elem_vec<NESTEROV, BOX>(a.y, o.y, q.y, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
+                    r.x = zf_elem_vec<NESTEROV, BOX>(a.x, o.x, q.x, beta[j], lr, tau, A.lo, A.hi, acc[j]);
+                    r.y = zf_elem_vec<NESTEROV, BOX>(a.y, o.y, q.y, beta[j], lr, tau, A.lo, A.hi, acc[j]);
                 }
                 o = a;
                 a = r;
@@ -355,15 +374,13 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
 
     // Workgroup b owns tiles b, b + G, b + 2G, ... (G = gridDim.x, A.tiles_per_wg of them):
     // interleaved, so that at any time the resident workgroups still cover one contiguous window
-    // of every stream (consecutive tiles per workgroup measured 4-8 % slower).  Which T wins is
-    // device-dependent (T = 4: -1 % on some MI355X boxes, +7 % on others, against T = 1), so the
-    // solver measures it once at initialisation (zf_solver_autotune); T = 1 otherwise.
+    // of every stream (consecutive tiles per workgroup measured 4-8 % slower).
     const int64_t full_tiles = n2 / ZF_TILE_UNITS;
     const int64_t G = gridDim.x;
     for (int t = 0; t < A.tiles_per_wg; ++t) {
         const int64_t tile = (int64_t)t * G + blockIdx.x;
         if (tile >= full_tiles) break;
-        const int64_t base = tile * ZF_TILE_UNITS + threadIdx.x;
+        const int64_t base_u = tile * ZF_TILE_UNITS + threadIdx.x;
         // UB units are loaded, then computed, at a time (16 loads in flight per thread at UB = 4)
         constexpr int UB = (S >= 8) ? ZF_S8_UB : ZF_TILE_U;
 #pragma unroll
@@ -371,7 +388,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
             zf_d2 a[UB], o[UB], q[UB], cc[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int64_t i = base + (u0 + u) * ZF_BLOCK;
+                const int64_t i = base_u + (u0 + u) * ZF_BLOCK;
                 a[u] = zf_ld2<NT && (ZF_X_NT != 0) && (S > 1)>(xk2 + i);
                 o[u] = a[u];
                 if (NESTEROV) o[u] = zf_ld2<NT && (ZF_X_NT != 0) && (S > 1)>(xo2 + i);
@@ -382,8 +399,25 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
             // keep all loads of the batch in flight: without this fence the scheduler sinks the
             // last ones below the first arithmetic to save registers
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!FULL && GRAD_INLINE) {
+                // replay of the lagging iterations: trial-outer, unit-inner - 2 UB independent
+                // element recursions per step, parameters are wave-uniform scalar loads
+                for (int i = 0; i < lag; ++i) {
+                    const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
+                    const double lr_i = A.ctl->lag_lr[i];
+                    const double tau_i = A.lam * lr_i;
 #pragma unroll
-            for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], base + (u0 + u) * ZF_BLOCK);
+                    for (int u = 0; u < UB; ++u) {
+                        zf_d2 r;
+                        r.x = zf_elem_diag_replay<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, cc[u].x, b_i, lr_i, tau_i, A.lo, A.hi);
+                        r.y = zf_elem_diag_replay<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, cc[u].y, b_i, lr_i, tau_i, A.lo, A.hi);
+                        o[u] = a[u];
+                        a[u] = r;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], base_u + (u0 + u) * ZF_BLOCK);
         }
     }
     // remainder of the vector (less than one tile, including an odd last element): element by
@@ -393,13 +427,22 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
         for (int64_t e = rem0 + threadIdx.x; e < n; e += ZF_BLOCK) {
             double a = xk[e], o = NESTEROV ? xo[e] : a;
             const double q = p0[e], cc = GRAD_INLINE ? p1[e] : q;
+            if constexpr (!FULL && GRAD_INLINE) {
+                for (int i = 0; i < lag; ++i) {
+                    const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
+                    const double lr_i = A.ctl->lag_lr[i];
+                    const double r = zf_elem_diag_replay<NESTEROV, BOX>(a, o, q, cc, b_i, lr_i, A.lam * lr_i, A.lo, A.hi);
+                    o = a;
+                    a = r;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < S; ++j) {
-                if (FULL || j < ntr) {
+                if (FULL || j < nf) {
                     double r;
                     if (GRAD_INLINE)
-                        r = zf_elem_diag<NESTEROV, BOX>(a, o, q, cc, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
-                    else r = zf_elem_vec<NESTEROV, BOX>(a, o, q, beta[j], lrj[j], tau[j], A.lo, A.hi, acc[j]);
+                        r = zf_elem_diag<NESTEROV, BOX>(a, o, q, cc, beta[j], lr, tau, A.lo, A.hi, acc[j]);
+                    else r = zf_elem_vec<NESTEROV, BOX>(a, o, q, beta[j], lr, tau, A.lo, A.hi, acc[j]);
                     o = a;
                     a = r;
                 }
@@ -409,7 +452,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
         }
     }
 
-    // workgroup partials of every trial of the chain: rows j * ZF_NPART + k.  All 6 S wave
+    // workgroup partials of every fresh trial of the chain: rows j * ZF_NPART + k.  All 6 S wave
     // reductions run as ONE transposing butterfly (zf_wave_reduce_multi: same pairing, hence the
     // same bits, as a butterfly per quantity), then the four wave totals are added in wave order.
     constexpr int H = (S >= 8) ? 3 : (S >= 4) ? 2 : (S >= 2) ? 1 : 0;
@@ -452,11 +495,14 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     // wave-uniform control reads (scalar loads); written by the previous step's decide
     if (A.ctl->status != ZF_RUNNING) return;
     if (S == 1) {
-        zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, true>(A, lds, 1);
+        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = 1;
+        zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, true>(A, lds, 0, 1);
     } else {
-        const int ntr = zf_plan_len(A.ctl);   // trials of this chain
-        if (ntr == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, true>(A, lds, S);
-        else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, false>(A, lds, ntr);
+        const int lag = A.ctl->lag;
+        const int nf = zf_fresh_len(A.ctl);   // fresh trials of this chain (0: materialise only)
+        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = (lag << 8) | nf;
+        if (lag == 0 && nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, true>(A, lds, 0, S);
+        else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, false>(A, lds, lag, nf);
     }
 }
 

@@ -55,11 +55,18 @@ __global__ void zf_set_max_iter_kernel(zf_control* ctl, int64_t max_iter) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     ctl->max_iter = max_iter;
     if (ctl->status == ZF_MAXITER && ctl->nit < max_iter) ctl->status = ZF_RUNNING;
+    if (ctl->pend_status == ZF_MAXITER && ctl->nit < max_iter) ctl->pend_status = 0;   // keep going instead
+}
+
+// ask the next pass to materialise lagging iterates (x_k, x_{k-1} into buffers) and nothing else
+__global__ void zf_flush_kernel(zf_control* ctl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (ctl->status == ZF_RUNNING && ctl->lag > 0 && ctl->pend_status == 0) ctl->pend_status = ZF_PEND_FLUSH;
 }
 
 // after the host refilled the momentum ring: re-resolve the factor of the pending trial
 __global__ void zf_refresh_beta_kernel(zf_control* ctl, const double* beta_ring) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) ctl->beta_next = beta_ring[ctl->nit % ZF_RING];
+    if (threadIdx.x == 0 && blockIdx.x == 0) zf_resolve_beta(ctl, beta_ring);
 }
 
 // initial F(x0): partials [f raw, |x|_1, violations] -> init pack [f, g, 0...]
@@ -146,10 +153,18 @@ struct zf_solver {
     size_t ev_used = 0;
     double ms_total = 0.0;
     int64_t ms_count = 0;
+    // the shape of every timed pass, written by the kernel itself (the host cannot know it at launch)
+    int* pass_log = nullptr;              // ZF_PASS_LOG slots (device)
+    std::vector<int> pass_log_host;
+    int64_t launches = 0;                 // timed launches so far (slot = launches % ZF_PASS_LOG)
+    int64_t first_uncollected = 0;
+    double ms_full = 0.0, ms_part = 0.0;  // S-trial chains without replay / everything else
+    int64_t n_full = 0, n_part = 0;
 };
+constexpr int ZF_PASS_LOG = 4096;
 
 static int zf_solver_free_all(zf_solver* s) {
-    void* ptrs[] = {s->blk_part, s->slice_part, s->fin_cnt, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
+    void* ptrs[] = {s->pass_log, s->blk_part, s->slice_part, s->fin_cnt, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
                     s->own_svec ? s->s_part : nullptr, s->own_svec ? s->s_all : nullptr};
@@ -353,6 +368,18 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
     a.tiles_per_wg = s->tiles;
     a.blk_part = s->blk_part;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    a.pass_log = nullptr;
+    a.pass_slot = 0;
+    if (s->timing && !dry) {
+        if (!s->pass_log) {
+            ZF_HIP(hipMalloc(&s->pass_log, sizeof(int) * ZF_PASS_LOG));
+            ZF_HIP(hipMemsetAsync(s->pass_log, 0xff, sizeof(int) * ZF_PASS_LOG, s->stream));
+            s->pass_log_host.assign(ZF_PASS_LOG, -1);
+        }
+        a.pass_log = s->pass_log;
+        a.pass_slot = (int)(s->launches % ZF_PASS_LOG);
+        s->launches += 1;
+    }
     if (s->timing) {
         if (s->ev_used == s->ev_pool.size()) {
             hipEvent_t x, y;
@@ -515,9 +542,8 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
     c.ring_size = s->ring;
     c.sub_iters = s->sub;
     c.prev = s->ring - 1;   // x_{-1} = x_0 (:463-465)
-    c.plan_n = s->sub;
-    c.cut_at = -1;
-    c.ncuts = 0;
+    c.lag = 0;
+    c.pend_status = 0;
     ZF_HIP(hipMemcpyAsync(s->ctl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));   // `c` is a stack object
     zf_init_args I;
@@ -563,11 +589,10 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
     return ZF_OK;
 }
 
-// Resume a solve from a saved state: x_k, x_{k-1} (device, n each) and the
-// control block zf_solver_poll() returned when the state was taken.  Counters, lr, F(x_k), status
-// continue from the saved values; buffer indices and the chain geometry are this solver's; a
-// pending plan is kept when the chain length is the same and dropped otherwise (the next pass then
-// simply rediscovers what the plan recorded).  The momentum ring is NOT part of the state: the
+// Resume a solve from a saved state: the iterates in buffers `cur`, `prev`
+// (device, n each; x_k, x_{k-1} once zf_solver_flush() has run) and the control block
+// zf_solver_poll() returned when the state was taken.  Counters, lr, F(x_k), status continue from
+// the saved values; buffer indices and the chain geometry are this solver's.  The momentum ring is NOT part of the state: the
 // host re-uploads the factors from accepted count `nit` on (zf_solver_set_beta), which also
 // resolves beta_next.  Least squares: A x_k and A x_{k-1} are recomputed by the same kernel that
 // produced them (unsharded only).
@@ -594,11 +619,11 @@ extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const doubl
     c.ring_size = s->ring;
     c.world = d.world;
     c.need_grad = 1;
-    if (saved->sub_iters != s->sub) {
-        c.plan_n = s->sub;
-        c.cut_at = -1;
-        c.ncuts = 0;
-    }
+    // lagging iterations (accepted, iterates not stored) travel with the state when the chain
+    // geometry can replay them; zf_solver_flush() before the snapshot removes them
+    ZF_REQUIRE(saved->lag >= 0 && saved->lag <= 2 * s->sub - 2,
+               "zf_solver_restore: the saved state lags more iterations than this chain length can replay "
+               "(zf_solver_flush before taking the snapshot)");
     c.sub_iters = s->sub;
     if (c.status == ZF_MAXITER && c.nit < c.max_iter) c.status = ZF_RUNNING;   // a larger max_iter continues (:539)
     ZF_HIP(hipMemcpyAsync(s->ctl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
@@ -706,6 +731,15 @@ extern "C" int zf_solver_set_max_iter(zf_solver* s, int64_t max_iter) {
     return ZF_OK;
 }
 
+// world == 1: make the next step materialise lagging iterates (no-op when there are none), so
+// that x_k, x_{k-1} are in buffers `cur`, `prev` at the next poll - snapshots, history taps
+extern "C" int zf_solver_flush(zf_solver* s) {
+    ZF_REQUIRE(s && s->initialised, "zf_solver_flush: solver not initialised");
+    hipLaunchKernelGGL(zf_flush_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
 extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_steps: solver not initialised");
     ZF_REQUIRE(s->desc.world == 1, "zf_solver_enqueue_steps: world > 1 needs trial/gather/decide");
@@ -724,72 +758,21 @@ static void zf_set_tiles(zf_solver* s, int tiles) {
     s->grid = (int)((s->ntiles + tiles - 1) / tiles);
 }
 
-// Measure the trial kernel with 1, 2, 4 (and 8) interleaved tiles per workgroup on THIS device and
-// keep the fastest: the ranking differs between MI355X boxes (tools/tune_trial.hip: T = 4 is
-// 1 % faster than T = 1 on some, 7 % slower on others).  The probe launches are dry runs of the
-// pending trial: they write only the scratch x+ buffer and the reduction workspace (re-armed by
-// the kernel itself), never the control block.  Synchronises the stream.
+// Launch geometry of the trial kernel: T interleaved tiles per workgroup.  T decides which
+// elements a thread accumulates, hence the rounding of the six sums and, at a knife edge, an
+// accept / reject decision - so it is a FUNCTION OF n ONLY (never of a timing measurement, the
+// chain length or the device): the same problem takes the same decisions in every process, on
+// every rank layout with equal shard sizes, for every S and after every restore.  T = 8 amortises
+// the per-workgroup reduction of long chains once the grid still fills the chip (>= 4096 tiles =
+// 64 MiB per stream); below that the launch is latency-bound and T = 1.  (Round 1 picked T by
+// timing; tools/tune_trial.hip keeps that experiment.)  ZF_TILES_PER_WG=<n> overrides it for
+// experiments and changes the rounding of the sums with it.
 extern "C" int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_autotune: solver not initialised");
     const char* env = getenv("ZF_TILES_PER_WG");
-    if (env) {
-        zf_set_tiles(s, atoi(env));
-    } else if (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->ntiles >= 4096) {
-        // (below ~64 MB per stream the launch is latency-, not bandwidth-bound: keep T = 1)
-        // One measurement per process, device, kernel variant and size class: later solvers of
-        // the same shape reuse it (the probe costs ~30 launches).
-        static std::mutex mu;
-        static std::map<std::tuple<int, int, int, int, int>, int> cache;
-        int dev = 0;
-        ZF_HIP(hipGetDevice(&dev));
-        int size_class = 0;
-        for (int64_t t = s->ntiles; t > 1; t >>= 1) ++size_class;
-        const auto key = std::make_tuple(dev, s->sub, (int)(s->opt.nesterov != 0), (int)s->box, size_class);
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            auto hit = cache.find(key);
-            if (hit != cache.end()) {
-                zf_set_tiles(s, hit->second);
-                if (chosen_tiles) *chosen_tiles = s->tiles;
-                return ZF_OK;
-            }
-        }
-        const int cand[4] = {1, 2, 4, 8};
-        const int ncand = s->sub >= 8 ? 4 : 3;   // long chains amortise the per-workgroup reduction
-        double best = 1e300;
-        int best_t = 1;
-        hipEvent_t e0, e1;
-        ZF_HIP(hipEventCreate(&e0));
-        ZF_HIP(hipEventCreate(&e1));
-        const bool timing = s->timing;
-        s->timing = false;
-        for (int c = 0; c < ncand; ++c) {
-            zf_set_tiles(s, cand[c]);
-            double t_min = 1e300;
-            for (int rep = 0; rep < 7; ++rep) {   // first repetition warms up
-                ZF_HIP(hipEventRecord(e0, s->stream));
-                int rc = zf_launch_trial(s, false, /*dry=*/true);
-                if (rc) return rc;
-                ZF_HIP(hipEventRecord(e1, s->stream));
-                ZF_HIP(hipEventSynchronize(e1));
-                float ms = 0.f;
-                ZF_HIP(hipEventElapsedTime(&ms, e0, e1));
-                if (rep > 0 && ms < t_min) t_min = ms;
-            }
-            if (getenv("ZF_AUTOTUNE_VERBOSE"))
-                fprintf(stderr, "[zf autotune] tiles_per_wg=%d  trial kernel %.4f ms\n", cand[c], t_min);
-            if (t_min < best * 0.995) {   // prefer the smaller T unless clearly faster
-                best = t_min;
-                best_t = cand[c];
-            }
-        }
-        s->timing = timing;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        zf_set_tiles(s, best_t);
-        std::lock_guard<std::mutex> lock(mu);
-        cache[key] = best_t;
-    }
+    if (env) zf_set_tiles(s, atoi(env));
+    else if (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->ntiles >= 4096) zf_set_tiles(s, ZF_MAX_TILES_PER_WG);
+    else zf_set_tiles(s, 1);
     if (chosen_tiles) *chosen_tiles = s->tiles;
     return ZF_OK;
 }
@@ -813,12 +796,31 @@ extern "C" int zf_solver_set_pack_buffers(zf_solver* s, double* pack_local_dev, 
 }
 
 static int zf_collect_timing(zf_solver* s) {
+    const bool have_log = s->pass_log && s->ev_used > 0 && s->ev_used <= (size_t)ZF_PASS_LOG &&
+                          s->launches - s->first_uncollected == (int64_t)s->ev_used;
+    if (have_log)
+        ZF_HIP(hipMemcpy(s->pass_log_host.data(), s->pass_log, sizeof(int) * ZF_PASS_LOG, hipMemcpyDeviceToHost));
     for (size_t k = 0; k < s->ev_used; ++k) {
         float ms = 0.f;
         ZF_HIP(hipEventElapsedTime(&ms, s->ev_pool[k].first, s->ev_pool[k].second));
         s->ms_total += ms;
         s->ms_count += 1;
+        if (have_log) {
+            const int shape = s->pass_log_host[(s->first_uncollected + (int64_t)k) % ZF_PASS_LOG];
+            if (shape < 0) continue;   // the launch found the solve finished and exited
+            if ((shape >> 8) == 0 && (shape & 0xff) == s->sub) {
+                s->ms_full += ms;
+                s->n_full += 1;
+            } else {
+                s->ms_part += ms;
+                s->n_part += 1;
+            }
+        }
     }
+    if (have_log) {   // re-arm the slots just read
+        ZF_HIP(hipMemsetAsync(s->pass_log, 0xff, sizeof(int) * ZF_PASS_LOG, s->stream));
+    }
+    s->first_uncollected = s->launches;
     s->ev_used = 0;
     return ZF_OK;
 }
@@ -858,6 +860,27 @@ extern "C" int zf_solver_set_timing(zf_solver* s, int32_t enabled) {
     return ZF_OK;
 }
 
+// Trial-kernel durations since the last call, split by the shape of the pass (the kernel logs it):
+// out[0], out[1] = mean ms and count of full chains (S fresh trials, nothing replayed);
+// out[2], out[3] = mean ms and count of every other pass (shorter chains, replays, materialise-only).
+// Launches that found the solve finished are not counted.  Resets the window; call it INSTEAD of
+// zf_solver_trial_kernel_ms (which resets the same window).
+extern "C" int zf_solver_pass_stats(zf_solver* s, double out[4]) {
+    ZF_REQUIRE(s && out, "zf_solver_pass_stats: null argument");
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    int rc = zf_collect_timing(s);
+    if (rc) return rc;
+    out[0] = s->n_full ? s->ms_full / (double)s->n_full : 0.0;
+    out[1] = (double)s->n_full;
+    out[2] = s->n_part ? s->ms_part / (double)s->n_part : 0.0;
+    out[3] = (double)s->n_part;
+    s->ms_full = s->ms_part = 0.0;
+    s->n_full = s->n_part = 0;
+    s->ms_total = 0.0;
+    s->ms_count = 0;
+    return ZF_OK;
+}
+
 extern "C" int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches) {
     ZF_REQUIRE(s && avg_ms && launches, "zf_solver_trial_kernel_ms: null argument");
     ZF_HIP(hipStreamSynchronize(s->stream));
@@ -867,6 +890,8 @@ extern "C" int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* 
     *avg_ms = s->ms_count ? s->ms_total / (double)s->ms_count : 0.0;
     s->ms_total = 0.0;
     s->ms_count = 0;
+    s->ms_full = s->ms_part = 0.0;
+    s->n_full = s->n_part = 0;
     return ZF_OK;
 }
 

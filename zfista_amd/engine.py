@@ -155,11 +155,10 @@ class DeviceSolver:
             self.init_finish()
             self._gather()
         self.init_commit()
-        self.tiles_per_wg = 1
-        if os.environ.get("ZF_AUTOTUNE", "1") != "0":
-            t = C.c_int32(1)
-            _lib.check(self.lib.zf_solver_autotune(self.handle, C.byref(t)), "autotune")
-            self.tiles_per_wg = int(t.value)
+        # launch geometry: a function of n only (it fixes the rounding of the reduced sums)
+        t = C.c_int32(1)
+        _lib.check(self.lib.zf_solver_autotune(self.handle, C.byref(t)), "geometry")
+        self.tiles_per_wg = int(t.value)
 
     def set_beta(self, first: int, betas: np.ndarray):
         betas = np.ascontiguousarray(betas, dtype=np.float64)
@@ -179,6 +178,12 @@ class DeviceSolver:
             self._gather()
             self.enqueue_decide()
 
+    def flush(self):
+        """One replay-only pass that stores x_k, x_{k-1} when iterates lag behind the accepted
+        count (zf_control.lag); no-op otherwise."""
+        _lib.check(self.lib.zf_solver_flush(self.handle), "flush")
+        self.enqueue(1)
+
     def get_x_prev(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.float64)
         _lib.check(self.lib.zf_solver_get_x_prev(self.handle, C.c_void_p(_lib.ptr(out))), "get_x_prev")
@@ -188,11 +193,10 @@ class DeviceSolver:
         """Instead of init(): continue from a saved (x_k, x_{k-1}, control block)."""
         _lib.check(self.lib.zf_solver_restore(self.handle, C.c_void_p(xk_dev_ptr), C.c_void_p(xprev_dev_ptr),
                                               C.byref(ctl)), "restore")
-        self.tiles_per_wg = 1
-        if os.environ.get("ZF_AUTOTUNE", "1") != "0":
-            t = C.c_int32(1)
-            _lib.check(self.lib.zf_solver_autotune(self.handle, C.byref(t)), "autotune")
-            self.tiles_per_wg = int(t.value)
+        # launch geometry: a function of n only (it fixes the rounding of the reduced sums)
+        t = C.c_int32(1)
+        _lib.check(self.lib.zf_solver_autotune(self.handle, C.byref(t)), "geometry")
+        self.tiles_per_wg = int(t.value)
 
     def set_max_iter(self, max_iter: int):
         _lib.check(self.lib.zf_solver_set_max_iter(self.handle, int(max_iter)), "set_max_iter")
@@ -217,6 +221,12 @@ class DeviceSolver:
         ms, cnt = C.c_double(0.0), C.c_int64(0)
         _lib.check(self.lib.zf_solver_trial_kernel_ms(self.handle, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def pass_stats(self):
+        """(mean ms, count) of full-chain passes and of all other passes since the last call."""
+        out = np.zeros(4)
+        _lib.check(self.lib.zf_solver_pass_stats(self.handle, C.c_void_p(_lib.ptr(out))))
+        return (out[0], int(out[1])), (out[2], int(out[3]))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -233,11 +233,10 @@ class MoEngine:
             pass
 
 
-def solve_dual(dual, m, w0, tol, max_iter):
-    """The reference's two SciPy calls (:179-205).  Returns (weight, fun, nit)."""
-    import os
-
-    if os.environ.get("ZF_DUAL_SOLVER", DUAL_SOLVER) == "native":
+def solve_dual(dual, m, w0, tol, max_iter, solver="scipy"):
+    """The reference's two SciPy calls (:179-205), or - ``solver`` "native" / "device" - the
+    library's own search driven from Python (opaque callbacks).  Returns (weight, fun, nit)."""
+    if solver in ("native", "device"):
         out = solve_dual_native(dual, m, w0, tol, max_iter)
         if out is not None:
             return out
@@ -258,7 +257,8 @@ def solve_dual(dual, m, w0, tol, max_iter):
 # ---------------------------------------------------------------------------
 # native dual solver: opt-in replacement of the two SciPy calls
 # ---------------------------------------------------------------------------
-DUAL_SOLVER = "scipy"   # "scipy" = the reference's calls (parity default); "native" = simplex Newton
+# selected per call: minimize_proximal_gradient(..., dual_solver="scipy" | "native" | "device");
+# "scipy" = the reference's calls (parity default)
 
 
 def _simplex_qp(q, Q):
@@ -430,9 +430,8 @@ def solve_native(problem, x0, o):
                          nesterov=o["nesterov"], nesterov_ratio=o["nesterov_ratio"])
     if o["verbose"]:
         _print_header()
-    import os
-
-    use_native = os.environ.get("ZF_DUAL_SOLVER", DUAL_SOLVER) == "native"
+    dual_solver = o.get("dual_solver", "scipy")
+    use_native = dual_solver in ("native", "device")
     host_f = bool(getattr(problem, "_host_f", False))   # f / jac_f are host NumPy (n <= 30 families)
 
     def eval_F(which):
@@ -469,7 +468,7 @@ def solve_native(problem, x0, o):
                                          o["max_iter_internal"])
                 if out is None:
                     dual = device_dual(eng, lr, f_y, F_old, o["deprecated"])
-                    out = solve_dual(dual, m, w0, o["tol_internal"], o["max_iter_internal"])
+                    out = solve_dual(dual, m, w0, o["tol_internal"], o["max_iter_internal"], dual_solver)
                 weight, dual_fun, nit_int = out
                 err = eng.recover(lr, weight)          # x+ and max|x+ - y|   (:206, :510)
                 fun = -dual_fun                         # (:207)
@@ -520,7 +519,7 @@ def solve_native(problem, x0, o):
 # ---------------------------------------------------------------------------
 # generic path: opaque host callbacks f, g, jac_f, prox_wsum_g with m >= 2
 # ---------------------------------------------------------------------------
-def trial_generic(ops, f, g, jac_f, prox, lr, x_old, y, w0, tol, max_iter, deprecated):
+def trial_generic(ops, f, g, jac_f, prox, lr, x_old, y, w0, tol, max_iter, deprecated, solver="scipy"):
     """(:140-209) for m >= 2 with opaque callbacks.  Returns (x, fun, nit, weight, err).
 
     J lives on the GPU for the duration of the trial; w@J, the norms and J@(p-y) are
@@ -549,7 +548,7 @@ def trial_generic(ops, f, g, jac_f, prox, lr, x_old, y, w0, tol, max_iter, depre
                 jac += F_old - f_y
             return fun, jac
 
-        weight, dual_fun, nit_int = solve_dual(dual, m, w0, tol, max_iter)
+        weight, dual_fun, nit_int = solve_dual(dual, m, w0, tol, max_iter, solver)
         eng.recover(lr, weight)
         x_new = prox(lr * weight, eng.get(X_NEW))    # (:206)
         _, _, err = ops.model_terms(np.zeros(n), x_new, y)

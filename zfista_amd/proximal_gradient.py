@@ -58,16 +58,34 @@ def minimize_proximal_gradient(
     lr=1, tol=1e-5, tol_internal=1e-12, max_iter=1000000, max_iter_internal=100000,
     max_backtrack_iter=100, warm_start=False, decay_rate=0.5, nesterov=False,
     nesterov_ratio=(0, 0.25), return_all=False, verbose=False, deprecated=False,
+    *, dual_solver=None, sub_iters=None,
 ):
     """Minimise F = f + g by the (accelerated) proximal gradient method on MI355X.
 
     Parameters, returned ``OptimizeResult`` fields and messages are those of
     zfista/proximal_gradient.py:332-443.  ``x0`` may be a NumPy array (or, on the
     native path, a float64 CUDA tensor holding this rank's shard).
+
+    Keyword-only extensions (not in the reference; the defaults reproduce it):
+
+    dual_solver : {"scipy", "native", "device"}, m >= 2 only.  "scipy" (default) minimises the dual
+        of every trial with the reference's two SciPy calls (:179-205).  "native" uses the library's
+        own simplex Newton / bracketing solver (host loop, one kernel per evaluation); "device"
+        runs that same search inside one persistent kernel per trial (recognised problems only).
+        The default can be set with the environment variable ZF_DUAL_SOLVER.
+    sub_iters : {1, 2, 4, 8}, separable single-objective problems only: iterations chained per
+        pass over the data (temporal blocking).  Results do not depend on it.  Default 8.
     """
     if deprecated:
         warn(_MSG_DEPRECATED, stacklevel=2)
+    if dual_solver is None:
+        import os
+
+        dual_solver = os.environ.get("ZF_DUAL_SOLVER", "scipy")
+    if dual_solver not in ("scipy", "native", "device"):
+        raise ValueError(f"dual_solver must be 'scipy', 'native' or 'device', got {dual_solver!r}")
     opts = dict(
+        dual_solver=dual_solver, sub_iters=int(sub_iters or 0),
         lr=lr, tol=tol, tol_internal=tol_internal, max_iter=max_iter,
         max_iter_internal=max_iter_internal, max_backtrack_iter=max_backtrack_iter,
         warm_start=warm_start, decay_rate=decay_rate, nesterov=nesterov,
@@ -154,8 +172,13 @@ class NativeRun:
 
     def snapshot(self):
         """The state of the solve after the last advance(): x_k, x_{k-1} and the control block
-        (host arrays; ``np.savez(path, **state)`` makes it a checkpoint file)."""
+        (host arrays; ``np.savez(path, **state)`` makes it a checkpoint file).  Iterations that
+        were accepted by a chain that broke before its end are materialised first (one
+        replay-only pass, zf_solver_flush), so the saved iterates are x_k, x_{k-1} of ``nit``."""
         ctl, _ = self.solver.poll()
+        if ctl.status == _lib.ZF_RUNNING and ctl.lag > 0:
+            self.solver.flush()
+            ctl, _ = self.solver.poll()
         return dict(x=self.solver.get_x(), x_prev=self.solver.get_x_prev(),
                     control=np.frombuffer(bytes(ctl), dtype=np.uint8).copy())
 
@@ -167,12 +190,16 @@ class NativeRun:
 
     def _fill_beta(self, upto):
         """Upload momentum factors for accepted-iteration counts < upto."""
-        if not self.opts["nesterov"] or upto <= self._beta_filled:
+        if not self.opts["nesterov"]:
             return
-        # refill as far ahead as the ring allows (slot of count nit_seen + ZF_RING would alias the
-        # pending one), bounded by what the solve can still use: one upload per ~1000 iterations
-        ahead = self.nit_seen + _lib.ZF_RING - 1
+        # refill as far ahead as the ring allows - the slots of the ZF_MAX_LAG counts behind
+        # nit_seen may still be replayed (zf_control.lag), the one of nit_seen + ZF_RING - ZF_MAX_LAG
+        # would alias the oldest of them - bounded by what the solve can still use: one upload
+        # per ~1000 iterations, and none between set_max_iter() and the passes that follow it
+        ahead = self.nit_seen + _lib.ZF_RING - 1 - _lib.ZF_MAX_LAG
         upto = max(upto, min(ahead, int(self.opts["max_iter"]) + 1))
+        if upto <= self._beta_filled:
+            return
         first = self._beta_filled
         count = upto - first
         betas = np.zeros(count)
@@ -195,7 +222,7 @@ class NativeRun:
 
     def enqueue_only(self, steps):
         # the trace / momentum rings hold ZF_RING iterations: never run further ahead of the host
-        steps = int(min(steps, (_lib.ZF_RING - 1) // self.sub_iters))
+        steps = int(min(steps, (_lib.ZF_RING - 1 - _lib.ZF_MAX_LAG) // self.sub_iters))
         # + 1: the decide step of the last trial resolves the factor of the trial after it
         self._fill_beta(self.nit_seen + steps * self.sub_iters + 1)
         self.solver.enqueue(steps)
@@ -505,7 +532,7 @@ def _solve_generic(f, g, jac_f, prox, x0, o):
                 else:
                     x_cur, fun, nit_int, weight, err = multiobjective.trial_generic(
                         ops, f, g, jac_f, prox, lr, x_old, y, w0, o["tol_internal"],
-                        o["max_iter_internal"], o["deprecated"])
+                        o["max_iter_internal"], o["deprecated"], o.get("dual_solver", "scipy"))
                 F_new = f(x_cur) + g(x_cur)   # :295
                 if w0 is not None and o["warm_start"]:
                     w0 = weight
