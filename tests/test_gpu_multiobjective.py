@@ -93,6 +93,17 @@ def test_callables_vs_oracle(tag):
     np.testing.assert_allclose(got, exp, rtol=0, atol=0)   # same elementwise expression order
 
 
+def _floor(tag):
+    """G10: spread of the imported reference against itself under permuted feature orders."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+
+    with open(os.path.join(GOLDEN, "g10_reference_noise_floor.json")) as fh:
+        return json.load(fh)["cases"][tag]
+
+
 @pytest.mark.parametrize("tag", CASES)
 def test_subproblem_capture(tag, golden):
     """Direct _solve_subproblem capture of the reference at a fixed (lr, x_old, y)."""
@@ -113,12 +124,16 @@ def test_subproblem_capture(tag, golden):
         w, dual_fun, nit = solve_dual(device_dual(eng, lr, f_y, f0 + g0, False), m, np.ones(m) / m, 1e-12, 100000)
     eng.recover(lr, w)
     x = eng.get(X_NEW)
-    tol = 1e-7 if m == 2 else 1e-6
-    assert rel_err(x, G(f"{tag}.sub.x")) <= tol
-    # the dual is flat near the simplex boundary: the barrier method's end point moves at the
-    # 1e-5 level with last-bit changes of the function values while x+ stays put (asserted above)
-    np.testing.assert_allclose(w, G(f"{tag}.sub.weight"), rtol=0, atol=1e-6 if m == 2 else 1e-4)
-    np.testing.assert_allclose(-dual_fun, float(G(f"{tag}.sub.fun")), rtol=1e-9 if m == 2 else 2e-5, atol=1e-12)
+    # tolerance = max(1e-10, 10 x the reference's OWN spread of this capture when its feature order
+    # is permuted, G10): five of the eight cases reproduce to 1e-13 or better, and there the engine
+    # has to as well; where SciPy's Brent / barrier end point itself moves with the last bits of the
+    # dual values (jos1_n50_l1: 2e-9, fds_n100_l1: 3e-8 in x+, 1e-5 in w) nothing tighter is defined
+    fl = _floor(tag)
+    assert rel_err(x, G(f"{tag}.sub.x")) <= max(1e-10, 10 * fl["sub_x_rel"])
+    np.testing.assert_allclose(w, G(f"{tag}.sub.weight"), rtol=0, atol=max(1e-10, 10 * fl["sub_w_abs"]))
+    if np.isfinite(float(G(f"{tag}.sub.fun"))):
+        np.testing.assert_allclose(-dual_fun, float(G(f"{tag}.sub.fun")), rtol=max(1e-10, 10 * fl["sub_fun_rel"]),
+                                   atol=1e-12)
 
 
 @pytest.mark.parametrize("tag", CASES)
@@ -135,11 +150,12 @@ def test_traces_vs_golden(tag, nesterov, golden):
         res = minimize_proximal_gradient(*p.callbacks(), G(f"{tag}.x0"), nesterov=nesterov, tol=1e-5, max_iter=12,
                                          return_all=True, **kw)
     assert res.nit == int(G(f"{tag}.{v}.nit"))
-    tol = 1e-7 if p.n_objectives == 2 else 1e-6
+    fl = _floor(tag)   # the reference's own spread over the same 12 iterations (G10), see above
+    tol = max(1e-10, 10 * fl["trace_x_rel"])
     for a, b in zip(res.allvecs, G(f"{tag}.{v}.vecs")):
         assert rel_err(a, b) <= tol
-    np.testing.assert_allclose(np.stack(res.allfuns), G(f"{tag}.{v}.allfuns"), rtol=1e-7)
-    np.testing.assert_allclose(res.allerrs, G(f"{tag}.{v}.allerrs"), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(np.stack(res.allfuns), G(f"{tag}.{v}.allfuns"), rtol=max(1e-10, 10 * fl["trace_F_rel"]))
+    np.testing.assert_allclose(res.allerrs, G(f"{tag}.{v}.allerrs"), rtol=1e-10, atol=max(1e-12, 10 * fl["trace_err_abs"]))
 
 
 # ---- the reference's own m = 2 / m = 3 solver tests (closures -> generic path) -----------------

@@ -113,7 +113,7 @@ constexpr int ZF_TILE_U = 4;
 #define ZF_X_NT 1   // nontemporal loads of x_k, x_{k-1} in chained passes: read once per pass (tools/tune_trial.hip: -1 %)
 #endif
 #ifndef ZF_S8_UB
-#define ZF_S8_UB 4   // units per load batch of the 8-trial chain (tools/tune_trial.hip: 4 is 3 % faster than 2)
+#define ZF_S8_UB 2   // units per load batch of the 8-trial chain: half a tile, software-pipelined (4 = whole tile, no pipeline)
 #endif
 constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per tile
 constexpr int ZF_MAX_TILES_PER_WG = 8;                // upper bound of zf_step_args.tiles_per_wg
@@ -377,47 +377,81 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     // of every stream (consecutive tiles per workgroup measured 4-8 % slower).
     const int64_t full_tiles = n2 / ZF_TILE_UNITS;
     const int64_t G = gridDim.x;
-    for (int t = 0; t < A.tiles_per_wg; ++t) {
-        const int64_t tile = (int64_t)t * G + blockIdx.x;
-        if (tile >= full_tiles) break;
-        const int64_t base_u = tile * ZF_TILE_UNITS + threadIdx.x;
-        // UB units are loaded, then computed, at a time (16 loads in flight per thread at UB = 4)
-        constexpr int UB = (S >= 8) ? ZF_S8_UB : ZF_TILE_U;
+    // UB units are loaded, then computed, at a time
+    constexpr int UB = (S >= 8) ? ZF_S8_UB : ZF_TILE_U;
+    auto load_batch = [&](int64_t first_unit, zf_d2 (&a)[UB], zf_d2 (&o)[UB], zf_d2 (&q)[UB], zf_d2 (&cc)[UB]) {
 #pragma unroll
-        for (int u0 = 0; u0 < ZF_TILE_U; u0 += UB) {
-            zf_d2 a[UB], o[UB], q[UB], cc[UB];
+        for (int u = 0; u < UB; ++u) {
+            const int64_t i = first_unit + u * ZF_BLOCK;
+            a[u] = zf_ld2<NT && (ZF_X_NT != 0) && (S > 1)>(xk2 + i);
+            o[u] = a[u];
+            if (NESTEROV) o[u] = zf_ld2<NT && (ZF_X_NT != 0) && (S > 1)>(xo2 + i);
+            q[u] = zf_ld2<NT>(p02 + i);
+            cc[u] = q[u];
+            if (GRAD_INLINE) cc[u] = zf_ld2<NT>(p12 + i);
+        }
+        // keep all loads of the batch in flight: without this fence the scheduler sinks the
+        // last ones below the first arithmetic to save registers
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute_batch = [&](int64_t first_unit, zf_d2 (&a)[UB], zf_d2 (&o)[UB], zf_d2 (&q)[UB], zf_d2 (&cc)[UB]) {
+        if constexpr (!FULL && GRAD_INLINE) {
+            // replay of the lagging iterations: trial-outer, unit-inner - 2 UB independent
+            // element recursions per step, parameters are wave-uniform scalar loads
+            for (int i = 0; i < lag; ++i) {
+                const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
+                const double lr_i = A.ctl->lag_lr[i];
+                const double tau_i = A.lam * lr_i;
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int64_t i = base_u + (u0 + u) * ZF_BLOCK;
-                a[u] = zf_ld2<NT && (ZF_X_NT != 0) && (S > 1)>(xk2 + i);
-                o[u] = a[u];
-                if (NESTEROV) o[u] = zf_ld2<NT && (ZF_X_NT != 0) && (S > 1)>(xo2 + i);
-                q[u] = zf_ld2<NT>(p02 + i);
-                cc[u] = q[u];
-                if (GRAD_INLINE) cc[u] = zf_ld2<NT>(p12 + i);
-            }
-            // keep all loads of the batch in flight: without this fence the scheduler sinks the
-            // last ones below the first arithmetic to save registers
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!FULL && GRAD_INLINE) {
-                // replay of the lagging iterations: trial-outer, unit-inner - 2 UB independent
-                // element recursions per step, parameters are wave-uniform scalar loads
-                for (int i = 0; i < lag; ++i) {
-                    const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
-                    const double lr_i = A.ctl->lag_lr[i];
-                    const double tau_i = A.lam * lr_i;
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        zf_d2 r;
-                        r.x = zf_elem_diag_replay<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, cc[u].x, b_i, lr_i, tau_i, A.lo, A.hi);
-                        r.y = zf_elem_diag_replay<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, cc[u].y, b_i, lr_i, tau_i, A.lo, A.hi);
-                        o[u] = a[u];
-                        a[u] = r;
-                    }
+                for (int u = 0; u < UB; ++u) {
+                    zf_d2 r;
+                    r.x = zf_elem_diag_replay<NESTEROV, BOX>(a[u].x, o[u].x, q[u].x, cc[u].x, b_i, lr_i, tau_i, A.lo, A.hi);
+                    r.y = zf_elem_diag_replay<NESTEROV, BOX>(a[u].y, o[u].y, q[u].y, cc[u].y, b_i, lr_i, tau_i, A.lo, A.hi);
+                    o[u] = a[u];
+                    a[u] = r;
                 }
             }
+        }
 #pragma unroll
-            for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], base_u + (u0 + u) * ZF_BLOCK);
+        for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], first_unit + u * ZF_BLOCK);
+    };
+    if constexpr (UB == ZF_TILE_U) {
+        // short chains (<= 148 VGPRs, three or more waves per SIMD): the other waves of the SIMD
+        // cover a wave's load latency; all 16 loads of a tile in flight, then its arithmetic
+        for (int t = 0; t < A.tiles_per_wg; ++t) {
+            const int64_t tile = (int64_t)t * G + blockIdx.x;
+            if (tile >= full_tiles) break;
+            const int64_t base_u = tile * ZF_TILE_UNITS + threadIdx.x;
+            zf_d2 a[UB], o[UB], q[UB], cc[UB];
+            load_batch(base_u, a, o, q, cc);
+            compute_batch(base_u, a, o, q, cc);
+        }
+    } else {
+        // long chains run two waves per SIMD (200 VGPRs) and compute ~1400 instructions per batch:
+        // software pipeline - the loads of the NEXT batch (half a tile, 8 x 16 B per thread) are
+        // issued before the arithmetic of the current one, across tile boundaries too, so every
+        // wave keeps memory requests in flight while it computes
+        static_assert(ZF_TILE_U == 2 * UB, "two batches per tile");
+        int my_tiles = 0;
+        for (int t = 0; t < A.tiles_per_wg; ++t)
+            if ((int64_t)t * G + blockIdx.x < full_tiles) my_tiles = t + 1;
+        if (my_tiles > 0) {
+            zf_d2 a0[UB], o0[UB], q0[UB], c0[UB], a1[UB], o1[UB], q1[UB], c1[UB];
+            int64_t base_u = (int64_t)blockIdx.x * ZF_TILE_UNITS + threadIdx.x;
+            load_batch(base_u, a0, o0, q0, c0);
+            // (the last tile is peeled: a conditional prefetch inside the loop made the register
+            //  allocator keep both buffers of both paths alive - 512 VGPRs and scratch)
+            for (int t = 0; t + 1 < my_tiles; ++t) {
+                load_batch(base_u + UB * ZF_BLOCK, a1, o1, q1, c1);
+                compute_batch(base_u, a0, o0, q0, c0);
+                const int64_t next_u = ((int64_t)(t + 1) * G + blockIdx.x) * ZF_TILE_UNITS + threadIdx.x;
+                load_batch(next_u, a0, o0, q0, c0);
+                compute_batch(base_u + UB * ZF_BLOCK, a1, o1, q1, c1);
+                base_u = next_u;
+            }
+            load_batch(base_u + UB * ZF_BLOCK, a1, o1, q1, c1);
+            compute_batch(base_u, a0, o0, q0, c0);
+            compute_batch(base_u + UB * ZF_BLOCK, a1, o1, q1, c1);
         }
     }
     // remainder of the vector (less than one tile, including an odd last element): element by
