@@ -1,5 +1,7 @@
+"""Soak: repeated solves + one long solve on the GPU (leaks, stability); run by hand on the GPU box."""
+import os
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bench import make_inputs, LAM, LR
 from zfista_amd import _lib

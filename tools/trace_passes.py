@@ -23,6 +23,6 @@ while run.status == _lib.ZF_RUNNING:
     rows = run.advance(1)
     p += 1
     ctl = run.solver.ctl
-    extra = "" if len(rows) else "   <- chain broke: nothing committed" if ctl.cut_at >= 0 or ctl.plan_n != run.sub_iters else ""
-    print(f"pass {p:3d}  nit {ctl.nit:4d}  lr {ctl.lr:.6g}  trials {ctl.total_trials:4d}  plan ({ctl.plan_n}, {ctl.cut_at}, "
-          f"{ctl.ncuts})  err {ctl.err:.3e}  F {ctl.F_old:.17g}{extra}")
+    extra = f"   <- chain broke: {ctl.lag} accepted iterations wait for the next pass to materialise" if ctl.lag else ""
+    print(f"pass {p:3d}  nit {ctl.nit:4d}  (+{len(rows)})  lr {ctl.lr:.6g}  trials {ctl.total_trials:4d}  lag {ctl.lag}  "
+          f"err {ctl.err:.3e}  F {ctl.F_old:.17g}{extra}")

@@ -313,13 +313,17 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 //     and decisions are bit-identical to S = 1 (tests/test_gpu_temporal.py).
 // FULL: no lagging iterations and S fresh trials (known at compile time: no per-trial branch);
 // otherwise `lag` replayed + `nf` < = S fresh trials, trial by trial
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool FULL>
+// MODE 0: FULL;  1: lagging iterations replayed, then S fresh trials (no per-trial branch either:
+// the usual pass after a broken chain);  2: anything else (shorter fresh chains, materialise-only)
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE>
 __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds, const int lag, const int nf) {
+    constexpr bool FULL = (MODE == 0);          // nothing replayed, S fresh trials
+    constexpr bool FRESH_FULL = (MODE <= 1);    // S fresh trials
     const int cur = A.ctl->cur;
     const int prev = A.ctl->prev;
     const int ring = A.ctl->ring_size;
     const double lr = A.ctl->lr;
-    const int ntr = FULL ? S : lag + nf;   // chain length: iterates x_{b+1} .. x_{b+ntr} from (x_b, x_{b-1})
+    const int ntr = FULL ? S : (FRESH_FULL ? lag + S : lag + nf);   // chain length: iterates x_{b+1} .. x_{b+ntr} from (x_b, x_{b-1})
     double beta[S];
     const int64_t nit = A.ctl->nit;
     const int64_t base = nit - lag;        // iteration count the stored iterates belong to
@@ -352,7 +356,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     auto advance = [&](zf_d2 a, zf_d2 o, zf_d2 q, zf_d2 cc, int64_t i) {
 #pragma unroll
         for (int j = 0; j < S; ++j) {
-            if (FULL || j < nf) {
+            if (FRESH_FULL || j < nf) {
                 zf_d2 r;
                 if (GRAD_INLINE) {
                     r.x = zf_elem_diag<NESTEROV, BOX>(a.x, o.x, q.x, cc.x, beta[j], lr, tau, A.lo, A.hi, acc[j]);
@@ -366,7 +370,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
             }
         }
         zf_st2<NT>(reinterpret_cast<zf_d2*>(out_last) + i, a);
-        if (S > 1 && (FULL || ntr >= 2)) zf_st2<NT>(reinterpret_cast<zf_d2*>(out_prev) + i, o);
+        if (S > 1 && (FRESH_FULL || ntr >= 2)) zf_st2<NT>(reinterpret_cast<zf_d2*>(out_prev) + i, o);
         // long chains: finish one unit before the next (interleaving four 8-trial chains costs
         // ~100 more VGPRs and halves the occupancy)
         if (S >= 8) __builtin_amdgcn_sched_barrier(0);
@@ -415,16 +419,20 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
 #pragma unroll
         for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], first_unit + u * ZF_BLOCK);
     };
-    if constexpr (UB == ZF_TILE_U) {
+    if constexpr (UB == ZF_TILE_U || MODE == 1) {
         // short chains (<= 148 VGPRs, three or more waves per SIMD): the other waves of the SIMD
-        // cover a wave's load latency; all 16 loads of a tile in flight, then its arithmetic
+        // cover a wave's load latency; all loads of a batch in flight, then its arithmetic.
+        // (Also the replay + S fresh trials body of long chains: pipelined, its registers spill.)
         for (int t = 0; t < A.tiles_per_wg; ++t) {
             const int64_t tile = (int64_t)t * G + blockIdx.x;
             if (tile >= full_tiles) break;
-            const int64_t base_u = tile * ZF_TILE_UNITS + threadIdx.x;
-            zf_d2 a[UB], o[UB], q[UB], cc[UB];
-            load_batch(base_u, a, o, q, cc);
-            compute_batch(base_u, a, o, q, cc);
+#pragma unroll 1
+            for (int u0 = 0; u0 < ZF_TILE_U; u0 += UB) {
+                const int64_t base_u = tile * ZF_TILE_UNITS + threadIdx.x + (int64_t)u0 * ZF_BLOCK;
+                zf_d2 a[UB], o[UB], q[UB], cc[UB];
+                load_batch(base_u, a, o, q, cc);
+                compute_batch(base_u, a, o, q, cc);
+            }
         }
     } else {
         // long chains run two waves per SIMD (200 VGPRs) and compute ~1400 instructions per batch:
@@ -472,7 +480,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
             }
 #pragma unroll
             for (int j = 0; j < S; ++j) {
-                if (FULL || j < nf) {
+                if (FRESH_FULL || j < nf) {
                     double r;
                     if (GRAD_INLINE)
                         r = zf_elem_diag<NESTEROV, BOX>(a, o, q, cc, beta[j], lr, tau, A.lo, A.hi, acc[j]);
@@ -482,7 +490,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
                 }
             }
             out_last[e] = a;
-            if (S > 1 && (FULL || ntr >= 2)) out_prev[e] = o;
+            if (S > 1 && (FRESH_FULL || ntr >= 2)) out_prev[e] = o;
         }
     }
 
@@ -530,13 +538,14 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     if (A.ctl->status != ZF_RUNNING) return;
     if (S == 1) {
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = 1;
-        zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, true>(A, lds, 0, 1);
+        zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0>(A, lds, 0, 1);
     } else {
         const int lag = A.ctl->lag;
         const int nf = zf_fresh_len(A.ctl);   // fresh trials of this chain (0: materialise only)
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = (lag << 8) | nf;
-        if (lag == 0 && nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, true>(A, lds, 0, S);
-        else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, false>(A, lds, lag, nf);
+        if (lag == 0 && nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0>(A, lds, 0, S);
+        else if (nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1>(A, lds, lag, S);
+        else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2>(A, lds, lag, nf);
     }
 }
 
