@@ -296,6 +296,11 @@ int zf_mo_set_x0(zf_mo* s, const double* x0_host);              /* :463-465 */
 /* point selector `which`: 0 = x_k, 1 = y, 2 = x+ (trial point), 3 = x_{k-1} */
 int zf_mo_eval_F(zf_mo* s, int32_t which, double* f_out /* m or NULL */, double* g_out /* m */); /* :279,:295 */
 int zf_mo_prepare(zf_mo* s, double* f_y_out /* m */);           /* J = jac_f(y), f(y)   :140,:142 */
+/* the same, stream-ordered and without a host round trip (built-in problems, unsharded x): f(y) is
+ * formed and kept on the device for zf_mo_solve_dual_device, which hands it back with its result;
+ * zf_mo_get_f_y fetches it otherwise (synchronises) */
+int zf_mo_prepare_async(zf_mo* s);
+int zf_mo_get_f_y(zf_mo* s, double* f_y_out /* m */);
 int zf_mo_set_jac(zf_mo* s, const double* J_host);              /* generic kind         :142 */
 /* out[0..m) = g_i(p), out[m] = |p-v|^2, out[m+1] = |w@J|^2, out[m+2..2m+2) = J_i.(p-y)   :162-173 */
 int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double* out);
@@ -306,6 +311,20 @@ int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double* out);
 int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
                      const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
                      int64_t* nit_out, int32_t* ok_out, int64_t* evals_out);
+/* the same search and the primal recovery (:206, :510) inside ONE persistent kernel: the dual
+ * evaluations run on register-resident (J, y), their sums are combined by a last-arriver reduction,
+ * the solver's state machine advances on the device; f(x+), g(x+) (:295) come out of the same pass
+ * (f_x_out[0] = NaN when f is a host callback); one launch and one read-back per trial.
+ * *ok_out = 0: not attempted (non-finite start, x sharded over ranks, m > 3) - fall back to
+ * zf_mo_solve_dual / the reference's calls + zf_mo_recover. */
+int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
+                            const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
+                            int64_t* nit_out, int32_t* ok_out, int64_t* evals_out, double* err_out,
+                            double* f_x_out /* m or NULL */, double* g_x_out /* m or NULL */,
+                            double* f_y_out /* m or NULL: the f(y) used; f_y may be NULL after zf_mo_prepare_async */);
+/* diagnostics of the last device solve: [0] batches (grid-wide hand-overs), [1] dual evaluations,
+ * [2..5] shader-clock cycles of workgroup 0: whole kernel / evaluation loops / hand-overs / solver steps */
+int zf_mo_solve_stats(zf_mo* s, int64_t out6[6]);
 int zf_mo_recover(zf_mo* s, double lr, const double* w_host, double* err_out);   /* :206, :510 */
 int zf_mo_commit(zf_mo* s, double beta, int32_t nesterov);      /* :530-538 */
 int zf_mo_get(zf_mo* s, int32_t which, double* host);

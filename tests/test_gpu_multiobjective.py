@@ -234,6 +234,104 @@ def test_native_dual_solver_full_solve(tag, golden):
     assert p._engine().n_dual_evals <= 60 * res.nit
 
 
+@pytest.mark.parametrize("tag", ["jos1_n50", "jos1_n1000_l1", "jos1_n50_box", "fds_n10_l1", "fds_n100_l1", "fds_n10_pos"])
+def test_device_dual_solver_matches_the_host_loop(tag, golden):
+    """dual_solver="device" (the whole search of a trial in one persistent kernel: register-resident
+    data, last-arriver reductions, the solver's state machine on the device) against
+    dual_solver="native" (the same state machine on the host, one launch per evaluation): same
+    weights, model value, iteration counts and recovered x+ to rounding - the two differ only in
+    the summation order of the 2m+2 sums."""
+    from zfista_amd.multiobjective import X_K, X_NEW, Y
+
+    G = golden("g4_multiobjective.npz")
+    make, _, _ = _cases()[tag]
+    p = make()
+    m = p.n_objectives
+    eng = p._engine()
+    x0, y, lr = G(f"{tag}.x0"), G(f"{tag}.sub.y"), float(G(f"{tag}.sub.lr"))
+    eng.set_x0(x0)
+    eng.put(Y, y)
+    f0, g0 = eng.eval_F(X_K)
+    f_y = eng.prepare()
+    host = eng.solve_dual(lr, f_y, f0 + g0, False, None, 1e-12, 100000)
+    dev = eng.solve_dual_device(lr, f_y, f0 + g0, False, None, 1e-12, 100000)
+    if host is None:   # non-finite start (x0 outside the box): neither is attempted
+        assert dev is None
+        return
+    assert dev is not None
+    w_h, fun_h, nit_h = host
+    w_d, fun_d, nit_d, err_d, f_d, g_d, f_y_d = dev
+    assert np.array_equal(f_y_d, f_y)
+    x_d = eng.get(X_NEW)
+    F_x = eng.eval_F(X_NEW)                      # the kernel's own f(x+), g(x+) against the separate kernels
+    np.testing.assert_allclose(g_d, F_x[1], rtol=1e-12)
+    np.testing.assert_allclose(f_d, F_x[0], rtol=1e-12)
+    err_h = eng.recover(lr, w_h)
+    x_h = eng.get(X_NEW)
+    np.testing.assert_allclose(w_d, w_h, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fun_d, fun_h, rtol=1e-9, atol=1e-12)
+    assert rel_err(x_d, x_h) <= 1e-9
+    np.testing.assert_allclose(err_d, err_h, rtol=1e-7, atol=1e-12)
+    assert abs(nit_d - nit_h) <= 1
+
+
+@pytest.mark.parametrize("tag", ["jos1_n1000_l1", "fds_n10_l1", "fds_n100_l1", "fds_n10_pos"])
+def test_device_dual_solver_full_solve(tag, golden):
+    """Full solves with dual_solver="device": same outer iteration count as the reference run,
+    iterates within the accuracy of the reference's own dual solves (as for "native")."""
+    from zfista_amd import minimize_proximal_gradient
+
+    G = golden("g4_multiobjective.npz")
+    make, _, kw = _cases()[tag]
+    p = make()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize_proximal_gradient(*p.callbacks(), G(f"{tag}.x0"), nesterov=True, tol=1e-5, max_iter=12,
+                                         return_all=True, dual_solver="device", **kw)
+    assert res.nit == int(G(f"{tag}.fista.nit"))
+    for a, b in zip(res.allvecs, G(f"{tag}.fista.vecs")):
+        assert rel_err(a, b) <= 2e-5
+    np.testing.assert_allclose(np.stack(res.allfuns), G(f"{tag}.fista.allfuns"), rtol=1e-5)
+
+
+def test_device_dual_solver_cfg4_size():
+    """BASELINE cfg4 size (FDS n = 1e6, m = 3): every thread of the persistent kernel keeps its 8
+    elements of (J, y) in registers; result against the host loop of the same solver."""
+    from zfista_amd.multiobjective import X_K, X_NEW
+    from zfista_amd.problems import FDS
+
+    n = 10**6
+    p = FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0, 1, 2])
+    x0 = np.random.default_rng(1).uniform(-2, 2, n)
+    eng = p._engine()
+    eng.set_x0(x0)
+    f0, g0 = eng.eval_F(X_K)
+    f_y = eng.prepare()
+    lr = 1e-7
+    w_h, fun_h, nit_h = eng.solve_dual(lr, f_y, f0 + g0, False, None, 1e-12, 100000)
+    before = eng.n_dual_evals
+    w_d, fun_d, nit_d, err_d, f_d, g_d, _ = eng.solve_dual_device(lr, f_y, f0 + g0, False, None, 1e-12, 100000)
+    assert eng.n_dual_evals - before >= 4
+    # f(y) formed on the device (prepare_async): the same search, f(y) to the last bits of exp()
+    eng.prepare_async()
+    w_a, fun_a, nit_a, err_a, _, _, f_y_a = eng.solve_dual_device(lr, None, f0 + g0, False, None, 1e-12, 100000)
+    np.testing.assert_allclose(f_y_a, f_y, rtol=1e-15)
+    np.testing.assert_allclose(w_a[1:], w_d[1:], rtol=0, atol=1e-9)
+    x_d = eng.get(X_NEW)
+    F_x = eng.eval_F(X_NEW)
+    np.testing.assert_allclose(f_d, F_x[0], rtol=1e-12)
+    np.testing.assert_allclose(g_d, F_x[1], rtol=1e-12)
+    err_h = eng.recover(lr, w_h)
+    x_h = eng.get(X_NEW)
+    # the first weight is ~2e-13 against a gradient row of ~1e16 (G10, cfg4 first trial): compare the
+    # STEPS, to the accuracy two summation orders of f_1 ~ 1.7e23 allow
+    step_d, step_h = x_d - x0, x_h - x0
+    assert rel_err(step_d, step_h) <= 0.05
+    assert rel_err(x_d, x_h) <= 1e-9
+    np.testing.assert_allclose(w_d[1:], w_h[1:], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(err_d, err_h, rtol=0.05)
+
+
 def test_fds_1e6_dual_eval_consistency():
     """BASELINE cfg4 size (n = 10^6, m = 3): one dual evaluation against the oracle's
     NumPy expressions on the same J, y, w (no SciPy in the loop)."""

@@ -137,6 +137,12 @@ SIGNATURES = {
     "zf_mo_solve_dual": (C.c_int, [_P, C.c_double, _P, _P, C.c_int32, _P, C.c_double, C.c_int64, _P,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int64)]),
+    "zf_mo_solve_dual_device": (C.c_int, [_P, C.c_double, _P, _P, C.c_int32, _P, C.c_double, C.c_int64, _P,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_double), _P, _P, _P]),
+    "zf_mo_prepare_async": (C.c_int, [_P]),
+    "zf_mo_get_f_y": (C.c_int, [_P, _P]),
+    "zf_mo_solve_stats": (C.c_int, [_P, _P]),
     "zf_mo_recover": (C.c_int, [_P, C.c_double, _P, _P]),
     "zf_mo_commit": (C.c_int, [_P, C.c_double, C.c_int32]),
     "zf_mo_get": (C.c_int, [_P, C.c_int32, _P]),

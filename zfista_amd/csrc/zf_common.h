@@ -37,6 +37,14 @@ static inline int zf_grid_for(int64_t items_per_thread_units) {
     return (int)blocks;
 }
 
+// ---- hand-over of doubles between workgroups of one launch (agent scope) ----
+__device__ __forceinline__ void zf_publish(double* p, double v) {   // 8-byte write-through store
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double zf_consume(const double* p) {     // sc1 load, bypasses this CU's L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- wave64 + LDS block reductions ----------------------------------------
 // Fixed shuffle tree (offsets 32..1) inside the wave, lane 0 of each wave
 // stages its value in LDS, thread k adds the four wave values in wave order:

@@ -130,12 +130,6 @@ template <bool NT> __device__ __forceinline__ void zf_st2(zf_d2* p, zf_d2 v) {
     if (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
-__device__ __forceinline__ void zf_publish(double* p, double v) {   // 8-byte write-through store
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double zf_consume(const double* p) {     // sc1 load, bypasses this CU's L1
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 constexpr int ZF_MAX_SUB = ZF_MAX_SUB_ITERS;   // trials chained per pass (temporal blocking), upper bound
 constexpr int ZF_MAX_RING = 4;

@@ -236,6 +236,468 @@ __global__ __launch_bounds__(64 * MO_RED_WAVES) void k_mo_reduce(const double* _
     }
 }
 
+
+// f(y) from the raw sums, on the device (zf_mo_prepare_async: no host round trip between the sums
+// of f(y), the Jacobian kernel that needs sum(y), and the dual search that needs f(y))
+__global__ void k_f_from_sums(int kind, double dn, const double* __restrict__ t, double* __restrict__ f_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (kind == ZF_MO_JOS1) {
+        const double n0 = sqrt(t[0]), n1 = sqrt(t[1]);
+        f_out[0] = n0 * n0 / dn;
+        f_out[1] = n1 * n1 / dn;
+    } else {
+        const double nx = sqrt(t[2]);
+        f_out[0] = t[0] / (dn * dn);
+        f_out[1] = exp(t[1] / dn) + nx * nx;
+        f_out[2] = t[3] / (dn * (dn + 1));
+    }
+}
+
+// ---- the whole dual search of one trial in ONE persistent kernel (dual_solver="device") ---------
+// Grid: one workgroup of MO_SOLVE_TPB threads per CU (all co-resident).  Every workgroup copies its
+// share of (J, y) into LDS once - up to ~156 KB of the CU's 160 KB: n = 1e6, m = 3 needs 125 KB per
+// workgroup, so a dual evaluation then touches no global memory at all; elements beyond the LDS
+// capacity are streamed from L2 / HBM per evaluation.
+// Per batch of points the zf_dual::machine asks for:
+//   every workgroup: sums of the batch over its elements -> workgroup totals published write-through
+//   -> one ticket; the LAST ARRIVER adds the workgroup totals in index order (deterministic, no float
+//   atomics), publishes the batch totals and bumps a generation word; every workgroup picks them up,
+//   composes D(w), grad D(w) (proximal_gradient.py:161-177) and lets lane 0 advance its own copy of
+//   the machine - all copies see the same numbers in the same order and stay in lock step, so no
+//   state is ever broadcast.  At the end the primal recovery x+ = prox(lr w*, y - lr w* @ J) (:206)
+//   and max|x+ - y| (:510) are fused in.  One launch, one result read-back per trial.
+constexpr int MO_SOLVE_TPB = 512;
+constexpr int MO_SOLVE_LDS_BYTES = 156 * 1024;   // dynamic LDS for the resident elements (static LDS: ~3 KB)
+constexpr int MO_SOLVE_WAVES = MO_SOLVE_TPB / 64;
+constexpr unsigned MO_SPIN_LIMIT = 1u << 24;   // polls (each >= ~100 ns): a stuck grid gives up after seconds
+
+struct mo_solve_result {
+    double w[MO_MAX_M];
+    double fun, err;
+    int64_t nit, evals, batches;
+    int32_t ok;        // 1 solved, 0 not attempted (non-finite start), -1 the grid-wide wait timed out
+    int32_t reserved;
+    int64_t cyc_total, cyc_eval, cyc_combine, cyc_step;   // workgroup 0, shader-clock cycles (diagnostics)
+    // F(x+) of the recovered point (tail_kind != 0): raw sums of f (problem-specific, see
+    // mo_builtin_f) and of g: [0..m) sum |x+ - s_i|, [m] box violations
+    double f_sums[4], g_sums[MO_MAX_M + 1];
+    int32_t has_F, reserved2;
+    double f_y[MO_MAX_M];   // f(y) the search used (computed on the device after zf_mo_prepare_async)
+};
+
+struct mo_solve_args {
+    const double* J;
+    const double* y;
+    double* xn;
+    mo_g G;
+    int64_t n;
+    double lr;
+    double f_y[MO_MAX_M], F_old[MO_MAX_M];
+    const double* f_y_dev;   // f(y) left on the device by zf_mo_prepare_async (else NULL: f_y[] above)
+    int deprecated, has_w0;
+    double w0[MO_MAX_M];
+    double tol;
+    int64_t max_iter;
+    int resident_rows;    // elements per thread kept in LDS (rows of MO_SOLVE_TPB elements)
+    int tail_kind;        // ZF_MO_JOS1 / ZF_MO_FDS: also evaluate f(x+), g(x+) (:295); 0: g only
+    double* partials;     // [2][MAXB * NQ][gridDim.x]
+    double* totals;       // [2][MAXB * NQ]
+    unsigned* sync;       // [0] arrival tickets (monotonic), [16] generation; zeroed before the launch
+    mo_solve_result* out;
+};
+
+template <int M>
+__device__ __forceinline__ double mo_prox_t(const mo_g& G, const double* coef, double tail_sum, double x, int64_t j) {
+    if (G.has_l1) {
+        x = zf_soft_threshold(x + tail_sum - G.shift[0] + G.shift[0], coef[0]);
+#pragma unroll
+        for (int i = 1; i < M; ++i) x = zf_soft_threshold(x - coef[i] - G.shift[i], coef[i]) + G.shift[i];
+    }
+    if (G.has_box) x = zf_clip(x, G.lo_v ? G.lo_v[j] : G.lo, G.hi_v ? G.hi_v[j] : G.hi);
+    return x;
+}
+
+// one element's contribution to the 2M+2 sums of a dual evaluation (k_dual_eval's arithmetic)
+template <int M>
+__device__ __forceinline__ void mo_dual_terms(const mo_g& G, const double (&w)[M], const double (&coef)[M],
+                                              double tail_sum, double lr, const double (&Jc)[M], double yj, int64_t j,
+                                              double (&acc)[2 * M + 2]) {
+    double wJ = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) wJ += w[i] * Jc[i];
+    const double v = yj - lr * wJ;
+    const double p = mo_prox_t<M>(G, coef, tail_sum, v, j);
+#pragma unroll
+    for (int i = 0; i < M; ++i) acc[i] += fabs(p - G.shift[i]);
+    const double dv = p - v;
+    acc[M] += dv * dv;
+    acc[M + 1] += wJ * wJ;
+    const double dy = p - yj;
+#pragma unroll
+    for (int i = 0; i < M; ++i) acc[M + 2 + i] += Jc[i] * dy;
+}
+
+// grid-wide hand-over of `count` doubles per workgroup: publish -> ticket -> last arriver reduces
+// (sums; quantity max_index, if >= 0, a maximum) in workgroup-index order -> totals + generation.  On return lds_tot[0..count)
+// holds the grid totals in every workgroup.  Returns false if the wait timed out.
+__device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, count */, int count, int max_index,
+                                                double* partials, double* totals, unsigned* sync, unsigned epoch,
+                                                double* lds_tot, int* lds_flag) {
+    const int G = (int)gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < count) zf_publish(partials + (int64_t)tid * G + blockIdx.x, my_vals[tid]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == epoch * (unsigned)G + (unsigned)(G - 1));
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *lds_flag = last;
+    }
+    __syncthreads();
+    if (*lds_flag) {
+        // last arriver: wave w adds quantities w, w + WAVES, ...; lane l takes workgroups l, l + 64, ...
+        // (index order; all loads of a wave are issued before the first use: one memory round trip)
+        constexpr int QW = 4, GL = 4;   // quantities per wave (<= 32 in all), workgroups per lane (<= 256)
+        double pv[QW][GL];
+#pragma unroll
+        for (int a = 0; a < QW; ++a) {
+            const int q = wave + a * MO_SOLVE_WAVES;
+#pragma unroll
+            for (int c = 0; c < GL; ++c) {
+                const int g = lane + 64 * c;
+                pv[a][c] = (q < count && g < G) ? zf_consume(partials + (int64_t)q * G + g) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < QW; ++a) {
+            const int q = wave + a * MO_SOLVE_WAVES;
+            const bool is_max = (q == max_index);
+            double v = pv[a][0];
+#pragma unroll
+            for (int c = 1; c < GL; ++c) v = is_max ? fmax(v, pv[a][c]) : v + pv[a][c];
+            v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
+            if (lane == 0 && q < count) zf_publish(totals + q, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sync + 16, epoch + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        unsigned spins = 0;
+        int okay = 1;
+        while (__hip_atomic_load(sync + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + 1u) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > MO_SPIN_LIMIT) {
+                okay = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *lds_flag = okay;
+    }
+    __syncthreads();
+    if (!*lds_flag) return false;
+    if (tid < count) lds_tot[tid] = zf_consume(totals + tid);
+    __syncthreads();
+    return true;
+}
+
+// One step of the solver's state machine, by ONE lane: LDS -> registers -> advance -> LDS (constant
+// indices throughout: ~80 registers, no scratch, no dependent LDS round trips in the dense helpers).
+// (A first version kept the resident elements in 64 registers per thread: together with this step
+// the kernel needed > 256 VGPRs and spilled; the elements now live in LDS.)
+template <int M>
+__device__ __forceinline__ void mo_machine_step(zf_dual::machine<M>* s_mach, const double* s_fun,
+                                                          const double (*s_jac)[M]) {
+    constexpr int NB = zf_dual::machine<M>::NB;
+    zf_dual::machine<M> mach = *s_mach;
+    double funs[NB], jacs[NB][M];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        funs[k] = s_fun[k];
+#pragma unroll
+        for (int i = 0; i < M; ++i) jacs[k][i] = s_jac[k][i];
+    }
+    mach.advance(funs, jacs);
+    *s_mach = mach;
+}
+
+template <int M>
+__global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
+    constexpr int NQ = 2 * M + 2;
+    extern __shared__ double s_data[];   // [(M + 1) x ER x MO_SOLVE_TPB]: J rows, then y
+    // The solver's state machine rests in LDS between batches; thread 0 advances it on a register
+    // copy (constant indices throughout: no scratch, no dependent LDS round trips inside the
+    // dense helpers) - its ~100 registers are then live only inside that step, not across the
+    // evaluation loops that hold the resident elements.
+    constexpr int NB = zf_dual::machine<M>::NB;
+    __shared__ zf_dual::machine<M> s_mach;
+    __shared__ double s_w[NB][M], s_coef[NB][M], s_tail[NB];
+    __shared__ double s_red[MO_SOLVE_WAVES * NB * NQ];
+    __shared__ double s_mine[NB * NQ], s_tot[NB * NQ];
+    __shared__ double s_fun[NB], s_jac[NB][M];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x;
+    const int64_t n = A.n;
+    const int64_t stride = (int64_t)gridDim.x * MO_SOLVE_TPB;
+    const int64_t j0 = (int64_t)blockIdx.x * MO_SOLVE_TPB + tid;
+
+    // this workgroup's first ER rows of elements stay in LDS for the whole search; element (e, tid)
+    // is j = j0 + e * stride and sits at [row e][tid] of every plane: conflict-free
+    const int ER = A.resident_rows;
+    for (int e = 0; e < ER; ++e) {
+        const int64_t j = j0 + e * stride;
+        s_data[((int64_t)M * ER + e) * MO_SOLVE_TPB + tid] = j < n ? A.y[j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) s_data[((int64_t)i * ER + e) * MO_SOLVE_TPB + tid] = j < n ? A.J[(int64_t)i * n + j] : 0.0;
+    }
+    if (tid == 0) {
+        zf_dual::machine<M> mach;
+        mach.start(A.has_w0 ? A.w0 : nullptr, A.tol, (long)A.max_iter);
+        s_mach = mach;
+    }
+    __syncthreads();
+
+    unsigned epoch = 0;
+    int64_t evals = 0, batches = 0;
+    int timed_out = 0;
+    int64_t c_eval = 0, c_comb = 0, c_step = 0;
+    const int64_t c_begin = clock64();
+    while (!s_mach.done()) {
+        const int64_t c0 = clock64();
+        const int npts = s_mach.npts;
+        if (tid < npts) {   // weights of point `tid` (proximal_gradient.py:164, problems.py:127)
+            double tail = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const double wi = s_mach.pts[tid][i];
+                s_w[tid][i] = wi;
+                s_coef[tid][i] = A.G.has_l1 ? (A.lr * wi) * A.G.ratio[i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 1; i < M; ++i) tail += s_coef[tid][i];
+            s_tail[tid] = tail;
+        }
+        __syncthreads();
+        {
+            // one pass over the workgroup's elements for ALL points of the batch: an element is read
+            // from LDS once; NB x NQ running sums per thread
+            double w[NB][M], coef[NB][M], tail[NB], acc[NB * NQ];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    w[k][i] = s_w[k][i];
+                    coef[k][i] = s_coef[k][i];
+                }
+                tail[k] = s_tail[k];
+            }
+#pragma unroll
+            for (int q = 0; q < NB * NQ; ++q) acc[q] = 0.0;
+            auto element = [&](const double (&Jc)[M], double yj, int64_t j) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    if (k < npts) {
+                        double a8[NQ];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) a8[q] = acc[k * NQ + q];
+                        mo_dual_terms<M>(A.G, w[k], coef[k], tail[k], A.lr, Jc, yj, j, a8);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) acc[k * NQ + q] = a8[q];
+                    }
+                }
+            };
+            for (int e = 0; e < ER; ++e) {
+                const int64_t j = j0 + e * stride;
+                if (j >= n) break;
+                double Jc[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) Jc[i] = s_data[((int64_t)i * ER + e) * MO_SOLVE_TPB + tid];
+                element(Jc, s_data[((int64_t)M * ER + e) * MO_SOLVE_TPB + tid], j);
+            }
+            for (int64_t j = j0 + ER * stride; j < n; j += stride) {   // beyond the LDS-resident part
+                double Jc[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) Jc[i] = A.J[(int64_t)i * n + j];
+                element(Jc, A.y[j], j);
+            }
+            // all NB x NQ workgroup sums with ONE transposing butterfly per wave (zf_wave_reduce_multi:
+            // the pairing of a shuffle tree per quantity), then the wave totals in wave order
+            constexpr int NV = NB * NQ;
+            constexpr int H = (NV % 8 == 0) ? 3 : (NV % 4 == 0) ? 2 : (NV % 2 == 0) ? 1 : 0;
+            const int lane = tid & 63, wave = tid >> 6;
+            zf_wave_reduce_multi<NV, H, false>(acc, lane);
+            if ((lane & ((64 >> H) - 1)) == 0) {
+#pragma unroll
+                for (int q = 0; q < (NV >> H); ++q) s_red[wave * NV + zf_wave_reduce_multi_index<NV, H>(q, lane)] = acc[q];
+            }
+            __syncthreads();
+            if (tid < NV) {
+                double v = s_red[tid];
+#pragma unroll
+                for (int wv = 1; wv < MO_SOLVE_WAVES; ++wv) v += s_red[wv * NV + tid];
+                s_mine[tid] = v;
+            }
+            __syncthreads();
+        }
+        const int parity = (int)(epoch & 1u);
+        const int cnt = npts * NQ;
+        const int64_t c1 = clock64();
+        c_eval += c1 - c0;
+        if (!mo_grid_combine(s_mine, cnt, -1, A.partials + (int64_t)parity * zf_dual::MAXB * NQ * gridDim.x,
+                             A.totals + parity * zf_dual::MAXB * NQ, A.sync, epoch, s_tot, &s_flag)) {
+            timed_out = 1;
+            break;
+        }
+        epoch += 1;
+        batches += 1;
+        evals += npts;
+        const int64_t c2 = clock64();
+        c_comb += c2 - c1;
+        if (tid < npts) {   // D(w), grad D(w) of point `tid` from the grid totals (:165-177)
+            const double* t = s_tot + tid * NQ;
+            double g_p[M], inner = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                g_p[i] = A.G.has_l1 ? A.G.ratio[i] * t[i] : 0.0;
+                inner += s_w[tid][i] * g_p[i];
+            }
+            const double n_pv = sqrt(t[M]), n_wJ = sqrt(t[M + 1]);
+            double f = -inner - n_pv * n_pv / 2 / A.lr + A.lr / 2 * (n_wJ * n_wJ);
+            double corr = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                double jv = -g_p[i] - t[M + 2 + i];
+                if (!A.deprecated) {
+                    const double dF = A.F_old[i] - (A.f_y_dev ? A.f_y_dev[i] : A.f_y[i]);
+                    corr += s_w[tid][i] * dF;
+                    jv += dF;
+                }
+                s_jac[tid][i] = jv;
+            }
+            if (!A.deprecated) f += corr;
+            s_fun[tid] = f;
+        }
+        __syncthreads();
+        if (tid == 0) mo_machine_step<M>(&s_mach, s_fun, s_jac);   // (inlined: see above)
+        __syncthreads();
+        c_step += clock64() - c2;
+    }
+
+    // primal recovery with the dual solution (:206), max|x+ - y| (:510) and - same pass - the sums
+    // of F(x+) = f(x+) + g(x+) (:295; problems.py:101-117,193-205,312-328): the trial's acceptance
+    // test then needs nothing but this kernel's result record
+    constexpr int NT = 1 + 4 + M + 1;   // [0] max|x+ - y|  [1..5) f sums  [5..5+M) sum|x+ - s_i|  [5+M] violations
+    double tl[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tl[q] = 0.0;
+    const bool solved = !timed_out && s_mach.ok;
+    const int tail_kind = A.tail_kind;
+    if (solved) {
+        double w[M], coef[M], tail = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            w[i] = s_mach.w[i];
+            coef[i] = A.G.has_l1 ? (A.lr * w[i]) * A.G.ratio[i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 1; i < M; ++i) tail += coef[i];
+        auto one = [&](const double (&Jc)[M], double yj, int64_t j) {
+            double wJ = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) wJ += w[i] * Jc[i];
+            const double p = mo_prox_t<M>(A.G, coef, tail, yj - A.lr * wJ, j);
+            A.xn[j] = p;
+            tl[0] = fmax(tl[0], fabs(p - yj));
+            // (terms first, then unconditional accumulation at constant indices: accumulating inside
+            //  the branches made the compiler merge them into a dynamically indexed stack slot)
+            double f1 = 0.0, f2 = 0.0, f3 = 0.0, f4 = 0.0;
+            if (tail_kind == ZF_MO_JOS1) {           // k_jos1_sums
+                const double t = p - 2;
+                f1 = p * p;
+                f2 = t * t;
+            } else if (tail_kind == ZF_MO_FDS) {     // k_fds_sums (x unsharded here: global index = j)
+                const double idx = (double)(j + 1);
+                const double conv = (double)((j + 1) * (n - j));
+                const double t = p - idx, t2 = t * t;
+                f1 = idx * (t2 * t2);
+                f2 = p;
+                f3 = p * p;
+                f4 = conv * exp(-p);
+            }
+            tl[1] += f1;
+            tl[2] += f2;
+            tl[3] += f3;
+            tl[4] += f4;
+#pragma unroll
+            for (int i = 0; i < M; ++i) tl[5 + i] += fabs(p - A.G.shift[i]);   // k_g_terms
+            if (A.G.has_box)
+                tl[5 + M] += (p < (A.G.lo_v ? A.G.lo_v[j] : A.G.lo) || p > (A.G.hi_v ? A.G.hi_v[j] : A.G.hi)) ? 1.0 : 0.0;
+        };
+        for (int e = 0; e < ER; ++e) {
+            const int64_t j = j0 + e * stride;
+            if (j >= n) break;
+            double Jc[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) Jc[i] = s_data[((int64_t)i * ER + e) * MO_SOLVE_TPB + tid];
+            one(Jc, s_data[((int64_t)M * ER + e) * MO_SOLVE_TPB + tid], j);
+        }
+        for (int64_t j = j0 + ER * stride; j < n; j += stride) {
+            double Jc[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) Jc[i] = A.J[(int64_t)i * n + j];
+            one(Jc, A.y[j], j);
+        }
+    }
+    if (solved) {
+        // workgroup totals: wave butterflies, then the wave values in wave order ([0] is a maximum)
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const double v = (q == 0) ? zf_wave_max(tl[q]) : zf_wave_sum(tl[q]);
+            if (lane == 0) s_red[wave * NT + q] = v;
+        }
+        __syncthreads();
+        if (tid < NT) {
+            double v = s_red[tid];
+#pragma unroll
+            for (int wv = 1; wv < MO_SOLVE_WAVES; ++wv) v = (tid == 0) ? fmax(v, s_red[wv * NT + tid]) : v + s_red[wv * NT + tid];
+            s_mine[tid] = v;
+        }
+        __syncthreads();
+        const int parity = (int)(epoch & 1u);
+        if (!mo_grid_combine(s_mine, NT, 0, A.partials + (int64_t)parity * zf_dual::MAXB * NQ * gridDim.x,
+                             A.totals + parity * zf_dual::MAXB * NQ, A.sync, epoch, s_tot, &s_flag))
+            timed_out = 1;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        mo_solve_result r;
+#pragma unroll
+        for (int i = 0; i < MO_MAX_M; ++i) r.w[i] = (i < M) ? s_mach.w[i < M ? i : 0] : 0.0;
+        r.fun = s_mach.fun;
+        r.err = (solved && !timed_out) ? s_tot[0] : 0.0;
+        r.has_F = (solved && !timed_out) ? 1 : 0;
+        r.reserved2 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r.f_sums[q] = r.has_F ? s_tot[1 + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < MO_MAX_M + 1; ++q) r.g_sums[q] = (q <= M && r.has_F) ? s_tot[5 + (q <= M ? q : 0)] : 0.0;
+#pragma unroll
+        for (int i = 0; i < MO_MAX_M; ++i) r.f_y[i] = (i < M) ? (A.f_y_dev ? A.f_y_dev[i < M ? i : 0] : A.f_y[i]) : 0.0;
+        r.nit = s_mach.nit;
+        r.evals = evals;
+        r.batches = batches;
+        r.ok = timed_out ? -1 : s_mach.ok;
+        r.reserved = 0;
+        r.cyc_total = clock64() - c_begin;
+        r.cyc_eval = c_eval;
+        r.cyc_combine = c_comb;
+        r.cyc_step = c_step;
+        *A.out = r;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -260,6 +722,15 @@ struct zf_mo {
     double* bounds_v = nullptr;             // 2 n: per-coordinate lower, upper bounds (optional)
     zf_mo_exchange_fn exchange = nullptr;   // combines raw totals over the ranks, in place
     void* exchange_ctx = nullptr;
+    // device-side dual search (k_dual_solve): workspace, allocated at first use
+    double* solve_partials = nullptr;
+    double* solve_totals = nullptr;
+    unsigned* solve_sync = nullptr;
+    mo_solve_result* solve_out = nullptr;      // device
+    mo_solve_result* h_solve_out = nullptr;    // pinned host mirror
+    int solve_grid = 0;
+    double* f_y_dev = nullptr;                 // f(y) of zf_mo_prepare_async (device, MO_MAX_M)
+    bool f_y_on_device = false;
 };
 
 
@@ -391,6 +862,12 @@ extern "C" int zf_mo_destroy(zf_mo* s) {
     if (!s) return ZF_OK;
     (void)hipStreamSynchronize(s->stream);
     if (s->bounds_v) (void)hipFree(s->bounds_v);
+    if (s->solve_partials) (void)hipFree(s->solve_partials);
+    if (s->solve_totals) (void)hipFree(s->solve_totals);
+    if (s->solve_sync) (void)hipFree(s->solve_sync);
+    if (s->solve_out) (void)hipFree(s->solve_out);
+    if (s->f_y_dev) (void)hipFree(s->f_y_dev);
+    if (s->h_solve_out) (void)hipHostFree(s->h_solve_out);
     (void)hipFree(s->buf);
     (void)hipFree(s->partials);
     (void)hipFree(s->totals);
@@ -411,6 +888,20 @@ extern "C" int zf_mo_set_x0(zf_mo* s, const double* x0_host) {
     return ZF_OK;
 }
 
+// f from the raw sums of k_jos1_sums / k_fds_sums (also produced by the tail of k_dual_solve)
+static void mo_f_from_sums(int kind, double dn, const double* t, double* f_out) {
+    if (kind == ZF_MO_JOS1) {
+        const double n0 = sqrt(t[0]), n1 = sqrt(t[1]);
+        f_out[0] = n0 * n0 / dn;   // np.linalg.norm(x) ** 2 / n
+        f_out[1] = n1 * n1 / dn;
+    } else {
+        const double nx = sqrt(t[2]);
+        f_out[0] = t[0] / (dn * dn);                    // inner(idx, (x-idx)**4) / n**2
+        f_out[1] = exp(t[1] / dn) + nx * nx;            // exp(x.sum()/n) + norm(x)**2
+        f_out[2] = t[3] / (dn * (dn + 1));              // inner(conv, exp(-x)) / (n (n+1))
+    }
+}
+
 static int mo_builtin_f(zf_mo* s, const double* x, double* f_out) {
     const double dn = (double)s->n_global;
     double t[4];
@@ -418,9 +909,7 @@ static int mo_builtin_f(zf_mo* s, const double* x, double* f_out) {
         hipLaunchKernelGGL(k_jos1_sums, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, x, s->n, s->partials);
         int rc = mo_reduce_to_host(s, 2, -1, t);
         if (rc) return rc;
-        const double n0 = sqrt(t[0]), n1 = sqrt(t[1]);
-        f_out[0] = n0 * n0 / dn;   // np.linalg.norm(x) ** 2 / n
-        f_out[1] = n1 * n1 / dn;
+        mo_f_from_sums(s->kind, dn, t, f_out);
         return ZF_OK;
     }
     if (s->kind == ZF_MO_FDS) {
@@ -428,10 +917,7 @@ static int mo_builtin_f(zf_mo* s, const double* x, double* f_out) {
                            s->partials);
         int rc = mo_reduce_to_host(s, 4, -1, t);
         if (rc) return rc;
-        const double nx = sqrt(t[2]);
-        f_out[0] = t[0] / (dn * dn);                    // inner(idx, (x-idx)**4) / n**2
-        f_out[1] = exp(t[1] / dn) + nx * nx;            // exp(x.sum()/n) + norm(x)**2
-        f_out[2] = t[3] / (dn * (dn + 1));              // inner(conv, exp(-x)) / (n (n+1))
+        mo_f_from_sums(s->kind, dn, t, f_out);
         return ZF_OK;
     }
     return zf_fail(ZF_ERR_STATE, "zf_mo: f is a host callback for this problem kind");
@@ -467,12 +953,52 @@ extern "C" int zf_mo_prepare(zf_mo* s, double* f_y_out) {
     ZF_REQUIRE(s && f_y_out, "zf_mo_prepare: null argument");
     int rc = mo_builtin_f(s, s->y, f_y_out);   // leaves the raw sums in s->totals (FDS needs sum x)
     if (rc) return rc;
+    s->f_y_on_device = false;
     if (s->kind == ZF_MO_JOS1)
         hipLaunchKernelGGL(k_jos1_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n, s->n_global);
     else
         hipLaunchKernelGGL(k_fds_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n, s->n_global,
                            s->offset, s->totals);
     ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+// The same without a host round trip (unsharded built-in problems): the sums of f(y) are reduced on
+// the device, f(y) is formed there (k_f_from_sums) and stays there for zf_mo_solve_dual_device, which
+// reports it back with its result; the Jacobian kernel reads sum(y) from the same device totals.
+// Everything is enqueued on the stream; nothing is synchronised.
+extern "C" int zf_mo_prepare_async(zf_mo* s) {
+    ZF_REQUIRE(s, "zf_mo_prepare_async: null argument");
+    ZF_REQUIRE(s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS, "zf_mo_prepare_async: f is a host callback for this kind");
+    ZF_REQUIRE(!s->exchange, "zf_mo_prepare_async: x is sharded over ranks (use zf_mo_prepare)");
+    if (!s->f_y_dev) ZF_HIP(hipMalloc(&s->f_y_dev, sizeof(double) * MO_MAX_M));
+    int nq = 2;
+    if (s->kind == ZF_MO_JOS1) {
+        hipLaunchKernelGGL(k_jos1_sums, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->n, s->partials);
+    } else {
+        nq = 4;
+        hipLaunchKernelGGL(k_fds_sums, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->n, s->n_global, s->offset,
+                           s->partials);
+    }
+    hipLaunchKernelGGL(k_mo_reduce, dim3(1), dim3(64 * MO_RED_WAVES), 0, s->stream, s->partials, s->grid, nq, -1, s->totals);
+    hipLaunchKernelGGL(k_f_from_sums, dim3(1), dim3(64), 0, s->stream, s->kind, (double)s->n_global, s->totals, s->f_y_dev);
+    if (s->kind == ZF_MO_JOS1)
+        hipLaunchKernelGGL(k_jos1_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n, s->n_global);
+    else
+        hipLaunchKernelGGL(k_fds_jac, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->J, s->n, s->n_global,
+                           s->offset, s->totals);
+    ZF_HIP(hipGetLastError());
+    s->f_y_on_device = true;
+    return ZF_OK;
+}
+
+// f(y) of the last zf_mo_prepare_async (synchronises the stream; only needed when the device search
+// was not attempted and the host continues)
+extern "C" int zf_mo_get_f_y(zf_mo* s, double* f_y_out) {
+    ZF_REQUIRE(s && f_y_out && s->f_y_dev && s->f_y_on_device, "zf_mo_get_f_y: no zf_mo_prepare_async result");
+    ZF_HIP(hipMemcpyAsync(s->h_totals, s->f_y_dev, sizeof(double) * s->m, hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    memcpy(f_y_out, s->h_totals, sizeof(double) * s->m);
     return ZF_OK;
 }
 
@@ -556,6 +1082,119 @@ extern "C" int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const do
     *fun_out = fun;
     *nit_out = nit;
     *ok_out = ok;
+    return ZF_OK;
+}
+
+// The same search inside ONE persistent kernel (k_dual_solve), primal recovery included: on return
+// x+ is in its buffer and *err_out = max|x+ - y| (what zf_mo_recover would have produced).  One
+// launch and one 128-byte read-back per trial; no host round trip per dual evaluation.
+// f_x_out / g_x_out (m each, may be NULL): f(x+), g(x+) from sums taken in the same pass (:295) - f_x_out[0]
+// is NaN when f is a host callback (ZF_MO_GENERIC).  f_y may be NULL after zf_mo_prepare_async (f(y) is
+// then read on the device); f_y_out (m, may be NULL) receives the f(y) the search used, also when it
+// was not attempted.
+// *ok_out = 0: not attempted (non-finite start, sharded x, unsupported m) - use zf_mo_solve_dual /
+// the reference's calls and zf_mo_recover instead.
+extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
+                                       const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
+                                       int64_t* nit_out, int32_t* ok_out, int64_t* evals_out, double* err_out,
+                                       double* f_x_out, double* g_x_out, double* f_y_out) {
+    ZF_REQUIRE(s && F_old && w_out && fun_out && nit_out && ok_out && err_out, "zf_mo_solve_dual_device: null argument");
+    ZF_REQUIRE(f_y || s->f_y_on_device, "zf_mo_solve_dual_device: f_y is NULL and no zf_mo_prepare_async result exists");
+    ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_solve_dual_device: lr must be > 0 and max_iter >= 1");
+    *ok_out = 0;
+    if (evals_out) *evals_out = 0;
+    if (s->exchange) return ZF_OK;   // x sharded over ranks: every evaluation needs an exchange (host loop)
+    if (!s->solve_partials) {
+        int dev = 0, cus = 0;
+        ZF_HIP(hipGetDevice(&dev));
+        ZF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        int64_t g = (s->n + MO_SOLVE_TPB - 1) / MO_SOLVE_TPB;
+        if (g > cus) g = cus;      // one workgroup per CU: the whole grid is resident (grid-wide waits)
+        if (g < 1) g = 1;
+        s->solve_grid = (int)g;
+        const size_t nq = 2 * MO_MAX_M + 2;
+        ZF_HIP(hipMalloc(&s->solve_partials, sizeof(double) * 2 * zf_dual::MAXB * nq * s->solve_grid));
+        ZF_HIP(hipMalloc(&s->solve_totals, sizeof(double) * 2 * zf_dual::MAXB * nq));
+        ZF_HIP(hipMalloc(&s->solve_sync, 256));
+        ZF_HIP(hipMalloc(&s->solve_out, sizeof(mo_solve_result)));
+        ZF_HIP(hipHostMalloc((void**)&s->h_solve_out, sizeof(mo_solve_result), hipHostMallocDefault));
+    }
+    mo_solve_args A;
+    memset(&A, 0, sizeof(A));
+    A.J = s->J;
+    A.y = s->y;
+    A.xn = s->xb[(s->cur + 1) % 3];
+    A.G = s->G;
+    A.n = s->n;
+    A.lr = lr;
+    for (int i = 0; i < s->m; ++i) {
+        A.f_y[i] = f_y ? f_y[i] : 0.0;
+        A.F_old[i] = F_old[i];
+        if (w0) A.w0[i] = w0[i];
+    }
+    A.f_y_dev = f_y ? nullptr : s->f_y_dev;
+    A.deprecated = deprecated;
+    A.has_w0 = w0 != nullptr;
+    A.tol = tol;
+    A.max_iter = max_iter;
+    A.tail_kind = (s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS) ? s->kind : 0;
+    A.partials = s->solve_partials;
+    A.totals = s->solve_totals;
+    A.sync = s->solve_sync;
+    A.out = s->solve_out;
+    ZF_HIP(hipMemsetAsync(s->solve_sync, 0, 256, s->stream));
+    const dim3 grid(s->solve_grid), block(MO_SOLVE_TPB);
+    // rows of MO_SOLVE_TPB elements a workgroup owns / can keep in LDS
+    const int64_t per_wg = (s->n + (int64_t)s->solve_grid * MO_SOLVE_TPB - 1) / ((int64_t)s->solve_grid * MO_SOLVE_TPB);
+    const int64_t cap = MO_SOLVE_LDS_BYTES / ((int64_t)(s->m + 1) * MO_SOLVE_TPB * sizeof(double));
+    A.resident_rows = (int)(per_wg < cap ? per_wg : cap);
+    const size_t lds = (size_t)A.resident_rows * (s->m + 1) * MO_SOLVE_TPB * sizeof(double);
+    switch (s->m) {
+        case 2:
+            ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_dual_solve<2>, grid, block, lds, s->stream, A);
+            break;
+        case 3:
+            ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_dual_solve<3>, grid, block, lds, s->stream, A);
+            break;
+        default: return ZF_OK;   // larger m: host loop (register budget of the resident elements + machine)
+    }
+    ZF_HIP(hipGetLastError());
+    ZF_HIP(hipMemcpyAsync(s->h_solve_out, s->solve_out, sizeof(mo_solve_result), hipMemcpyDeviceToHost, s->stream));
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    const mo_solve_result& r = *s->h_solve_out;
+    if (evals_out) *evals_out = r.evals;
+    if (f_y_out)
+        for (int i = 0; i < s->m; ++i) f_y_out[i] = r.f_y[i];
+    if (r.ok < 0) return zf_fail(ZF_ERR_STATE, "zf_mo_solve_dual_device: a grid-wide wait timed out (is another kernel "
+                                               "occupying the GPU?)");
+    if (r.ok == 0) return ZF_OK;
+    for (int i = 0; i < s->m; ++i) w_out[i] = r.w[i];
+    *fun_out = r.fun;
+    *nit_out = r.nit;
+    *err_out = r.err;
+    *ok_out = 1;
+    // F(x+) from the sums of the same kernel (:295): g always, f for the built-in problems
+    if (g_x_out)
+        for (int i = 0; i < s->m; ++i) {
+            if (s->G.has_box && r.g_sums[s->m] > 0.0) g_x_out[i] = INFINITY;      // problems.py:104-106
+            else g_x_out[i] = s->G.has_l1 ? s->G.ratio[i] * r.g_sums[i] : 0.0;     // :112-117
+        }
+    if (f_x_out) {
+        if (A.tail_kind) mo_f_from_sums(s->kind, (double)s->n_global, r.f_sums, f_x_out);
+        else f_x_out[0] = NAN;   // f is a host callback for this kind
+    }
+    return ZF_OK;
+}
+
+// diagnostics of the last zf_mo_solve_dual_device call: [0] batches, [1] evaluations, [2..5] shader-clock
+// cycles of workgroup 0: whole kernel, evaluation loops, grid-wide hand-overs, solver steps
+extern "C" int zf_mo_solve_stats(zf_mo* s, int64_t out[6]) {
+    ZF_REQUIRE(s && out && s->h_solve_out, "zf_mo_solve_stats: no device solve has run");
+    const mo_solve_result& r = *s->h_solve_out;
+    out[0] = r.batches, out[1] = r.evals, out[2] = r.cyc_total, out[3] = r.cyc_eval, out[4] = r.cyc_combine,
+    out[5] = r.cyc_step;
     return ZF_OK;
 }
 

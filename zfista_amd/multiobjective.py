@@ -139,6 +139,15 @@ class MoEngine:
         self._check(self.lib.zf_mo_prepare(self.h, C.c_void_p(_lib.ptr(f_y))), "zf_mo_prepare")
         return f_y
 
+    def prepare_async(self):
+        """prepare() without the host round trip: f(y) stays on the device for solve_dual_device."""
+        self._check(self.lib.zf_mo_prepare_async(self.h), "zf_mo_prepare_async")
+
+    def get_f_y(self):
+        f_y = np.zeros(self.m)
+        self._check(self.lib.zf_mo_get_f_y(self.h, C.c_void_p(_lib.ptr(f_y))), "zf_mo_get_f_y")
+        return f_y
+
     def set_jac(self, J):
         J = np.ascontiguousarray(np.asarray(J, dtype=np.float64))
         if J.shape != (self.m, self.n):
@@ -179,6 +188,38 @@ class MoEngine:
         if not ok.value:
             return None
         return w, np.float64(fun.value), int(nit.value)
+
+    def solve_dual_device(self, lr, f_y, F_old, deprecated, w0, tol, max_iter):
+        """The dual search AND the primal recovery of a trial in one persistent kernel
+        (zf_mo_solve_dual_device, dual_solver="device").  ``f_y`` None: take f(y) from the device
+        (after prepare_async()).  Returns (weight, fun, nit, err, f_x, g_x, f_y)
+        with x+ left in its buffer (f_x is None when f is a host callback), or None when it was not attempted (non-finite start, sharded x,
+        m > 3): the caller continues with solve_dual() / the reference's calls and recover()."""
+        f_y = None if f_y is None else np.ascontiguousarray(f_y, dtype=np.float64)
+        F_old = np.ascontiguousarray(F_old, dtype=np.float64)
+        w0 = None if w0 is None else np.ascontiguousarray(w0, dtype=np.float64)
+        w, f_x, g_x, f_y_used = np.zeros(self.m), np.zeros(self.m), np.zeros(self.m), np.zeros(self.m)
+        fun, nit, ok, evals, err = C.c_double(0.0), C.c_int64(0), C.c_int32(0), C.c_int64(0), C.c_double(0.0)
+        rc = self.lib.zf_mo_solve_dual_device(self.h, float(lr), None if f_y is None else C.c_void_p(_lib.ptr(f_y)),
+                                              C.c_void_p(_lib.ptr(F_old)),
+                                              int(bool(deprecated)), None if w0 is None else C.c_void_p(_lib.ptr(w0)),
+                                              float(tol), int(max_iter), C.c_void_p(_lib.ptr(w)), C.byref(fun),
+                                              C.byref(nit), C.byref(ok), C.byref(evals), C.byref(err),
+                                              C.c_void_p(_lib.ptr(f_x)), C.c_void_p(_lib.ptr(g_x)),
+                                              C.c_void_p(_lib.ptr(f_y_used)))
+        self.n_dual_evals += int(evals.value)
+        self._check(rc, "zf_mo_solve_dual_device")
+        if not ok.value:
+            return None
+        return (w, np.float64(fun.value), int(nit.value), np.float64(err.value),
+                None if np.isnan(f_x[0]) else f_x, g_x, f_y_used)
+
+    def solve_stats(self):
+        """Diagnostics of the last solve_dual_device(): batches, evaluations and the shader-clock
+        cycles workgroup 0 spent in total / evaluating / in grid-wide hand-overs / advancing the solver."""
+        out = np.zeros(6, dtype=np.int64)
+        _lib.check(self.lib.zf_mo_solve_stats(self.h, C.c_void_p(_lib.ptr(out))), "zf_mo_solve_stats")
+        return dict(zip(("batches", "evals", "cyc_total", "cyc_eval", "cyc_combine", "cyc_step"), map(int, out)))
 
     def recover(self, lr, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
@@ -440,7 +481,14 @@ def solve_native(problem, x0, o):
         _, g_val = eng.eval_F(which, builtin_f=False)
         return np.asarray(problem.f(eng.get(which)), dtype=np.float64), g_val
 
+    # dual_solver="device" on a built-in problem: f(y), J are enqueued without a host round trip and
+    # f(y) comes back with the result of the trial's one kernel
+    lazy_f_y = dual_solver == "device" and not host_f and eng.group is None and m <= 3
+
     def prepare():
+        if lazy_f_y:
+            eng.prepare_async()
+            return None
         if not host_f:
             return eng.prepare()
         y = eng.get(Y)
@@ -462,17 +510,28 @@ def solve_native(problem, x0, o):
             f_y = prepare()             # f(y_k), J = jac_f(y_k): once per line search (y_k is fixed)
             accepted = False
             for _ in range(o["max_backtrack_iter"]):
-                out = None
-                if use_native:   # the library's own dual solver: no Python between the evaluations
+                out = err = F_dev = None
+                if dual_solver == "device":   # search + recovery + F(x+) in one persistent kernel
+                    out = eng.solve_dual_device(lr, f_y, F_old, o["deprecated"], w0, o["tol_internal"],
+                                                o["max_iter_internal"])
+                    if out is not None:
+                        out, err, F_dev, f_y = out[:3], out[3], out[4:6], out[6]
+                if f_y is None:   # the device search was not attempted (non-finite start): fetch f(y)
+                    f_y = eng.get_f_y()
+                if out is None and use_native:   # the library's own dual solver: no Python between the evaluations
                     out = eng.solve_dual(lr, f_y, F_old, o["deprecated"], w0, o["tol_internal"],
                                          o["max_iter_internal"])
                 if out is None:
                     dual = device_dual(eng, lr, f_y, F_old, o["deprecated"])
                     out = solve_dual(dual, m, w0, o["tol_internal"], o["max_iter_internal"], dual_solver)
                 weight, dual_fun, nit_int = out
-                err = eng.recover(lr, weight)          # x+ and max|x+ - y|   (:206, :510)
+                if err is None:
+                    err = eng.recover(lr, weight)      # x+ and max|x+ - y|   (:206, :510)
                 fun = -dual_fun                         # (:207)
-                f_x, g_x = eval_F(X_NEW)
+                if F_dev is not None and F_dev[0] is not None and not host_f:
+                    f_x, g_x = F_dev                    # sums taken by the same kernel
+                else:
+                    f_x, g_x = eval_F(X_NEW)
                 F_new = f_x + g_x                       # (:295)
                 if o["warm_start"]:
                     w0 = weight
