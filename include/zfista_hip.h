@@ -195,6 +195,11 @@ int zf_solver_enqueue_decide(zf_solver* s);
 /* device addresses of this rank's packs (sub_iters x ZF_PACK_LEN doubles) and of the gathered
  * packs (world x sub_iters x ZF_PACK_LEN doubles, rank-major); zf_solver_sub_iters() tells S */
 int zf_solver_sub_iters(zf_solver* s, int32_t* sub_iters);
+/* streaming return_all (proximal_gradient.py:521-524): from now on every trial also stores its
+ * iterate x_{k+1} into slot (k + 1) % cap_slots of the caller-owned ring `hist_dev` (slots `stride`
+ * doubles apart, stride >= n and a multiple of 64) - 8 more bytes per element and iteration, no host
+ * transfer, chains stay 8 long.  Slot 0 (x0) is the caller's.  Chain lengths 1 and 8. */
+int zf_solver_set_history(zf_solver* s, double* hist_dev, int64_t cap_slots, int64_t stride);
 /* change max_iter of a live solve (stream-ordered); a solve stopped by ZF_MAXITER resumes when
  * the new bound is above nit - how a caller continues `res.nit < max_iter` runs (:539) */
 int zf_solver_set_max_iter(zf_solver* s, int64_t max_iter);

@@ -175,3 +175,62 @@ def test_large_n_geometry_is_a_function_of_n_only():
             (ref["nit"], ref["status"], ref["lr"], ref["F"], ref["trials"])
         assert np.array_equal(r["rows"], ref["rows"])
         assert np.array_equal(r["x"], ref["x"])
+
+
+@pytest.mark.parametrize("sub", [1, 8])
+@pytest.mark.parametrize("slots", [None, 19])
+def test_streaming_return_all_records_every_iterate(sub, slots):
+    """return_all on the device-resident path: every trial stores its iterate into a ring in HBM as
+    it computes it (zf_solver_set_history), chains stay 8 long, the host receives the trace rows per
+    chunk and the iterates on access.  A run with rejections (speculative iterates of a broken chain
+    are overwritten by the retry), terminated by tol in the middle of a chain; with a ring smaller
+    than the run (19 slots: iterates are moved to the host in blocks) and a roomy one - all against
+    the oracle's allvecs, bit for bit."""
+    import warnings
+
+    from oracle import cpu_ref, problems_ref as P
+    from zfista_amd import _lib
+    from zfista_amd.proximal_gradient import NativeRun
+
+    n = 10007
+    d, c, lam = P.make_pdiag(n, seed=1)
+    kw = dict(lr=4.0, nesterov=True, tol=1e-6, max_iter=400)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*P.DiagQuadL1Ref(d, c, lam).callbacks(), np.zeros(n), return_all=True, **kw)
+    o = dict(BASE)
+    o.update(kw, return_all=True, sub_iters=sub, history_slots=slots)
+    x0 = np.zeros(n)
+    run = NativeRun(_pdiag(n), x0, o)
+    assert run.sub_iters == sub
+    rows = []
+    while run.status == _lib.ZF_RUNNING:
+        rows.append(run.advance(3))
+    H = run.history()
+    assert len(H) == exp.nit + 1 == len(exp.allvecs) and H[0] is x0
+    for k in range(len(H)):
+        assert np.array_equal(H[k], exp.allvecs[k]), k
+    assert np.array_equal(H[-1], run.solver.get_x())
+    np.testing.assert_allclose(np.concatenate(rows)[:, _lib.TR_ERR], exp.allerrs, rtol=1e-10)
+    if slots:
+        assert len(run._hist_host) >= exp.nit - slots   # the ring wrapped: older iterates live on the host
+    run.solver.close()
+
+
+def test_streaming_return_all_through_the_public_entry(golden):
+    """minimize_proximal_gradient(..., return_all=True): allvecs is a sequence of NumPy arrays like
+    the reference's list; the chains are 8 long (no per-iteration host round trip)."""
+    import warnings
+
+    from zfista_amd import minimize_proximal_gradient
+
+    G = golden("g3_diag_n10007.npz")
+    tag = "fista_lr4_backtrack"
+    p = _pdiag(10007)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize_proximal_gradient(*p.callbacks(), np.zeros(10007), return_all=True, **RUNS[tag])
+    assert res.nit == int(G(f"{tag}.nit")) and len(res.allvecs) == res.nit + 1
+    assert np.array_equal(np.stack([res.allvecs[k] for k in G(f"{tag}.kept")]), G(f"{tag}.vecs"))
+    assert np.array_equal(np.asarray(res.allvecs)[-1], res.x)
+    np.testing.assert_allclose(res.allfuns, G(f"{tag}.allfuns"), rtol=1e-10)

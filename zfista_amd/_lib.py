@@ -99,6 +99,7 @@ SIGNATURES = {
     "zf_solver_enqueue_trial": (C.c_int, [_P]),
     "zf_solver_enqueue_decide": (C.c_int, [_P]),
     "zf_solver_sub_iters": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "zf_solver_set_history": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "zf_solver_set_max_iter": (C.c_int, [_P, C.c_int64]),
     "zf_solver_pack_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "zf_solver_set_pack_buffers": (C.c_int, [_P, _P, _P]),

@@ -146,6 +146,9 @@ struct zf_step_args {
     double* blk_part;         // (S * ZF_NPART) x gridDim.x per-workgroup partials, quantity-major
     int* pass_log;            // timing only (else NULL): slot pass_slot receives (lag << 8) | fresh trials
     int pass_slot;
+    double* hist;             // HIST kernels: ring of hist_cap iterates (n doubles each); the iterate of
+    int64_t hist_cap;         //   iteration k goes to slot k % hist_cap, written by the trial that computes it
+    int64_t hist_stride;      // doubles between slots (>= n, 512-B aligned)
 };
 
 struct zf_finalize_args {
@@ -309,7 +312,10 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 // otherwise `lag` replayed + `nf` < = S fresh trials, trial by trial
 // MODE 0: FULL;  1: lagging iterations replayed, then S fresh trials (no per-trial branch either:
 // the usual pass after a broken chain);  2: anything else (shorter fresh chains, materialise-only)
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE>
+// HIST: every fresh trial also stores its iterate into the history ring (streaming return_all: the
+// iterates of a chain never exist anywhere else).  A trial that turns out rejected leaves garbage in a
+// slot that the retry overwrites; replayed trials wrote theirs when they were fresh.
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST>
 __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds, const int lag, const int nf) {
     constexpr bool FULL = (MODE == 0);          // nothing replayed, S fresh trials
     constexpr bool FRESH_FULL = (MODE <= 1);    // S fresh trials
@@ -361,6 +367,8 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
                 }
                 o = a;
                 a = r;
+                if (HIST)   // x_{nit+j+1} -> its slot (16-byte stores: slots are 512-B aligned)
+                    zf_st2<NT>(reinterpret_cast<zf_d2*>(A.hist + ((nit + j + 1) % A.hist_cap) * A.hist_stride) + i, a);
             }
         }
         zf_st2<NT>(reinterpret_cast<zf_d2*>(out_last) + i, a);
@@ -413,10 +421,11 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
 #pragma unroll
         for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], first_unit + u * ZF_BLOCK);
     };
-    if constexpr (UB == ZF_TILE_U || MODE == 1) {
+    if constexpr (UB == ZF_TILE_U || MODE == 1 || HIST) {
         // short chains (<= 148 VGPRs, three or more waves per SIMD): the other waves of the SIMD
         // cover a wave's load latency; all loads of a batch in flight, then its arithmetic.
-        // (Also the replay + S fresh trials body of long chains: pipelined, its registers spill.)
+        // (Also the replay + S fresh trials body of long chains and the history-recording kernels:
+        //  pipelined, their registers spill.)
         for (int t = 0; t < A.tiles_per_wg; ++t) {
             const int64_t tile = (int64_t)t * G + blockIdx.x;
             if (tile >= full_tiles) break;
@@ -481,6 +490,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
                     else r = zf_elem_vec<NESTEROV, BOX>(a, o, q, beta[j], lr, tau, A.lo, A.hi, acc[j]);
                     o = a;
                     a = r;
+                    if (HIST) A.hist[((nit + j + 1) % A.hist_cap) * A.hist_stride + e] = a;
                 }
             }
             out_last[e] = a;
@@ -524,7 +534,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     }
 }
 
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S>
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
@@ -532,14 +542,14 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     if (A.ctl->status != ZF_RUNNING) return;
     if (S == 1) {
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = 1;
-        zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0>(A, lds, 0, 1);
+        zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, 1);
     } else {
         const int lag = A.ctl->lag;
         const int nf = zf_fresh_len(A.ctl);   // fresh trials of this chain (0: materialise only)
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = (lag << 8) | nf;
-        if (lag == 0 && nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0>(A, lds, 0, S);
-        else if (nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1>(A, lds, lag, S);
-        else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2>(A, lds, lag, nf);
+        if (lag == 0 && nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, S);
+        else if (nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1, HIST>(A, lds, lag, S);
+        else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, lag, nf);
     }
 }
 

@@ -160,6 +160,9 @@ struct zf_solver {
     int64_t first_uncollected = 0;
     double ms_full = 0.0, ms_part = 0.0;  // S-trial chains without replay / everything else
     int64_t n_full = 0, n_part = 0;
+    // streaming return_all: caller-owned ring of iterates in HBM (zf_solver_set_history)
+    double* hist = nullptr;
+    int64_t hist_cap = 0, hist_stride = 0;
 };
 constexpr int ZF_PASS_LOG = 4096;
 
@@ -295,6 +298,17 @@ extern "C" int zf_solver_destroy(zf_solver* s) {
 }
 
 // ---- launches ---------------------------------------------------------------
+// history-recording variants (nontemporal policy only: the history is write-once)
+template <bool GI, int S>
+static void zf_launch_trial_hist(zf_solver* s, const zf_step_args& a) {
+    const bool nest = s->opt.nesterov != 0;
+    dim3 g(s->grid), b(ZF_BLOCK);
+    if (nest && s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, true, true, true, S, true>), g, b, 0, s->stream, a);
+    else if (nest) hipLaunchKernelGGL((zf_trial_kernel<GI, true, false, true, S, true>), g, b, 0, s->stream, a);
+    else if (s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, false, true, true, S, true>), g, b, 0, s->stream, a);
+    else hipLaunchKernelGGL((zf_trial_kernel<GI, false, false, true, S, true>), g, b, 0, s->stream, a);
+}
+
 template <bool GI, bool NT, int S>
 static void zf_launch_trial_t3(zf_solver* s, const zf_step_args& a) {
     const bool nest = s->opt.nesterov != 0;
@@ -315,6 +329,12 @@ static void zf_launch_trial_t2(zf_solver* s, const zf_step_args& a) {
 }
 template <bool GI>
 static void zf_launch_trial_t(zf_solver* s, const zf_step_args& a) {
+    if (s->hist) {   // (zf_solver_set_history allowed only chain lengths 1 and 8)
+        if constexpr (GI) {
+            if (s->sub == 8) return zf_launch_trial_hist<GI, 8>(s, a);
+        }
+        return zf_launch_trial_hist<GI, 1>(s, a);
+    }
     if (s->nt) zf_launch_trial_t2<GI, true>(s, a);
     else zf_launch_trial_t2<GI, false>(s, a);
 }
@@ -370,6 +390,9 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
     hipEvent_t e0 = nullptr, e1 = nullptr;
     a.pass_log = nullptr;
     a.pass_slot = 0;
+    a.hist = s->hist;
+    a.hist_cap = s->hist_cap > 0 ? s->hist_cap : 1;
+    a.hist_stride = s->hist_stride;
     if (s->timing && !dry) {
         if (!s->pass_log) {
             ZF_HIP(hipMalloc(&s->pass_log, sizeof(int) * ZF_PASS_LOG));
@@ -713,6 +736,25 @@ extern "C" int zf_solver_enqueue_decide(zf_solver* s) {
     hipLaunchKernelGGL(zf_decide_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, s->trace,
                        s->beta_ring, s->sub);
     ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+// Streaming return_all (proximal_gradient.py:521-524 keeps every iterate): `hist_dev` is a caller-owned
+// ring of `cap_slots` iterates, `stride` doubles apart (>= n, a multiple of 64: slots stay 512-B
+// aligned).  From now on every trial stores its iterate x_{k+1} into slot (k + 1) % cap_slots as it
+// computes it - the iterates inside a chain of 8 exist nowhere else - so recording costs 8 more bytes
+// per element and iteration and no host transfer; x0 (slot 0) is the caller's.  The caller reads slots
+// of accepted iterations after a poll and must not let the solve run cap_slots iterations ahead of
+// what it still needs.  Chain lengths 1 and 8 only (2 and 4 fall back to 1 at creation).
+extern "C" int zf_solver_set_history(zf_solver* s, double* hist_dev, int64_t cap_slots, int64_t stride) {
+    ZF_REQUIRE(s && hist_dev && cap_slots >= 2, "zf_solver_set_history: bad argument");
+    ZF_REQUIRE(stride >= s->desc.n && stride % 64 == 0 && zf_aligned16(hist_dev),
+               "zf_solver_set_history: stride must be >= n and a multiple of 64 doubles, the ring 16-byte aligned");
+    ZF_REQUIRE(s->sub == 1 || s->sub == 8, "zf_solver_set_history: chain length must be 1 or 8");
+    ZF_REQUIRE(cap_slots > 2 * s->sub, "zf_solver_set_history: the ring must hold more than two chains");
+    s->hist = hist_dev;
+    s->hist_cap = cap_slots;
+    s->hist_stride = stride;
     return ZF_OK;
 }
 

@@ -178,6 +178,11 @@ class DeviceSolver:
             self._gather()
             self.enqueue_decide()
 
+    def set_history(self, ring_dev_ptr: int, cap_slots: int, stride: int):
+        """Streaming return_all: every trial stores its iterate into slot (k + 1) % cap_slots."""
+        _lib.check(self.lib.zf_solver_set_history(self.handle, C.c_void_p(ring_dev_ptr), int(cap_slots), int(stride)),
+                   "set_history")
+
     def flush(self):
         """One replay-only pass that stores x_k, x_{k-1} when iterates lag behind the accepted
         count (zf_control.lag); no-op otherwise."""

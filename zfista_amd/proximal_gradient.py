@@ -19,6 +19,7 @@ Two execution paths, both on the GPU (there is no host fallback):
 """
 from __future__ import annotations
 
+import collections.abc as _abc
 import ctypes as C
 import time
 from warnings import warn
@@ -37,6 +38,40 @@ _MSG_DEPRECATED = (
     "Using the deprecated option is not mathematically proven to converge. "
     "Please consider using the recommended condition instead."
 )   # :446-447
+class IterateHistory(_abc.Sequence):
+    """``allvecs`` of a device-resident solve: x_0 ... x_nit, as the reference's list is
+    (zfista/proximal_gradient.py:471,521-522), but kept where the kernels wrote it - a ring in HBM
+    (``zf_solver_set_history``) - and brought to the host iterate by iterate on access.  Iterates
+    the ring could not hold any longer were moved to host memory during the solve.  Indexing /
+    iterating yield NumPy arrays; ``device(k)`` is the iterate as a CUDA tensor view (no copy)
+    while it is still in the ring."""
+
+    def __init__(self, x0, n, length, ring, cap, stride, host):
+        self._x0, self._n, self._len = x0, n, length
+        self._ring, self._cap, self._stride, self._host = ring, cap, stride, host
+
+    def __len__(self):
+        return self._len
+
+    def device(self, k):
+        if k in self._host or self._ring is None:
+            return None
+        return self._ring[(k % self._cap) * self._stride:(k % self._cap) * self._stride + self._n]
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(self._len))]
+        if k < 0:
+            k += self._len
+        if not 0 <= k < self._len:
+            raise IndexError("iterate index out of range")
+        if k == 0:
+            return self._x0          # the caller's own object, as in the reference (:471)
+        if k not in self._host:
+            self._host[k] = self.device(k).cpu().numpy()
+        return self._host[k]
+
+
 _HEADER = ["niter", "nit internal", "max(abs(xk - yk)))", "subprob func", "learning rate"]   # :24-30
 _WIDTHS = [7, 7, 13, 13, 10]
 
@@ -127,8 +162,10 @@ class NativeRun:
             decay_rate=float(opts["decay_rate"]), max_iter=int(opts["max_iter"]),
             max_backtrack_iter=int(opts["max_backtrack_iter"]),
             nesterov=int(bool(opts["nesterov"])), deprecated=int(bool(opts["deprecated"])),
-            # return_all needs every iterate on the host: one iteration per pass then
-            sub_iters=1 if opts.get("return_all") else int(opts.get("sub_iters", 0) or 0),
+            # return_all records every iterate into a ring in HBM as the trial computes it
+            # (zf_solver_set_history): chains stay 8 long; chain lengths 2 / 4 have no recording kernel
+            sub_iters=(int(opts.get("sub_iters", 0) or 0) if not opts.get("return_all")
+                       else (1 if int(opts.get("sub_iters", 0) or 0) in (1, 2, 4) else 0)),
         )
         if solver_factory is not None:
             # test seam: a stand-in with DeviceSolver's interface (tests/fake_engine.py)
@@ -143,6 +180,8 @@ class NativeRun:
             if x0_dev.numel() != problem.n_features:
                 raise ValueError(f"len(x) should be equal to n_features, got {x0}.")
             self.solver = DeviceSolver(fields, options, keepalive=keep, group=problem.group, timing=timing)
+            if opts.get("return_all"):
+                self._init_history(x0, x0_dev, int(opts["max_iter"]), opts.get("history_slots"))
             if _snapshot is None:
                 self.solver.init(x0_dev.data_ptr())
             else:
@@ -169,6 +208,45 @@ class NativeRun:
                     _, self._t_state = momentum_factors(self.nit_seen - 1, self.ratio, None)
                 self._beta_filled = self.nit_seen
                 self._fill_beta(self.nit_seen + 1)
+
+    # -- streaming return_all -------------------------------------------------------------------
+    def _init_history(self, x0, x0_dev, max_iter, slots=None):
+        """A ring of iterates in HBM: as many slots as the solve can need, bounded by half of the free
+        device memory and - for small n - 2 GiB or 4096 slots (or ``history_slots``); what the ring cannot keep is moved
+        to the host in blocks between chunks of passes (PCIe-bound: 0.8 GB per iterate at n = 1e8)."""
+        import torch
+
+        n = x0_dev.numel()
+        stride = (n + 63) // 64 * 64
+        S = int(self.solver.sub_iters)
+        free, _ = torch.cuda.mem_get_info()
+        budget = max(2 * S + 2, (free // 2) // (8 * stride))
+        cap = int(slots) if slots else min(max_iter + 1, budget, max(4096, (2 << 30) // (8 * stride)))
+        cap = max(cap, 2 * S + 2)
+        self._hist = torch.empty(cap * stride, dtype=torch.float64, device=x0_dev.device)
+        self._hist[:n].copy_(x0_dev)
+        self._hist_x0, self._hist_n, self._hist_cap, self._hist_stride = x0, n, cap, stride
+        self._hist_host = {}          # iterates already moved to host memory
+        self._hist_saved = 0          # iterations <= this are safe (x0, or on the host)
+        self.solver.set_history(self._hist.data_ptr(), cap, stride)
+
+    def _history_room(self):
+        """Passes that may be enqueued before a slot still needed would be overwritten; iterates
+        are moved to the host first when there is no room for a single pass."""
+        S = self.sub_iters
+        room = (self._hist_saved + self._hist_cap - 1 - self.nit_seen) // S
+        if room < 1:
+            for k in range(self._hist_saved + 1, self.nit_seen + 1):   # accepted, final, still in the ring
+                lo = (k % self._hist_cap) * self._hist_stride
+                self._hist_host[k] = self._hist[lo:lo + self._hist_n].cpu().numpy()
+            self._hist_saved = self.nit_seen
+            room = (self._hist_cap - 1) // S
+        return room
+
+    def history(self):
+        """x_0 ... x_nit of the solve so far (IterateHistory), after collect()."""
+        return IterateHistory(self._hist_x0, self._hist_n, self.nit_seen + 1, self._hist, self._hist_cap,
+                              self._hist_stride, self._hist_host)
 
     def snapshot(self):
         """The state of the solve after the last advance(): x_k, x_{k-1} and the control block
@@ -223,6 +301,8 @@ class NativeRun:
     def enqueue_only(self, steps):
         # the trace / momentum rings hold ZF_RING iterations: never run further ahead of the host
         steps = int(min(steps, (_lib.ZF_RING - 1 - _lib.ZF_MAX_LAG) // self.sub_iters))
+        if getattr(self, "_hist", None) is not None:
+            steps = int(min(steps, self._history_room()))
         # + 1: the decide step of the last trial resolves the factor of the trial after it
         self._fill_beta(self.nit_seen + steps * self.sub_iters + 1)
         self.solver.enqueue(steps)
@@ -256,9 +336,11 @@ def _solve_native(problem, x0, opts, solver_factory=None):
     return_all, verbose = opts["return_all"], opts["verbose"]
     allvecs = allfuns = allerrs = None
     if return_all:
-        allvecs = [x0]
         allfuns = [np.float64(run.F0)]
         allerrs = []
+    streaming = return_all and getattr(run, "_hist", None) is not None   # (test stand-ins have no ring)
+    if return_all and not streaming:
+        allvecs = [x0]
     chunk = 1
     last_lr = float(opts["lr"])
     while run.status == _lib.ZF_RUNNING:
@@ -271,10 +353,12 @@ def _solve_native(problem, x0, opts, solver_factory=None):
                 allfuns.append(np.float64(row[_lib.TR_F]))
                 allerrs.append(np.float64(row[_lib.TR_ERR]))
             last_lr = row[_lib.TR_LR]
-        if return_all and len(rows):
+        if return_all and not streaming and len(rows):
             allvecs.append(run.solver.get_x())   # chunk == 1: exactly this iterate
-        if not return_all:
+        if streaming or not return_all:
             chunk = min(chunk * 2, 256)
+    if streaming:
+        allvecs = run.history()
     ctl = run.solver.ctl
     x = run.solver.get_x()
     F = np.float64(ctl.F_old)
