@@ -133,6 +133,9 @@ def main():
                     help="repeat the W + K block until this much timed work has run (sustained clocks)")
     ap.add_argument("--max-blocks", type=int, default=400)
     ap.add_argument("--sub-iters", type=int, default=0, help="chain length S (0 = library default 8)")
+    ap.add_argument("--libcomm", action="store_true",
+                    help="N = 1 only: run the sharded step sequence over a 1-rank RCCL communicator created "
+                         "inside the library (zf_comm): what the per-pass exchange costs without a second GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket every trial kernel with HIP events (roofline becomes null); "
@@ -176,6 +179,10 @@ def main():
     if args.total_n:
         n = args.total_n * (rank + 1) // world - args.total_n * rank // world   # this rank's block
     K, W = args.steps, args.warmup
+    if args.libcomm and world == 1:
+        from zfista_amd.comm import LibComm
+
+        group = LibComm(0, 1, LibComm.new_unique_id())
     d, c = make_inputs(n, seed=1 + rank, device="cuda")
     prob = DiagQuadL1(d, c, LAM, group=group)
     opts = dict(lr=LR, tol=0.0, tol_internal=1e-12, max_iter=max(W, 1), max_backtrack_iter=100, decay_rate=0.5,
@@ -263,8 +270,9 @@ def main():
                 "full_chain_passes": full_n if timing else None,
                 "other_passes": part_n if timing else None,
                 "tiles_per_workgroup": tiles,
-                "parallelism": f"x sharded over {world} GPU(s); per-pass scalar pack all-gather"
-                               if world > 1 else "single GPU",
+                "parallelism": f"x sharded over {world} GPU(s); per-pass scalar pack all-gather (RCCL inside the library)"
+                               if world > 1 else ("single GPU, 1-rank RCCL all-gather per pass" if args.libcomm
+                                                  else "single GPU"),
             },
         }
         if timing and (full_n or part_n):

@@ -147,6 +147,18 @@ int zf_memcpy_d2h(void* dst_host, const void* src_dev, int64_t bytes, void* stre
 int zf_memcpy_d2d(void* dst_dev, const void* src_dev, int64_t bytes, void* stream);
 int zf_stream_synchronize(void* stream);
 
+/* ---- RCCL communicator (x sharded over the GPUs of one node) -----
+ * One rank per GPU/process.  Rank 0 calls zf_comm_unique_id and ships the 128 bytes to the other ranks
+ * over any host channel; then every rank calls zf_comm_create (collective) with its GPU current.
+ * librccl is loaded with dlopen on first use - single-GPU users never need it. */
+typedef struct zf_comm zf_comm;
+int zf_comm_unique_id(void* id128);
+int zf_comm_create(zf_comm** out, int32_t rank, int32_t world, const void* id128);
+int zf_comm_destroy(zf_comm* c);
+int zf_comm_info(zf_comm* c, int32_t* rank, int32_t* world);
+/* recv (world x count doubles, rank-major) <- send (count doubles) of every rank; stream-ordered */
+int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream);
+
 /* ---- the decision step on the host (no GPU needed) ----------------------
  * Same inline function the decide kernel runs (csrc/zf_decide.h); exported so
  * the control logic of proximal_gradient.py:279-307,510,525-543 can be tested
@@ -189,7 +201,13 @@ int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles);
 /* make the next step materialise iterates that lag behind the accepted count (zf_control.lag),
  * so that buffers cur / prev hold x_k, x_{k-1} afterwards; stream-ordered, no-op without lag */
 int zf_solver_flush(zf_solver* s);
-/* world > 1: the two halves of a step; the caller gathers pack_local -> pack_all between them */
+/* world > 1 with a communicator attached: the solver issues the exchanges of a sharded step itself
+ * (packed all-gather of the scalar packs; for column-sharded least squares also of A_p x_p) on its
+ * stream - zf_solver_enqueue_steps then works for world > 1 and a pass needs no host code.
+ * zf_solver_enqueue_init_all = init + exchanges + commit in one call (world == 1 too). */
+int zf_solver_set_comm(zf_solver* s, zf_comm* comm);
+int zf_solver_enqueue_init_all(zf_solver* s, const double* x0_dev);
+/* world > 1 without one: the two halves of a step; the caller gathers pack_local -> pack_all between them */
 int zf_solver_enqueue_trial(zf_solver* s);
 int zf_solver_enqueue_decide(zf_solver* s);
 /* device addresses of this rank's packs (sub_iters x ZF_PACK_LEN doubles) and of the gathered

@@ -87,6 +87,13 @@ SIGNATURES = {
     "zf_memcpy_d2h": (C.c_int, [_P, _P, C.c_int64, _P]),
     "zf_memcpy_d2d": (C.c_int, [_P, _P, C.c_int64, _P]),
     "zf_stream_synchronize": (C.c_int, [_P]),
+    "zf_comm_unique_id": (C.c_int, [_P]),
+    "zf_comm_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, _P]),
+    "zf_comm_destroy": (C.c_int, [_P]),
+    "zf_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "zf_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "zf_solver_set_comm": (C.c_int, [_P, _P]),
+    "zf_solver_enqueue_init_all": (C.c_int, [_P, _P]),
     "zf_decide_host": (C.c_int, [C.POINTER(Control), _P, _P]),
     "zf_solver_create": (C.c_int, [C.POINTER(_P), C.POINTER(ProblemDesc), C.POINTER(Options), _P]),
     "zf_solver_destroy": (C.c_int, [_P]),

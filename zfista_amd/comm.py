@@ -1,0 +1,81 @@
+"""RCCL communicator of the library (``zf_comm``, csrc/zf_comm.hip) for a decision vector sharded
+over the GPUs of one node - one process per GPU.
+
+``LibComm`` owns one ``ncclComm_t`` created INSIDE libzfista_hip.so.  A device solver that has one
+attached (``zf_solver_set_comm``) issues the per-pass exchanges itself, on its own stream, between
+the trial and the decide kernel: a multi-rank pass is one C call with no host code per pass, exactly
+like the single-GPU case.  The 128-byte unique id travels over whatever host channel is at hand:
+
+* ``LibComm.from_group(group)`` - an initialised ``torch.distributed`` process group (the id is
+  broadcast through it once; torch is not involved afterwards);
+* ``LibComm(rank, world, unique_id)`` - the caller ships ``LibComm.new_unique_id()`` itself
+  (a file, MPI, a socket ...).
+
+Any ``NativeProblem(..., group=comm)`` accepts a ``LibComm`` in place of a process group.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _lib
+
+_CACHE = {}
+
+
+class LibComm:
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of LibComm.new_unique_id()")
+        self.lib = _lib.require_gpu()
+        self.rank, self.world = int(rank), int(world)
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _lib.check(self.lib.zf_comm_create(C.byref(h), self.rank, self.world, C.cast(buf, C.c_void_p)), "zf_comm_create")
+        self.handle = h
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        lib = _lib.require_gpu()
+        buf = (C.c_char * 128)()
+        _lib.check(lib.zf_comm_unique_id(C.cast(buf, C.c_void_p)), "zf_comm_unique_id")
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_group(cls, group=None):
+        """One communicator per torch.distributed group and process (cached).  Collective."""
+        import torch.distributed as dist
+
+        key = id(group) if group is not None else 0
+        if key in _CACHE:
+            return _CACHE[key]
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        comm = cls(rank, world, box[0])
+        _CACHE[key] = comm
+        return comm
+
+    def all_gather(self, send, recv, stream=None):
+        """recv (world x count, rank-major) <- send of every rank (float64 CUDA tensors)."""
+        import torch
+
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _lib.check(self.lib.zf_comm_all_gather(self.handle, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                               send.numel(), C.c_void_p(st)), "zf_comm_all_gather")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.zf_comm_destroy(self.handle)
+            self.handle = None
+
+
+def rank_world(group):
+    """(rank, world) of a torch.distributed group, a LibComm, or an in-process stand-in (tests)."""
+    if group is None:
+        return 0, 1
+    if isinstance(group, LibComm) or hasattr(group, "all_gather_host"):
+        return group.rank, group.world
+    import torch.distributed as dist
+
+    return dist.get_rank(group), dist.get_world_size(group)

@@ -108,6 +108,10 @@ __global__ void zf_init_commit_kernel(zf_control* ctl, const double* packs, int 
 // ---------------------------------------------------------------------------
 // solver object
 // ---------------------------------------------------------------------------
+struct zf_comm;
+extern "C" int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream);
+extern "C" int zf_comm_info(zf_comm* c, int32_t* rank, int32_t* world);
+
 struct zf_solver {
     zf_problem_desc desc;
     zf_options opt;
@@ -160,6 +164,7 @@ struct zf_solver {
     int64_t first_uncollected = 0;
     double ms_full = 0.0, ms_part = 0.0;  // S-trial chains without replay / everything else
     int64_t n_full = 0, n_part = 0;
+    zf_comm* comm = nullptr;              // RCCL communicator (zf_solver_set_comm): the solver gathers itself
     // streaming return_all: caller-owned ring of iterates in HBM (zf_solver_set_history)
     double* hist = nullptr;
     int64_t hist_cap = 0, hist_stride = 0;
@@ -782,13 +787,61 @@ extern "C" int zf_solver_flush(zf_solver* s) {
     return ZF_OK;
 }
 
+// Attach an RCCL communicator (zf_comm_create; its rank / world must be the descriptor's): from now on
+// zf_solver_enqueue_init_all and zf_solver_enqueue_steps issue the exchanges of a sharded step - the
+// packed all-gather of the scalar packs (C1), and for column-sharded least squares the all-gather of
+// A_p x_p (C2) - themselves, on the solver's stream.  The communicator must outlive the solver.
+extern "C" int zf_solver_set_comm(zf_solver* s, zf_comm* comm) {
+    ZF_REQUIRE(s && comm, "zf_solver_set_comm: null argument");
+    int32_t rank = 0, world = 1;
+    int rc = zf_comm_info(comm, &rank, &world);
+    if (rc) return rc;
+    ZF_REQUIRE(rank == s->desc.rank && world == s->desc.world, "zf_solver_set_comm: rank / world differ from the problem descriptor");
+    s->comm = comm;
+    return ZF_OK;
+}
+
+static int zf_gather_packs(zf_solver* s, int64_t packs) {
+    return zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, s->stream);
+}
+static int zf_gather_svec(zf_solver* s) {
+    if (s->desc.kind != ZF_PROBLEM_LEAST_SQUARES_L1 || s->desc.world == 1) return ZF_OK;
+    return zf_comm_all_gather(s->comm, s->s_part, s->s_all, s->desc.m_rows, s->stream);
+}
+
+// the whole initialisation of a solver with a communicator: init, exchanges, commit (world == 1 too)
+extern "C" int zf_solver_enqueue_init_all(zf_solver* s, const double* x0_dev) {
+    ZF_REQUIRE(s && x0_dev, "zf_solver_enqueue_init_all: null argument");
+    int rc = zf_solver_enqueue_init(s, x0_dev);
+    if (rc) return rc;
+    if (s->comm) {
+        if ((rc = zf_gather_svec(s))) return rc;
+        if ((rc = zf_solver_enqueue_init_finish(s))) return rc;
+        if ((rc = zf_gather_packs(s, 1))) return rc;
+    } else {
+        ZF_REQUIRE(s->desc.world == 1, "zf_solver_enqueue_init_all: world > 1 needs zf_solver_set_comm");
+    }
+    return zf_solver_enqueue_init_commit(s);
+}
+
 extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_steps: solver not initialised");
-    ZF_REQUIRE(s->desc.world == 1, "zf_solver_enqueue_steps: world > 1 needs trial/gather/decide");
+    ZF_REQUIRE(s->desc.world == 1 || s->comm, "zf_solver_enqueue_steps: world > 1 needs zf_solver_set_comm "
+                                              "(or the caller's own trial / gather / decide sequence)");
     ZF_REQUIRE(steps >= 0 && steps <= ZF_RING, "zf_solver_enqueue_steps: steps must be in [0, ZF_RING]");
     for (int64_t k = 0; k < steps; ++k) {
-        int rc = zf_launch_trial(s, true);
-        if (rc) return rc;
+        int rc;
+        if (!s->comm) {
+            if ((rc = zf_launch_trial(s, true))) return rc;
+            continue;
+        }
+        // sharded step: trial -> (C2) -> finish -> C1 -> decide; every rank runs the same decide on the
+        // same gathered packs, so nothing else is exchanged
+        if ((rc = zf_launch_trial(s, false))) return rc;
+        if ((rc = zf_gather_svec(s))) return rc;
+        if ((rc = zf_solver_enqueue_trial_finish(s))) return rc;
+        if ((rc = zf_gather_packs(s, s->sub))) return rc;
+        if ((rc = zf_solver_enqueue_decide(s))) return rc;
     }
     return ZF_OK;
 }

@@ -95,9 +95,27 @@ class DeviceSolver:
         self._pack_local = self._pack_all = None
         if timing:
             _lib.check(self.lib.zf_solver_set_timing(self.handle, 1))
-        # ZF_FORCE_SPLIT=1 runs the sharded step sequence (trial -> all-gather -> decide) even
-        # for one rank: lets a 1-GPU box exercise the RCCL path end to end
-        self.split = self.world > 1 or os.environ.get("ZF_FORCE_SPLIT") == "1"
+        # Sharded x.  Preferred: the library's own RCCL communicator (zfista_amd.comm.LibComm, given
+        # as `group` or derived from an nccl process group): the exchanges of a pass are issued by
+        # zf_solver_enqueue_steps itself, no host code per pass.  Otherwise (gloo rehearsals, thread
+        # stand-ins, ZF_COMM=torch) the host runs trial -> torch.distributed all-gather -> decide.
+        # ZF_FORCE_SPLIT=1 runs that sequence even for one rank.
+        from .comm import LibComm
+
+        self.comm = None
+        if isinstance(group, LibComm):
+            self.comm = group
+        elif self.world > 1 and group is not None and os.environ.get("ZF_COMM", "lib") == "lib":
+            try:
+                import torch.distributed as dist
+
+                if dist.get_backend(group) == "nccl":
+                    self.comm = LibComm.from_group(group)
+            except Exception:   # (in-process stand-ins of the tests have no backend)
+                self.comm = None
+        if self.comm is not None:
+            _lib.check(self.lib.zf_solver_set_comm(self.handle, self.comm.handle), "zf_solver_set_comm")
+        self.split = self.comm is None and (self.world > 1 or os.environ.get("ZF_FORCE_SPLIT") == "1")
         if self.split:
             self._wrap_packs()
 
@@ -149,6 +167,12 @@ class DeviceSolver:
 
     # -- life cycle ---------------------------------------------------------------
     def init(self, x0_dev_ptr: int):
+        if self.comm is not None:   # init + exchanges + commit inside the library
+            _lib.check(self.lib.zf_solver_enqueue_init_all(self.handle, C.c_void_p(x0_dev_ptr)), "init_all")
+            t = C.c_int32(1)
+            _lib.check(self.lib.zf_solver_autotune(self.handle, C.byref(t)), "geometry")
+            self.tiles_per_wg = int(t.value)
+            return
         self.init_begin(x0_dev_ptr)
         if self.split:
             self._gather_svec()

@@ -33,6 +33,13 @@ def combine_totals(vals, max_index, group):
     vals = np.asarray(vals, dtype=np.float64)
     if hasattr(group, "all_gather_host"):
         parts = group.all_gather_host(vals.copy())
+    elif hasattr(group, "handle") and hasattr(group, "all_gather"):   # zfista_amd.comm.LibComm (RCCL in the library)
+        import torch
+
+        mine = torch.from_numpy(vals.copy()).cuda()
+        out = torch.empty(group.world * vals.size, dtype=torch.float64, device=mine.device)
+        group.all_gather(mine, out)
+        parts = list(out.cpu().numpy().reshape(group.world, vals.size))
     else:
         import torch
         import torch.distributed as dist

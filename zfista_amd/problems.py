@@ -125,10 +125,9 @@ class DiagQuadL1(NativeProblem):
         return out
 
     def _descriptor(self):
-        import torch.distributed as dist
+        from .comm import rank_world
 
-        world = dist.get_world_size(self.group) if self.group is not None else 1
-        rank = dist.get_rank(self.group) if self.group is not None else 0
+        rank, world = rank_world(self.group)
         fields = dict(kind=self.kind, world=world, rank=rank, n=self.n_features, m_rows=0,
                       d=self.d.data_ptr(), c=self.c.data_ptr(), A=None, b=None,
                       scale=0.5, lam=self.lam, box_lo=self.box[0], box_hi=self.box[1])
@@ -184,10 +183,9 @@ class LeastSquaresL1(NativeProblem):
         return None, np.float64(self.lam * s.value)
 
     def _descriptor(self):
-        import torch.distributed as dist
+        from .comm import rank_world
 
-        world = dist.get_world_size(self.group) if self.group is not None else 1
-        rank = dist.get_rank(self.group) if self.group is not None else 0
+        rank, world = rank_world(self.group)
         fields = dict(kind=self.kind, world=world, rank=rank, n=self.n_features, m_rows=self.m_rows,
                       d=None, c=None, A=self.A.data_ptr(), b=self.b.data_ptr(),
                       scale=self.scale, lam=self.lam, box_lo=self.box[0], box_hi=self.box[1])
@@ -262,12 +260,9 @@ class Problem:
         """[lo, hi): this rank's block of the decision vector (the whole vector without a group)."""
         if self.group is None:
             return 0, self.n_features
-        if hasattr(self.group, "all_gather_host"):   # in-process stand-in (tests)
-            rank, world = self.group.rank, self.group.world
-        else:
-            import torch.distributed as dist
+        from .comm import rank_world
 
-            rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        rank, world = rank_world(self.group)
         return rank * self.n_features // world, (rank + 1) * self.n_features // world
 
     def _check_len(self, x):
