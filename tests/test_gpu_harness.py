@@ -1,0 +1,79 @@
+"""GPU: the experiment harness (tools/harness.py: the design of benchmarks/benchmark.py:303-374 - three
+solver variants per random start, metric tables of zfista/metrics.py:103-199) and the replica launcher
+behind it (zfista_amd/replicas.py: the reference's joblib sweeps as one worker process per GPU)."""
+import importlib.util
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _harness():
+    spec = importlib.util.spec_from_file_location("zf_harness", os.path.join(ROOT, "tools", "harness.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_harness_jos1_sweep_and_metric_tables(tmp_path):
+    H = _harness()
+    out = tmp_path / "h.json"
+    rep = H.main(["--samples", "6", "--problems", "JOS1", "--max-n", "10", "--out", str(out)])
+    assert json.load(open(out)).keys() == rep.keys() and len(rep) == 4   # JOS1 n = 5, 10, each with its l1 twin
+    for name, r in rep.items():
+        m = r["metrics"]
+        assert set(m["Avg iterations"]) == {"Normal", "Accelerated", "Accelerated (deprecated test)"}
+        # every start converges (tol 1e-5)
+        assert all(v is not None and v > 0 for v in m["Avg iterations"].values()), name
+        assert all(0.0 <= v <= 1.0 for v in m["Purity"].values()) and all(v == 0.0 for v in m["Error rate"].values())
+        assert all(v >= 1.0 for v in r["ratios"]["Avg iterations"].values())   # value / best
+        assert all(v is None or v > 0 for v in r["iterations_per_second"].values())
+    # the same sweep as replicas (2 worker processes sharing this GPU): identical solves, identical tables
+    rep2 = H.main(["--samples", "6", "--problems", "JOS1", "--max-n", "10", "--workers", "2", "--out", str(out)])
+    for name in rep:
+        assert rep2[name]["metrics"]["Avg iterations"] == rep[name]["metrics"]["Avg iterations"], name
+        for key in ("Hypervolume", "Purity", "Gamma", "Delta", "Avg iterations"):
+            assert rep2[name]["ratios"][key] == rep[name]["ratios"][key], (name, key)
+
+
+def _make_closure_problem():
+    """The reference's toy LASSO closures (tests/test_proximal_gradient.py:75-97): opaque callbacks."""
+    A = np.array([[-1.0], [0.0], [1.0]])
+    b = np.array([-1.0, 0.0, 1.0])
+
+    def f(x):
+        return np.linalg.norm(A @ x - b) ** 2 / 6
+
+    def g(x):
+        return 0.1 * np.linalg.norm(x, ord=1)
+
+    def jac_f(x):
+        return A.T @ (A @ x - b) / 3
+
+    def prox(weight, x):
+        return np.sign(x) * np.maximum(np.abs(x) - 0.1 * weight, 0)
+
+    return f, g, jac_f, prox
+
+
+def test_replicas_of_opaque_callbacks():
+    """Generic Python callbacks: "replicas only" (SURVEY 8e).  Three workers, five starts."""
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.replicas import solve_replicas
+
+    starts = [np.array([v]) for v in (0.3, -1.0, 2.0, 0.0, 0.7)]
+    res = solve_replicas(_make_closure_problem, starts, workers=3, nesterov=True, return_all=True)
+    assert len(res) == 5
+    for x0, r in zip(starts, res):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            here = minimize_proximal_gradient(*_make_closure_problem(), x0, nesterov=True, return_all=True)
+        assert r.nit == here.nit and np.array_equal(r.x, here.x) and r.success
+        np.testing.assert_array_almost_equal(r.x, [0.85], decimal=3)
+        assert len(r.allvecs) == r.nit + 1

@@ -2,9 +2,11 @@
 """Pareto-front experiment harness: the experimental design of the reference's
 ``benchmarks/benchmark.py`` (:303-376 the three solver variants per random start; :413-470 the
 problem list and the start ranges) on this engine, with ``zfista_amd.metrics`` for the tables.
-No joblib (one GPU, runs are sequential), no plots; results go to a JSON file.
+No plots; results go to a JSON file.  The reference's three ``Parallel(n_jobs=-1)`` sweeps over the
+start points (:325,:341,:360) are replicas: ``--workers W`` spreads them over W worker processes,
+one per GPU (``zfista_amd.replicas.solve_replicas``; W > GPUs: the workers share devices).
 
-    python tools/harness.py --samples 20 --problems JOS1,SD,FDS --out harness.json
+    python tools/harness.py --samples 20 --problems JOS1,SD,FDS --workers 8 --out harness.json
 
 Variants per start x0 ~ U[low, high]^n (as the reference): proximal gradient, accelerated
 (``nesterov=True``), accelerated with the ``deprecated`` acceptance test; all with
@@ -52,22 +54,27 @@ def build_problems(names, max_n):
     return out
 
 
-def run_variants(problem, starts, max_iter, tol_internal):
+def run_variants(problem, starts, max_iter, tol_internal, workers=1, dual_solver="scipy"):
     variants = {"Normal": {}, "Accelerated": dict(nesterov=True),
                 "Accelerated (deprecated test)": dict(nesterov=True, deprecated=True)}
     results = {}
     for label, kw in variants.items():
+        common = dict(return_all=True, max_iter=max_iter, tol_internal=tol_internal, dual_solver=dual_solver, **kw)
+        if workers > 1:
+            from zfista_amd.replicas import ProblemRecipe, solve_replicas
+
+            results[label] = solve_replicas(ProblemRecipe(problem), list(starts), workers=workers, **common)
+            continue
         rs = []
         for x0 in starts:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                rs.append(problem.minimize_proximal_gradient(x0, return_all=True, max_iter=max_iter,
-                                                             tol_internal=tol_internal, **kw))
+                rs.append(problem.minimize_proximal_gradient(x0, **common))
         results[label] = rs
     return results
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=20, help="random starts per problem (the reference: 100-1000)")
     ap.add_argument("--problems", default="JOS1,SD,TOI4,TRIDIA,LinearFunctionRank1,ZDT1,FDS")
@@ -75,8 +82,10 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100000000)
     ap.add_argument("--tol-internal", type=float, default=1e-11)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--workers", type=int, default=1, help="replica worker processes (one per GPU)")
+    ap.add_argument("--dual-solver", default="scipy", help="scipy (the reference's calls) | native | device")
     ap.add_argument("--out", default="harness.json")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     from zfista_amd.metrics import calculate_metrics
 
     rng = np.random.default_rng(a.seed)
@@ -85,7 +94,7 @@ def main():
         low, high = RANGES[type(prob).__name__]
         starts = rng.uniform(low, high, size=(a.samples, prob.n_features))
         t0 = time.time()
-        res = run_variants(prob, starts, a.max_iter, a.tol_internal)
+        res = run_variants(prob, starts, a.max_iter, a.tol_internal, a.workers, a.dual_solver)
         metrics, ratios = calculate_metrics(*res.items())
         ok = {k: [r for r in v if r.success] for k, v in res.items()}
         report[prob.name] = {
@@ -101,6 +110,7 @@ def main():
     with open(a.out, "w") as fh:
         json.dump(report, fh, indent=1)
     print("wrote", a.out)
+    return report
 
 
 if __name__ == "__main__":
