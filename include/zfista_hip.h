@@ -146,6 +146,9 @@ int zf_memcpy_h2d(void* dst_dev, const void* src_host, int64_t bytes, void* stre
 int zf_memcpy_d2h(void* dst_host, const void* src_dev, int64_t bytes, void* stream);
 int zf_memcpy_d2d(void* dst_dev, const void* src_dev, int64_t bytes, void* stream);
 int zf_stream_synchronize(void* stream);
+/* release the library's staging workspaces (one per host thread and device, used by zf_host_* / zf_dev_*);
+ * call when none of those is in flight - a later call allocates again */
+int zf_shutdown(void);
 
 /* ---- RCCL communicator (x sharded over the GPUs of one node) -----
  * One rank per GPU/process.  Rank 0 calls zf_comm_unique_id and ships the 128 bytes to the other ranks

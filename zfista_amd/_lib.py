@@ -87,6 +87,7 @@ SIGNATURES = {
     "zf_memcpy_d2h": (C.c_int, [_P, _P, C.c_int64, _P]),
     "zf_memcpy_d2d": (C.c_int, [_P, _P, C.c_int64, _P]),
     "zf_stream_synchronize": (C.c_int, [_P]),
+    "zf_shutdown": (C.c_int, []),
     "zf_comm_unique_id": (C.c_int, [_P]),
     "zf_comm_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, _P]),
     "zf_comm_destroy": (C.c_int, [_P]),

@@ -8,19 +8,70 @@
 //   v = y - lr * jac                                   :148
 //   <jac, x - y>, |x - y|^2, max|x - y|                :150-152, :510
 //   y' = x + beta * (x - x_old)                        :534
+#include <mutex>
+#include <vector>
+
 #include "zf_common.h"
 
 namespace {
 
+// Staging workspace of the host-pointer entry points: one per host thread AND device (a caller
+// that switches devices between calls gets that device's buffers, never pointers into another
+// GPU's memory), registered so that zf_shutdown() can release all of them.
 struct zf_workspace {
+    int device = -1;
     double* buf[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t cap = 0;
     double* partials = nullptr;
     double* out = nullptr;
 };
-thread_local zf_workspace g_ws;
+constexpr int ZF_WS_DEVICES = 16;
+thread_local zf_workspace g_ws_tab[ZF_WS_DEVICES];
+thread_local zf_workspace* g_ws_cur = nullptr;
+#define g_ws (*g_ws_cur)
+std::mutex g_ws_mu;
+std::vector<zf_workspace*> g_ws_all;   // every workspace ever used, for zf_shutdown
+
+void zf_ws_release(zf_workspace* w) {
+    if (w->device < 0) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(w->device);
+    for (int k = 0; k < 4; ++k)
+        if (w->buf[k]) (void)hipFree(w->buf[k]);
+    if (w->partials) (void)hipFree(w->partials);
+    if (w->out) (void)hipFree(w->out);
+    *w = zf_workspace();
+    (void)hipSetDevice(cur);
+}
+
+// a thread that ends takes its workspaces with it (and out of the registry)
+struct zf_ws_owner {
+    ~zf_ws_owner() {
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        for (zf_workspace& w : g_ws_tab) {
+            for (size_t k = 0; k < g_ws_all.size(); ++k)
+                if (g_ws_all[k] == &w) {
+                    g_ws_all.erase(g_ws_all.begin() + k);
+                    break;
+                }
+            zf_ws_release(&w);
+        }
+    }
+};
+thread_local zf_ws_owner g_ws_owner;
 
 int zf_ws_reserve(int64_t n) {
+    (void)&g_ws_owner;   // (constructs the owner of this thread's table)
+    int dev = 0;
+    ZF_HIP(hipGetDevice(&dev));
+    ZF_REQUIRE(dev >= 0 && dev < ZF_WS_DEVICES, "zf_host_*: device index beyond the workspace table");
+    g_ws_cur = &g_ws_tab[dev];
+    if (g_ws.device < 0) {
+        g_ws.device = dev;
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        g_ws_all.push_back(g_ws_cur);
+    }
     if (!g_ws.partials) {
         ZF_HIP(hipMalloc(&g_ws.partials, sizeof(double) * 4 * ZF_MAX_GRID));
         ZF_HIP(hipMalloc(&g_ws.out, sizeof(double) * 8));
@@ -318,5 +369,14 @@ extern "C" int zf_host_asum(const double* x_host, int64_t n, double* out) {
     ZF_HIP(hipGetLastError());
     ZF_HIP(hipMemcpyAsync(out, g_ws.out, sizeof(double), hipMemcpyDeviceToHost, nullptr));
     ZF_HIP(hipStreamSynchronize(nullptr));
+    return ZF_OK;
+}
+
+// Release the staging workspaces of the host-pointer entry points (all threads, all devices).  Call
+// when no zf_host_* / zf_dev_* call is in flight; later calls allocate again.
+extern "C" int zf_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    for (zf_workspace* w : g_ws_all) zf_ws_release(w);
+    g_ws_all.clear();
     return ZF_OK;
 }
