@@ -6,6 +6,7 @@
 // each) back to back on one HIP stream; acceptance, lr decay, termination and
 // buffer rotation happen in a one-workgroup decide kernel, so there is no host
 // round trip inside a chunk of steps.
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <new>
@@ -15,6 +16,7 @@
 #include "zf_common.h"
 #include "zf_decide.h"
 #include "zf_kernels_gemv.h"
+#include "zf_kernels_ls_small.h"
 #include "zf_kernels_step.h"
 
 thread_local char zf_errbuf[512] = "";
@@ -148,6 +150,9 @@ struct zf_solver {
     bool initialised = false;
     bool own_packs = true;
     bool gemv_mfma = false;       // A^T r on v_mfma_f64_16x16x4 (n % 32 == 0; ZF_GEMV_MFMA=0 disables)
+    bool ls_small = false;        // cache-resident A: two fused launches per trial (zf_kernels_ls_small.h)
+    double* row_part = nullptr;   // ls_small: workgroup sums of the row kernel
+    unsigned* ls_cnt = nullptr;
     int64_t ntiles = 1;           // 16 KiB tiles of the trial kernel
     int tiles = 1;                // interleaved tiles per workgroup (zf_solver_autotune picks it)
     int max_grid = 1;
@@ -172,7 +177,7 @@ struct zf_solver {
 constexpr int ZF_PASS_LOG = 4096;
 
 static int zf_solver_free_all(zf_solver* s) {
-    void* ptrs[] = {s->pass_log, s->blk_part, s->slice_part, s->fin_cnt, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
+    void* ptrs[] = {s->row_part, s->ls_cnt, s->pass_log, s->blk_part, s->slice_part, s->fin_cnt, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
                     s->own_svec ? s->s_part : nullptr, s->own_svec ? s->s_all : nullptr};
@@ -252,7 +257,10 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * s->ring * n_pad));
     for (int k = 0; k < s->ring; ++k) s->xb[k] = s->xbuf + k * n_pad;
     ZF_TRY(hipMalloc(&s->partials, sizeof(double) * ZF_NPART * ZF_MAX_GRID));
-    ZF_TRY(hipMalloc(&s->blk_part, sizeof(double) * ZF_NPART * s->sub * s->max_grid));
+    {   // (the small least-squares step kernel has n / 32 workgroups: more than tiles)
+        const int64_t parts = std::max<int64_t>(s->max_grid, n / LS_SMALL_COLS + 1);
+        ZF_TRY(hipMalloc(&s->blk_part, sizeof(double) * ZF_NPART * s->sub * parts));
+    }
     ZF_TRY(hipMalloc(&s->slice_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_WGS));
     ZF_TRY(hipMalloc(&s->fin_cnt, 64));
     ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, 64, s->stream));
@@ -287,6 +295,15 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         if (desc->world > 1) {
             ZF_TRY(hipMalloc(&s->s_part, sizeof(double) * m_pad));
             ZF_TRY(hipMalloc(&s->s_all, sizeof(double) * m * desc->world));
+        }
+        // launch-bound sizes (BASELINE cfg1): two fused launches per trial; ZF_LS_SMALL=0 keeps the general path
+        const char* sm = getenv("ZF_LS_SMALL");
+        s->ls_small = desc->world == 1 && n % LS_SMALL_COLS == 0 && m <= LS_SMALL_MAX_M &&
+                      m * n <= LS_SMALL_MAX_ELEMS && zf_aligned16(desc->A) && !(sm && atoi(sm) == 0);
+        if (s->ls_small) {
+            ZF_TRY(hipMalloc(&s->row_part, sizeof(double) * ((m + ZF_WAVES - 1) / ZF_WAVES)));
+            ZF_TRY(hipMalloc(&s->ls_cnt, 64));
+            ZF_TRY(hipMemsetAsync(s->ls_cnt, 0, 64, s->stream));
         }
     }
 #undef ZF_TRY
@@ -426,6 +443,40 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         zf_launch_trial_t<true>(s, a);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
         if (!dry) zf_launch_finalize(s, d.world == 1 && decide_in_launch);
+    } else if (s->ls_small && !dry && decide_in_launch) {
+        // cache-resident A: the whole trial in two launches (zf_kernels_ls_small.h)
+        zf_ls_small_args P;
+        P.ctl = s->ctl;
+        P.beta_ring = s->beta_ring;
+        for (int k = 0; k < 3; ++k) P.xb[k] = s->xb[k];
+        P.sring = s->sring;
+        P.A = d.A;
+        P.b = d.b;
+        P.m = d.m_rows;
+        P.n = d.n;
+        P.scale = d.scale;
+        P.lam = d.lam;
+        P.lo = d.box_lo;
+        P.hi = d.box_hi;
+        P.ls_scal = s->ls_scal;
+        P.blk_part = s->blk_part;
+        P.grid_step = (int)(d.n / LS_SMALL_COLS);
+        P.row_part = s->row_part;
+        P.cnt = s->ls_cnt;
+        P.pack = s->pack_local;
+        P.trace = s->trace;
+        P.hist = s->hist;
+        P.hist_cap = s->hist_cap > 0 ? s->hist_cap : 1;
+        P.hist_stride = s->hist_stride;
+        const bool nest = s->opt.nesterov != 0;
+        dim3 gs(P.grid_step), gr((unsigned)((d.m_rows + ZF_WAVES - 1) / ZF_WAVES)), b(ZF_BLOCK);
+        if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
+        if (nest && s->box) hipLaunchKernelGGL((zf_ls_small_step_kernel<true, true>), gs, b, 0, s->stream, P);
+        else if (nest) hipLaunchKernelGGL((zf_ls_small_step_kernel<true, false>), gs, b, 0, s->stream, P);
+        else if (s->box) hipLaunchKernelGGL((zf_ls_small_step_kernel<false, true>), gs, b, 0, s->stream, P);
+        else hipLaunchKernelGGL((zf_ls_small_step_kernel<false, false>), gs, b, 0, s->stream, P);
+        if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+        hipLaunchKernelGGL(zf_ls_small_rows_kernel, gr, b, 0, s->stream, P);
     } else {
         const int64_t n = d.n, m = d.m_rows;
         const int V = (n % 2 == 0) ? 2 : 1;
