@@ -266,6 +266,7 @@ __global__ void k_f_from_sums(int kind, double dn, const double* __restrict__ t,
 //   the machine - all copies see the same numbers in the same order and stay in lock step, so no
 //   state is ever broadcast.  At the end the primal recovery x+ = prox(lr w*, y - lr w* @ J) (:206)
 //   and max|x+ - y| (:510) are fused in.  One launch, one result read-back per trial.
+typedef unsigned long long mo_u64;
 constexpr int MO_SOLVE_TPB = 512;
 constexpr int MO_SOLVE_LDS_BYTES = 156 * 1024;   // dynamic LDS for the resident elements (static LDS: ~3 KB)
 constexpr int MO_SOLVE_WAVES = MO_SOLVE_TPB / 64;
@@ -300,9 +301,9 @@ struct mo_solve_args {
     int64_t max_iter;
     int resident_rows;    // elements per thread kept in LDS (rows of MO_SOLVE_TPB elements)
     int tail_kind;        // ZF_MO_JOS1 / ZF_MO_FDS: also evaluate f(x+), g(x+) (:295); 0: g only
-    double* partials;     // [2][MAXB * NQ][gridDim.x]
-    double* totals;       // [2][MAXB * NQ]
-    unsigned* sync;       // [0] arrival tickets (monotonic), [16] generation; zeroed before the launch
+    mo_u64* partials;     // [2][MAXB * NQ][gridDim.x] self-validating 16-byte records (mo_grid_combine)
+    mo_u64* totals;       // [2][MAXB * NQ] records
+    unsigned nonce;       // launch number: part of the records' key (stale records of earlier launches fail the check)
     mo_solve_result* out;
 };
 
@@ -337,36 +338,75 @@ __device__ __forceinline__ void mo_dual_terms(const mo_g& G, const double (&w)[M
     for (int i = 0; i < M; ++i) acc[M + 2 + i] += Jc[i] * dy;
 }
 
-// grid-wide hand-over of `count` doubles per workgroup: publish -> ticket -> last arriver reduces
-// (sums; quantity max_index, if >= 0, a maximum) in workgroup-index order -> totals + generation.  On return lds_tot[0..count)
-// holds the grid totals in every workgroup.  Returns false if the wait timed out.
+// Grid-wide hand-over of `count` doubles per workgroup WITHOUT atomics, flags or fences: every value
+// travels as a self-validating 16-byte record {bits(v), bits(v) ^ key}, key unique per launch and
+// batch.  Workgroup 0 polls the records of all workgroups (a torn or stale record fails the check and
+// is simply read again), adds them in workgroup-index order (sums; quantity max_index, if >= 0, a
+// maximum: deterministic, no float atomics) and publishes the totals the same way; every workgroup
+// polls the totals.  Two dependent memory round trips (records visible to workgroup 0, totals visible
+// to all) instead of the six of publish / ticket / gather / publish / flag / read: 12.5 -> ~4 us.
+// Records of batch e + 2 reuse the slots of batch e, which nobody can still need: a workgroup
+// publishes e + 2 only after it has read the totals of e + 1, which exist only after every workgroup
+// published e + 1, i.e. after every workgroup read the totals of e.
+// On return lds_tot[0..count) holds the grid totals in every workgroup; false = the wait timed out.
+__device__ __forceinline__ mo_u64 mo_key(unsigned nonce, unsigned epoch) {
+    return ((mo_u64)nonce * 0x9E3779B97F4A7C15ull) ^ ((mo_u64)(epoch + 1u) * 0xC2B2AE3D27D4EB4Full) ^ 0x5851F42D4C957F2Dull;
+}
+__device__ __forceinline__ void mo_put(mo_u64* rec, double v, mo_u64 key) {
+    const mo_u64 lo = (mo_u64)__double_as_longlong(v);
+    __hip_atomic_store(rec, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + 1, lo ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool mo_get(const mo_u64* rec, mo_u64 key, double* v) {
+    const mo_u64 lo = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const mo_u64 hi = __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *v = __longlong_as_double((long long)lo);
+    return (lo ^ hi) == key;
+}
+
+// QW: quantities per wave of the reducer = ceil(largest count / waves)
+template <int QW>
 __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, count */, int count, int max_index,
-                                                double* partials, double* totals, unsigned* sync, unsigned epoch,
-                                                double* lds_tot, int* lds_flag) {
+                                                mo_u64* partials /* [count][G] records */, mo_u64* totals /* [count + 1] */,
+                                                unsigned nonce, unsigned epoch, double* lds_tot, int* lds_flag) {
     const int G = (int)gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < count) zf_publish(partials + (int64_t)tid * G + blockIdx.x, my_vals[tid]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const mo_u64 key = mo_key(nonce, epoch);
+    if (tid < count) mo_put(partials + 2 * ((int64_t)tid * G + blockIdx.x), my_vals[tid], key);
+    if (tid == 0) *lds_flag = 1;
     __syncthreads();
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == epoch * (unsigned)G + (unsigned)(G - 1));
-        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *lds_flag = last;
-    }
-    __syncthreads();
-    if (*lds_flag) {
-        // last arriver: wave w adds quantities w, w + WAVES, ...; lane l takes workgroups l, l + 64, ...
-        // (index order; all loads of a wave are issued before the first use: one memory round trip)
-        constexpr int QW = 4, GL = 4;   // quantities per wave (<= 32 in all), workgroups per lane (<= 256)
+    if (blockIdx.x == 0) {
+        // the reducer: wave w takes quantities w, w + WAVES, ...; lane l takes workgroups l, l + 64, ...
+        constexpr int GL = 4;   // workgroups per lane (<= 256 workgroups)
         double pv[QW][GL];
+        unsigned pending = 0;
 #pragma unroll
-        for (int a = 0; a < QW; ++a) {
-            const int q = wave + a * MO_SOLVE_WAVES;
+        for (int a = 0; a < QW; ++a)
 #pragma unroll
             for (int c = 0; c < GL; ++c) {
-                const int g = lane + 64 * c;
-                pv[a][c] = (q < count && g < G) ? zf_consume(partials + (int64_t)q * G + g) : 0.0;
+                pv[a][c] = 0.0;
+                if (wave + a * MO_SOLVE_WAVES < count && lane + 64 * c < G) pending |= 1u << (a * GL + c);
+            }
+        unsigned spins = 0;
+        while (pending) {
+#pragma unroll
+            for (int a = 0; a < QW; ++a)
+#pragma unroll
+                for (int c = 0; c < GL; ++c)
+                    if (pending & (1u << (a * GL + c))) {
+                        const int q = wave + a * MO_SOLVE_WAVES, g = lane + 64 * c;
+                        double v;
+                        if (mo_get(partials + 2 * ((int64_t)q * G + g), key, &v)) {
+                            pv[a][c] = v;
+                            pending &= ~(1u << (a * GL + c));
+                        }
+                    }
+            if (pending) {
+                __builtin_amdgcn_s_sleep(2);   // (do not hammer the memory system while the others still compute)
+                if (++spins > MO_SPIN_LIMIT) {
+                    *lds_flag = 0;
+                    break;
+                }
             }
         }
 #pragma unroll
@@ -377,30 +417,38 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
 #pragma unroll
             for (int c = 1; c < GL; ++c) v = is_max ? fmax(v, pv[a][c]) : v + pv[a][c];
             v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
-            if (lane == 0 && q < count) zf_publish(totals + q, v);
+            if (lane == 0 && q < count) mo_put(totals + 2 * q, v, key);
         }
+        // "totals are out" record, after them in program order (its readers validate every total anyway)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(sync + 16, epoch + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) mo_put(totals + 2 * count, 1.0, key);
     }
-    if (tid == 0) {
+    if (tid == 0) {   // ONE poller per workgroup (hundreds of threads spinning on three cache lines slow the writer down)
         unsigned spins = 0;
-        int okay = 1;
-        while (__hip_atomic_load(sync + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch + 1u) {
-            __builtin_amdgcn_s_sleep(2);
+        double v = 0.0;
+        while (!mo_get(totals + 2 * count, key, &v)) {
+            __builtin_amdgcn_s_sleep(4);
             if (++spins > MO_SPIN_LIMIT) {
-                okay = 0;
+                *lds_flag = 0;
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *lds_flag = okay;
     }
     __syncthreads();
-    if (!*lds_flag) return false;
-    if (tid < count) lds_tot[tid] = zf_consume(totals + tid);
+    if (tid < count && *lds_flag) {
+        unsigned spins = 0;
+        double v = 0.0;
+        while (!mo_get(totals + 2 * tid, key, &v)) {
+            if (++spins > MO_SPIN_LIMIT) {
+                *lds_flag = 0;
+                break;
+            }
+        }
+        lds_tot[tid] = v;
+    }
     __syncthreads();
-    return true;
+    return *lds_flag != 0;
 }
 
 // One step of the solver's state machine, by ONE lane: LDS -> registers -> advance -> LDS (constant
@@ -545,8 +593,8 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         const int cnt = npts * NQ;
         const int64_t c1 = clock64();
         c_eval += c1 - c0;
-        if (!mo_grid_combine(s_mine, cnt, -1, A.partials + (int64_t)parity * zf_dual::MAXB * NQ * gridDim.x,
-                             A.totals + parity * zf_dual::MAXB * NQ, A.sync, epoch, s_tot, &s_flag)) {
+        if (!mo_grid_combine<(NB * NQ + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, cnt, -1, A.partials + 2 * ((int64_t)parity * zf_dual::MAXB * NQ * gridDim.x),
+                             A.totals + 2 * (parity * zf_dual::MAXB * NQ), A.nonce, epoch, s_tot, &s_flag)) {
             timed_out = 1;
             break;
         }
@@ -667,8 +715,8 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         }
         __syncthreads();
         const int parity = (int)(epoch & 1u);
-        if (!mo_grid_combine(s_mine, NT, 0, A.partials + (int64_t)parity * zf_dual::MAXB * NQ * gridDim.x,
-                             A.totals + parity * zf_dual::MAXB * NQ, A.sync, epoch, s_tot, &s_flag))
+        if (!mo_grid_combine<(NT + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, NT, 0, A.partials + 2 * ((int64_t)parity * zf_dual::MAXB * NQ * gridDim.x),
+                             A.totals + 2 * (parity * zf_dual::MAXB * NQ), A.nonce, epoch, s_tot, &s_flag))
             timed_out = 1;
     }
     if (blockIdx.x == 0 && tid == 0) {
@@ -723,9 +771,9 @@ struct zf_mo {
     zf_mo_exchange_fn exchange = nullptr;   // combines raw totals over the ranks, in place
     void* exchange_ctx = nullptr;
     // device-side dual search (k_dual_solve): workspace, allocated at first use
-    double* solve_partials = nullptr;
-    double* solve_totals = nullptr;
-    unsigned* solve_sync = nullptr;
+    unsigned long long* solve_partials = nullptr;
+    unsigned long long* solve_totals = nullptr;
+    unsigned solve_nonce = 0;
     mo_solve_result* solve_out = nullptr;      // device
     mo_solve_result* h_solve_out = nullptr;    // pinned host mirror
     int solve_grid = 0;
@@ -864,7 +912,6 @@ extern "C" int zf_mo_destroy(zf_mo* s) {
     if (s->bounds_v) (void)hipFree(s->bounds_v);
     if (s->solve_partials) (void)hipFree(s->solve_partials);
     if (s->solve_totals) (void)hipFree(s->solve_totals);
-    if (s->solve_sync) (void)hipFree(s->solve_sync);
     if (s->solve_out) (void)hipFree(s->solve_out);
     if (s->f_y_dev) (void)hipFree(s->f_y_dev);
     if (s->h_solve_out) (void)hipHostFree(s->h_solve_out);
@@ -1113,9 +1160,10 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
         if (g < 1) g = 1;
         s->solve_grid = (int)g;
         const size_t nq = 2 * MO_MAX_M + 2;
-        ZF_HIP(hipMalloc(&s->solve_partials, sizeof(double) * 2 * zf_dual::MAXB * nq * s->solve_grid));
-        ZF_HIP(hipMalloc(&s->solve_totals, sizeof(double) * 2 * zf_dual::MAXB * nq));
-        ZF_HIP(hipMalloc(&s->solve_sync, 256));
+        ZF_HIP(hipMalloc(&s->solve_partials, 16 * 2 * zf_dual::MAXB * nq * s->solve_grid));
+        ZF_HIP(hipMalloc(&s->solve_totals, 16 * 2 * zf_dual::MAXB * nq));
+        ZF_HIP(hipMemsetAsync(s->solve_partials, 0, 16 * 2 * zf_dual::MAXB * nq * s->solve_grid, s->stream));
+        ZF_HIP(hipMemsetAsync(s->solve_totals, 0, 16 * 2 * zf_dual::MAXB * nq, s->stream));
         ZF_HIP(hipMalloc(&s->solve_out, sizeof(mo_solve_result)));
         ZF_HIP(hipHostMalloc((void**)&s->h_solve_out, sizeof(mo_solve_result), hipHostMallocDefault));
     }
@@ -1140,9 +1188,8 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
     A.tail_kind = (s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS) ? s->kind : 0;
     A.partials = s->solve_partials;
     A.totals = s->solve_totals;
-    A.sync = s->solve_sync;
+    A.nonce = ++s->solve_nonce;
     A.out = s->solve_out;
-    ZF_HIP(hipMemsetAsync(s->solve_sync, 0, 256, s->stream));
     const dim3 grid(s->solve_grid), block(MO_SOLVE_TPB);
     // rows of MO_SOLVE_TPB elements a workgroup owns / can keep in LDS
     const int64_t per_wg = (s->n + (int64_t)s->solve_grid * MO_SOLVE_TPB - 1) / ((int64_t)s->solve_grid * MO_SOLVE_TPB);
