@@ -158,6 +158,10 @@ typedef struct zf_comm zf_comm;
 int zf_comm_unique_id(void* id128);
 int zf_comm_create(zf_comm** out, int32_t rank, int32_t world, const void* id128);
 int zf_comm_destroy(zf_comm* c);
+/* in-process stand-in (tests on one GPU, where RCCL cannot place two ranks): `world` communicators for
+ * `world` host threads with a stream each; all-gathers go through a shared staging buffer, a host
+ * barrier and stream events.  cap_doubles bounds the per-rank count of an all-gather. */
+int zf_comm_create_local_group(zf_comm** out_world, int32_t world, int64_t cap_doubles);
 int zf_comm_info(zf_comm* c, int32_t* rank, int32_t* world);
 /* recv (world x count doubles, rank-major) <- send (count doubles) of every rank; stream-ordered */
 int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream);

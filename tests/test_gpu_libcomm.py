@@ -46,7 +46,9 @@ def test_one_rank_rccl_communicator_in_the_library():
         warnings.simplefilter("ignore")
         plain = minimize_proximal_gradient(*LeastSquaresL1(A, bb, lam).callbacks(), np.zeros(128), **kw)
         shard = minimize_proximal_gradient(*LeastSquaresL1(A, bb, lam, group=comm).callbacks(), np.zeros(128), **kw)
-    assert shard.nit == plain.nit and np.array_equal(shard.x, plain.x)
+    # (the unsharded small matrix takes the two-launch path, the sharded sequence the general one: other
+    #  summation orders of grad and f, same iterates to rounding)
+    assert shard.nit == plain.nit and np.linalg.norm(shard.x - plain.x) <= 1e-12 * np.linalg.norm(plain.x)
     comm.close()
 
 
@@ -91,3 +93,75 @@ def test_two_rank_rccl_communicator_in_the_library(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, timeout=600, env=dict(os.environ, ZF_ROOT=ROOT))
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind", ["diag", "diag_backtrack_history", "lasso"])
+def test_library_multi_rank_step_sequence_with_thread_ranks(kind, world):
+    """The library's OWN multi-rank sequence (zf_solver_enqueue_init_all / zf_solver_enqueue_steps with
+    a communicator attached: trial -> all-gather -> decide, rank-major pack layout, rank-ordered sums)
+    with `world` ranks on this one GPU: each rank is a host thread with its own stream, the
+    communicators are the in-process stand-in (zf_comm_create_local_group) behind the same
+    zf_comm_all_gather the RCCL communicator serves.  Against the oracle on the unsharded problem;
+    every rank must report bitwise-identical scalars."""
+    import threading
+
+    import torch
+
+    from oracle import cpu_ref, problems_ref as P
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.comm import LibComm
+    from zfista_amd.problems import DiagQuadL1, LeastSquaresL1
+
+    if kind == "lasso":
+        m, n = 96, 192
+        A, b, lam = P.make_plasso(m, n, seed=2)
+        kw = dict(lr=1.0, nesterov=True, tol=0.0, max_iter=25, return_all=True)
+        ref = P.LeastSquaresL1Ref(A, b, lam)
+    else:
+        n = 30011
+        d, c, lam = P.make_pdiag(n, seed=1)
+        kw = dict(lr=4.0 if "backtrack" in kind else 0.45, nesterov=True, tol=1e-8, max_iter=70,
+                  return_all="history" in kind)
+        ref = P.DiagQuadL1Ref(d, c, lam)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), np.zeros(n), **kw)
+    comms = LibComm.local_group(world, cap_doubles=4096)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            lo, hi = r * n // world, (r + 1) * n // world
+            with torch.cuda.stream(torch.cuda.Stream()):
+                if kind == "lasso":
+                    prob = LeastSquaresL1(np.ascontiguousarray(A[:, lo:hi]), b, lam, group=comms[r])
+                else:
+                    prob = DiagQuadL1(d[lo:hi], c[lo:hi], lam, group=comms[r])
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    res = minimize_proximal_gradient(*prob.callbacks(), np.zeros(hi - lo), **kw)
+                torch.cuda.current_stream().synchronize()
+            out[r] = res
+        except Exception as exc:   # pragma: no cover - reported below
+            errs.append(exc)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs, errs
+    assert all(o is not None for o in out), "a rank thread did not finish"
+    for res in out:
+        assert res.nit == exp.nit == out[0].nit and res.fun == out[0].fun, "ranks must agree bit for bit"
+    x = np.concatenate([o.x for o in out])
+    assert np.linalg.norm(x - exp.x) <= 1e-10 * np.linalg.norm(exp.x)
+    np.testing.assert_allclose(out[0].fun, exp.fun, rtol=1e-10)
+    if kw.get("return_all"):
+        for k in (1, exp.nit // 2, exp.nit):
+            xk = np.concatenate([o.allvecs[k] for o in out])
+            assert np.linalg.norm(xk - exp.allvecs[k]) <= 1e-10 * max(1.0, np.linalg.norm(exp.allvecs[k]))
+        np.testing.assert_allclose(out[0].allerrs, exp.allerrs, rtol=1e-10, atol=1e-300)
+    for c_ in comms:
+        c_.close()

@@ -91,6 +91,7 @@ SIGNATURES = {
     "zf_comm_unique_id": (C.c_int, [_P]),
     "zf_comm_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, _P]),
     "zf_comm_destroy": (C.c_int, [_P]),
+    "zf_comm_create_local_group": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int64]),
     "zf_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "zf_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "zf_solver_set_comm": (C.c_int, [_P, _P]),

@@ -33,6 +33,21 @@ class LibComm:
         _lib.check(self.lib.zf_comm_create(C.byref(h), self.rank, self.world, C.cast(buf, C.c_void_p)), "zf_comm_create")
         self.handle = h
 
+    @classmethod
+    def local_group(cls, world: int, cap_doubles: int = 1 << 20):
+        """``world`` communicators of an in-process group, one per host THREAD playing a rank on this
+        one GPU (each thread runs its solver on its own stream).  For tests: the library's multi-rank
+        step sequence and buffer layouts without a second device (zf_comm_create_local_group)."""
+        lib = _lib.require_gpu()
+        arr = (C.c_void_p * world)()
+        _lib.check(lib.zf_comm_create_local_group(arr, int(world), int(cap_doubles)), "zf_comm_create_local_group")
+        out = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c.lib, c.rank, c.world, c.handle = lib, r, int(world), C.c_void_p(arr[r])
+            out.append(c)
+        return out
+
     @staticmethod
     def new_unique_id() -> bytes:
         lib = _lib.require_gpu()

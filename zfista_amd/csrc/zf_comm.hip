@@ -12,6 +12,9 @@
 // dependency on it and single-GPU users never touch it.  Inside a process that already loaded
 // RCCL (PyTorch does) the same soname resolves to that copy.
 #include <dlfcn.h>
+#include <pthread.h>
+
+#include <new>
 
 #include "zf_common.h"
 
@@ -55,9 +58,28 @@ int rccl_check(int rc, const char* what) {
 }
 }  // namespace
 
+// In-process stand-in for a communicator (tests on ONE GPU: RCCL places one rank per device): `world`
+// host threads, one per emulated rank, each with its own stream.  An all-gather copies the rank's
+// contribution into a shared staging buffer, meets the other threads at a host barrier (so that every
+// rank's copy-in is enqueued and its event recorded), makes its stream wait for all copy-ins and copies
+// the gathered block out.  Staging is double-buffered by call parity: a rank's copy-in of call k + 2
+// is stream-ordered after its copy-out of k + 1, which waited for every other rank's copy-in of k + 1,
+// which those ranks enqueued after their copy-out of call k.
+struct zf_local_group {
+    int world = 0;
+    int64_t cap = 0;                  // doubles per rank and parity
+    double* staging = nullptr;        // [2][world][cap]
+    hipEvent_t* ev = nullptr;         // [2][world]
+    pthread_barrier_t barrier;
+    int refs = 0;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+};
+
 struct zf_comm {
     nccl_comm_t comm = nullptr;
     int rank = 0, world = 1;
+    zf_local_group* local = nullptr;  // non-NULL: the in-process stand-in
+    unsigned calls = 0;
 };
 
 // 128 bytes that rank 0 creates and every rank of the communicator must receive (over any host
@@ -90,9 +112,46 @@ extern "C" int zf_comm_create(zf_comm** out, int32_t rank, int32_t world, const 
     return ZF_OK;
 }
 
+// `world` communicators of one in-process group (see zf_local_group): out[r] belongs to the host
+// thread that plays rank r.  cap_doubles bounds the count of any all-gather on them.
+extern "C" int zf_comm_create_local_group(zf_comm** out, int32_t world, int64_t cap_doubles) {
+    ZF_REQUIRE(out && world >= 1 && cap_doubles >= 1, "zf_comm_create_local_group: bad argument");
+    zf_local_group* g = new (std::nothrow) zf_local_group();
+    if (!g) return zf_fail(ZF_ERR_ARG, "zf_comm_create_local_group: out of host memory");
+    g->world = world;
+    g->cap = cap_doubles;
+    g->refs = world;
+    ZF_HIP(hipMalloc(&g->staging, sizeof(double) * 2 * world * cap_doubles));
+    g->ev = new hipEvent_t[2 * world];
+    for (int k = 0; k < 2 * world; ++k) ZF_HIP(hipEventCreateWithFlags(&g->ev[k], hipEventDisableTiming));
+    pthread_barrier_init(&g->barrier, nullptr, (unsigned)world);
+    for (int r = 0; r < world; ++r) {
+        zf_comm* c = new zf_comm();
+        c->rank = r;
+        c->world = world;
+        c->local = g;
+        out[r] = c;
+    }
+    return ZF_OK;
+}
+
 extern "C" int zf_comm_destroy(zf_comm* c) {
     if (!c) return ZF_OK;
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    if (c->local) {
+        zf_local_group* g = c->local;
+        pthread_mutex_lock(&g->mu);
+        const int left = --g->refs;
+        pthread_mutex_unlock(&g->mu);
+        if (left == 0) {
+            (void)hipDeviceSynchronize();
+            for (int k = 0; k < 2 * g->world; ++k) (void)hipEventDestroy(g->ev[k]);
+            delete[] g->ev;
+            (void)hipFree(g->staging);
+            pthread_barrier_destroy(&g->barrier);
+            delete g;
+        }
+    }
     delete c;
     return ZF_OK;
 }
@@ -107,6 +166,20 @@ extern "C" int zf_comm_info(zf_comm* c, int32_t* rank, int32_t* world) {
 // recv (world x count doubles, rank-major) <- send (count doubles) of every rank, on `stream`
 extern "C" int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream) {
     ZF_REQUIRE(c && send_dev && recv_dev && count >= 0, "zf_comm_all_gather: bad argument");
+    if (c->local) {
+        zf_local_group* g = c->local;
+        ZF_REQUIRE(count <= g->cap, "zf_comm_all_gather: count exceeds the local group's staging capacity");
+        const int par = (int)(c->calls++ & 1u);
+        double* stage = g->staging + (int64_t)par * g->world * g->cap;
+        hipStream_t st = (hipStream_t)stream;
+        ZF_HIP(hipMemcpyAsync(stage + (int64_t)c->rank * count, send_dev, sizeof(double) * count, hipMemcpyDeviceToDevice, st));
+        ZF_HIP(hipEventRecord(g->ev[par * g->world + c->rank], st));
+        pthread_barrier_wait(&g->barrier);   // every rank's copy-in is enqueued and its event recorded
+        for (int r = 0; r < g->world; ++r) ZF_HIP(hipStreamWaitEvent(st, g->ev[par * g->world + r], 0));
+        ZF_HIP(hipMemcpyAsync(recv_dev, stage, sizeof(double) * count * g->world, hipMemcpyDeviceToDevice, st));
+        pthread_barrier_wait(&g->barrier);   // nobody re-records an event of this parity before all waits are enqueued
+        return ZF_OK;
+    }
     return rccl_check(g_rccl.AllGather(send_dev, recv_dev, (size_t)count, /*ncclDouble*/ 8, c->comm, (hipStream_t)stream),
                       "ncclAllGather");
 }

@@ -868,7 +868,9 @@ extern "C" int zf_solver_enqueue_init_all(zf_solver* s, const double* x0_dev) {
     if (s->comm) {
         if ((rc = zf_gather_svec(s))) return rc;
         if ((rc = zf_solver_enqueue_init_finish(s))) return rc;
-        if ((rc = zf_gather_packs(s, 1))) return rc;
+        // the init pack sits at the head of this rank's pack buffer; ranks are sub x ZF_PACK_LEN apart in
+        // pack_all (zf_init_commit_kernel's stride), so the whole buffer is gathered
+        if ((rc = zf_gather_packs(s, s->sub))) return rc;
     } else {
         ZF_REQUIRE(s->desc.world == 1, "zf_solver_enqueue_init_all: world > 1 needs zf_solver_set_comm");
     }
