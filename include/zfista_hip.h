@@ -103,9 +103,12 @@ typedef struct zf_problem_desc {
     int32_t kind;      /* ZF_PROBLEM_*                                                */
     int32_t world;     /* ranks sharing the decision vector (1 = unsharded)           */
     int32_t rank;
-    int32_t reserved;
-    int64_t n;         /* local length of x (this rank's shard)                       */
-    int64_t m_rows;    /* least squares: rows of A (0 otherwise)                      */
+    int32_t row_sharded; /* LEAST_SQUARES_L1, world > 1: 0 = the COLUMNS of A and x are split over the
+                            ranks (b replicated; the m-vector A_p x_p is exchanged once per trial);
+                            1 = the ROWS of A and b are split, x is replicated on every rank and the
+                            n-vector A_p^T r_p is exchanged ("all-reduce of A^T r")          */
+    int64_t n;         /* length of x held by this rank (its shard; the whole x if row_sharded) */
+    int64_t m_rows;    /* least squares: rows of A held by this rank (0 otherwise)   */
     const double* d;   /* dev, n   - DIAG_QUAD_L1                                     */
     const double* c;   /* dev, n   - DIAG_QUAD_L1                                     */
     const double* A;   /* dev, m_rows x n row-major - LEAST_SQUARES_L1                */
@@ -232,8 +235,10 @@ int zf_solver_pack_ptrs(zf_solver* s, double** pack_local_dev, double** pack_all
 /* make the solver write / read caller-owned pack buffers instead (e.g. torch
  * tensors the collective runs on); sizes as above; must outlive the solver */
 int zf_solver_set_pack_buffers(zf_solver* s, double* pack_local_dev, double* pack_all_dev);
-/* sharded least squares (x and the columns of A split over ranks): the
- * m-vector A_p x_p of every rank is exchanged once per trial.  Between
+/* sharded least squares.  Column blocks (x split): the m-vector A_p x_p of every rank
+ * is exchanged once per trial.  Row blocks (desc.row_sharded, x replicated): the n-vector
+ * 2 scale A_p^T r_p is exchanged instead (s_part / s_all then hold n and world x n doubles) and the
+ * init needs no exchange of its own.  Between
  * zf_solver_enqueue_trial() and zf_solver_enqueue_trial_finish() (and between
  * zf_solver_enqueue_init() and zf_solver_enqueue_init_finish()) the caller gathers
  * s_part (m doubles) of all ranks into s_all (world x m, rank-major); the finish call

@@ -96,7 +96,7 @@ def test_two_rank_rccl_communicator_in_the_library(tmp_path):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("kind", ["diag", "diag_backtrack_history", "lasso"])
+@pytest.mark.parametrize("kind", ["diag", "diag_backtrack_history", "lasso", "lasso_rows"])
 def test_library_multi_rank_step_sequence_with_thread_ranks(kind, world):
     """The library's OWN multi-rank sequence (zf_solver_enqueue_init_all / zf_solver_enqueue_steps with
     a communicator attached: trial -> all-gather -> decide, rank-major pack layout, rank-ordered sums)
@@ -113,7 +113,7 @@ def test_library_multi_rank_step_sequence_with_thread_ranks(kind, world):
     from zfista_amd.comm import LibComm
     from zfista_amd.problems import DiagQuadL1, LeastSquaresL1
 
-    if kind == "lasso":
+    if kind.startswith("lasso"):
         m, n = 96, 192
         A, b, lam = P.make_plasso(m, n, seed=2)
         kw = dict(lr=1.0, nesterov=True, tol=0.0, max_iter=25, return_all=True)
@@ -134,7 +134,11 @@ def test_library_multi_rank_step_sequence_with_thread_ranks(kind, world):
         try:
             lo, hi = r * n // world, (r + 1) * n // world
             with torch.cuda.stream(torch.cuda.Stream()):
-                if kind == "lasso":
+                if kind == "lasso_rows":   # rows of A and b split, x replicated
+                    r0, r1 = r * m // world, (r + 1) * m // world
+                    lo, hi = 0, n
+                    prob = LeastSquaresL1(np.ascontiguousarray(A[r0:r1]), b[r0:r1], lam, group=comms[r], shard="rows")
+                elif kind == "lasso":
                     prob = LeastSquaresL1(np.ascontiguousarray(A[:, lo:hi]), b, lam, group=comms[r])
                 else:
                     prob = DiagQuadL1(d[lo:hi], c[lo:hi], lam, group=comms[r])
@@ -155,12 +159,17 @@ def test_library_multi_rank_step_sequence_with_thread_ranks(kind, world):
     assert all(o is not None for o in out), "a rank thread did not finish"
     for res in out:
         assert res.nit == exp.nit == out[0].nit and res.fun == out[0].fun, "ranks must agree bit for bit"
-    x = np.concatenate([o.x for o in out])
+    if kind == "lasso_rows":
+        assert all(np.array_equal(o.x, out[0].x) for o in out), "the replicated x must be identical on every rank"
+        cat = lambda vs: vs[0]   # noqa: E731
+    else:
+        cat = np.concatenate
+    x = cat([o.x for o in out])
     assert np.linalg.norm(x - exp.x) <= 1e-10 * np.linalg.norm(exp.x)
     np.testing.assert_allclose(out[0].fun, exp.fun, rtol=1e-10)
     if kw.get("return_all"):
         for k in (1, exp.nit // 2, exp.nit):
-            xk = np.concatenate([o.allvecs[k] for o in out])
+            xk = cat([o.allvecs[k] for o in out])
             assert np.linalg.norm(xk - exp.allvecs[k]) <= 1e-10 * max(1.0, np.linalg.norm(exp.allvecs[k]))
         np.testing.assert_allclose(out[0].allerrs, exp.allerrs, rtol=1e-10, atol=1e-300)
     for c_ in comms:

@@ -37,7 +37,13 @@ def _worker(rank, world, port, case, outdir):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     warnings.simplefilter("ignore")
-    if case == "lasso":
+    if case == "lasso_rows":   # rows of A and b split over the ranks, x replicated: A_p^T r_p is exchanged
+        A, b, lam = P.make_plasso(96, 301, seed=3, n_informative=12)
+        r0, r1 = rank * 96 // world, (rank + 1) * 96 // world
+        prob = LeastSquaresL1(np.ascontiguousarray(A[r0:r1]), b[r0:r1], lam, group=dist.group.WORLD, shard="rows")
+        kw = dict(lr=1.0, nesterov=True, tol=1e-8, max_iter=60)
+        n_loc = 301
+    elif case == "lasso":
         A, b, lam = P.make_plasso(96, 301, seed=3, n_informative=12)
         lo, hi = rank * 301 // world, (rank + 1) * 301 // world
         prob = LeastSquaresL1(np.ascontiguousarray(A[:, lo:hi]), b, lam, group=dist.group.WORLD)
@@ -56,7 +62,8 @@ def _worker(rank, world, port, case, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,world", [("lasso", 2), ("lasso", 3), ("diag", 2), ("diag", 4)])
+@pytest.mark.parametrize("case,world", [("lasso", 2), ("lasso", 3), ("lasso_rows", 2), ("lasso_rows", 3), ("diag", 2),
+                                        ("diag", 4)])
 def test_sharded_solve_in_separate_processes(case, world, tmp_path):
     import torch.multiprocessing as mp
 
@@ -66,7 +73,7 @@ def test_sharded_solve_in_separate_processes(case, world, tmp_path):
     r = [np.load(tmp_path / f"r{k}.npz") for k in range(world)]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        if case == "lasso":
+        if case.startswith("lasso"):
             A, b, lam = P.make_plasso(96, 301, seed=3, n_informative=12)
             exp = cpu_ref.minimize_proximal_gradient(*P.LeastSquaresL1Ref(A, b, lam).callbacks(), np.zeros(301), lr=1.0,
                                                      nesterov=True, tol=1e-8, max_iter=60)
@@ -76,5 +83,9 @@ def test_sharded_solve_in_separate_processes(case, world, tmp_path):
                                                      nesterov=True, tol=1e-9, max_iter=120)
     assert all(int(k["nit"]) == exp.nit and int(k["status"]) == exp.status for k in r)
     assert all(float(k["fun"]) == float(r[0]["fun"]) for k in r), "ranks must agree bit for bit"
-    assert rel_err(np.concatenate([k["x"] for k in r]), exp.x) <= 1e-10
+    if case == "lasso_rows":
+        assert all(np.array_equal(k["x"], r[0]["x"]) for k in r), "the replicated x must be identical on every rank"
+        assert rel_err(r[0]["x"], exp.x) <= 1e-10
+    else:
+        assert rel_err(np.concatenate([k["x"] for k in r]), exp.x) <= 1e-10
     np.testing.assert_allclose(float(r[0]["fun"]), exp.fun, rtol=1e-10)

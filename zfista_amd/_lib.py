@@ -57,7 +57,7 @@ class Control(C.Structure):
 
 class ProblemDesc(C.Structure):
     _fields_ = [
-        ("kind", C.c_int32), ("world", C.c_int32), ("rank", C.c_int32), ("reserved", C.c_int32),
+        ("kind", C.c_int32), ("world", C.c_int32), ("rank", C.c_int32), ("row_sharded", C.c_int32),
         ("n", C.c_int64), ("m_rows", C.c_int64),
         ("d", C.c_void_p), ("c", C.c_void_p), ("A", C.c_void_p), ("b", C.c_void_p),
         ("scale", C.c_double), ("lam", C.c_double), ("box_lo", C.c_double), ("box_hi", C.c_double),

@@ -160,7 +160,8 @@ struct zf_finalize_args {
     double scale[ZF_NPART];   // pack[k] = scale[k] * total[k]
     const double* f_y_ext;    // least squares: f(y), f(x+) come from the GEMV side (else NULL)
     const double* f_x_ext;
-    int contribute_f;         // sharded least squares: only rank 0 contributes the replicated f values
+    int contribute_f;         // column-sharded least squares: only rank 0 contributes the replicated f values
+    int contribute_x;         // row-sharded least squares: x is replicated - only rank 0 contributes its sums
     double* pack;             // local packs out (S x ZF_PACK_LEN)
     zf_control* ctl;          // read for the early exit; written when `decide`
     int decide;               // unsharded x: run the decide pass here
@@ -276,9 +277,9 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     const int trial = lane / LSTR;   // slot q of this lane = quantity q of trial `trial`
     double pk[ZF_PACK_LEN];
     pk[ZF_PK_FY] = F.f_y_ext ? (F.contribute_f ? *F.f_y_ext : 0.0) : F.scale[0] * sums[0];
-    pk[ZF_PK_DOT] = sums[1];
-    pk[ZF_PK_SS] = sums[2];
-    pk[ZF_PK_GX] = F.scale[3] * sums[3];
+    pk[ZF_PK_DOT] = F.contribute_x ? sums[1] : 0.0;
+    pk[ZF_PK_SS] = F.contribute_x ? sums[2] : 0.0;
+    pk[ZF_PK_GX] = F.contribute_x ? F.scale[3] * sums[3] : 0.0;
     pk[ZF_PK_FX] = F.f_x_ext ? (F.contribute_f ? *F.f_x_ext : 0.0) : F.scale[4] * sums[4];
     pk[ZF_PK_ERR] = maxs[0];
     pk[6] = 0.0;

@@ -78,6 +78,7 @@ struct zf_init_args {
     double f_scale, lam;
     const double* f_ext;
     double* pack;
+    int contribute_g;   // row-sharded least squares: x is replicated, only rank 0 contributes g(x0)
 };
 __global__ __launch_bounds__(ZF_FIN_BLOCK) void zf_init_finalize_kernel(zf_init_args I) {
     __shared__ double lds[(ZF_FIN_BLOCK / 64) * 8];
@@ -88,9 +89,9 @@ __global__ __launch_bounds__(ZF_FIN_BLOCK) void zf_init_finalize_kernel(zf_init_
         double g = I.lam * totals[1];
         if (totals[2] > 0.0) g = INFINITY;   // zfista/problems.py:104-106
         I.pack[0] = f;
-        I.pack[1] = g;
+        I.pack[1] = I.contribute_g ? g : 0.0;
         for (int k = 2; k < ZF_PACK_LEN; ++k) I.pack[k] = 0.0;
-        I.pack[2] = totals[2];
+        I.pack[2] = I.contribute_g ? totals[2] : 0.0;
     }
 }
 __global__ void zf_init_commit_kernel(zf_control* ctl, const double* packs, int f_replicated, int stride) {
@@ -292,9 +293,10 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         ZF_TRY(hipMalloc(&s->resid, sizeof(double) * m_pad));
         ZF_TRY(hipMalloc(&s->slab, sizeof(double) * s->slices * n));
         ZF_TRY(hipMalloc(&s->ls_scal, sizeof(double) * 8));
-        if (desc->world > 1) {
-            ZF_TRY(hipMalloc(&s->s_part, sizeof(double) * m_pad));
-            ZF_TRY(hipMalloc(&s->s_all, sizeof(double) * m * desc->world));
+        if (desc->world > 1) {   // exchanged vector: A_p x_p (m) for column blocks, A_p^T r_p (n) for row blocks
+            const int64_t len = desc->row_sharded ? n : m;
+            ZF_TRY(hipMalloc(&s->s_part, sizeof(double) * ((len + 63) & ~int64_t(63))));
+            ZF_TRY(hipMalloc(&s->s_all, sizeof(double) * len * desc->world));
         }
         // launch-bound sizes (BASELINE cfg1): two fused launches per trial; ZF_LS_SMALL=0 keeps the general path
         const char* sm = getenv("ZF_LS_SMALL");
@@ -375,13 +377,16 @@ static void zf_launch_finalize(zf_solver* s, bool decide) {
     F.f_y_ext = nullptr;
     F.f_x_ext = nullptr;
     F.contribute_f = 1;
+    F.contribute_x = 1;
     if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
         F.scale[0] = 0.5;             // f = 0.5 * sum(d (x-c)^2)
         F.scale[4] = 0.5;
     } else {
         F.f_y_ext = s->ls_scal + 0;   // f(y), f(x+) come from the GEMV side and are replicated
         F.f_x_ext = s->ls_scal + 1;
-        F.contribute_f = (d.world == 1 || d.rank == 0) ? 1 : 0;
+        // column blocks: f is replicated, the x sums are partial; row blocks: the other way round
+        F.contribute_f = (d.world == 1 || d.rank == 0 || d.row_sharded) ? 1 : 0;
+        F.contribute_x = (d.world == 1 || d.rank == 0 || !d.row_sharded) ? 1 : 0;
     }
     F.pack = s->pack_local;
     F.ctl = s->ctl;
@@ -498,8 +503,15 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
                 hipLaunchKernelGGL(zf_gemvT_partial_kernel<1>, gT, dim3(ZF_BLOCK), 0, s->stream, s->ctl,
                                    d.A, s->resid, s->slab, m, n, s->rows_per_slice);
         }
+        const bool rows = d.world > 1 && d.row_sharded;
+        // (row blocks: this rank's part 2 scale A_p^T r_p goes to s_part; the caller gathers the parts
+        //  and zf_solver_enqueue_trial_finish() adds them and runs the rest of the trial)
         hipLaunchKernelGGL(zf_gemvT_combine_kernel, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, s->stream,
-                           s->ctl, s->slab, s->grad, 2 * d.scale, n, s->slices);
+                           rows ? nullptr : s->ctl, s->slab, rows ? s->s_part : s->grad, 2 * d.scale, n, s->slices);
+        if (rows) {
+            ZF_HIP(hipGetLastError());
+            return ZF_OK;
+        }
         // (2) fused prox step with the gradient vector in HBM
         a.p0 = s->grad;
         a.p1 = nullptr;
@@ -510,7 +522,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         // s_part; the caller gathers the parts and zf_solver_enqueue_trial_finish() adds them.
         zf_ring3 xr = {{s->xb[0], s->xb[1], s->xb[2]}};
         zf_ring3 sout = s->sring;
-        if (d.world > 1) sout = {{s->s_part, s->s_part, s->s_part}};
+        if (d.world > 1) sout = {{s->s_part, s->s_part, s->s_part}};   // (column blocks; row blocks returned above)
         int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
         if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
         if (V == 2)
@@ -536,6 +548,48 @@ extern "C" int zf_solver_enqueue_trial_finish(zf_solver* s) {
     const zf_problem_desc& d = s->desc;
     if (d.kind != ZF_PROBLEM_LEAST_SQUARES_L1 || d.world == 1) return ZF_OK;
     const int64_t m = d.m_rows;
+    if (d.row_sharded) {
+        // row blocks: grad = sum over ranks (rank order) of the gathered parts, then - on the full,
+        // replicated x, identically on every rank - the prox step, this rank's rows of A x+ and its
+        // part of f(x+); the pack carries the replicated x sums from rank 0 only
+        const int64_t n = d.n;
+        zf_ring3 g3 = {{s->grad, s->grad, s->grad}};
+        hipLaunchKernelGGL(zf_sum_parts_kernel, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, s->stream, nullptr, s->s_all,
+                           (int)d.world, n, g3, -1);
+        zf_step_args a;
+        a.ctl = s->ctl;
+        a.beta_ring = s->beta_ring;
+        for (int k = 0; k < ZF_MAX_RING; ++k) a.xb[k] = s->xb[k < s->ring ? k : 0];
+        a.lam = d.lam;
+        a.lo = d.box_lo;
+        a.hi = d.box_hi;
+        a.n = n;
+        a.tiles_per_wg = s->tiles;
+        a.blk_part = s->blk_part;
+        a.pass_log = nullptr;
+        a.pass_slot = 0;
+        a.hist = s->hist;
+        a.hist_cap = s->hist_cap > 0 ? s->hist_cap : 1;
+        a.hist_stride = s->hist_stride;
+        a.p0 = s->grad;
+        a.p1 = nullptr;
+        zf_launch_trial_t<false>(s, a);
+        const int V = (n % 2 == 0) ? 2 : 1;
+        zf_ring3 xr = {{s->xb[0], s->xb[1], s->xb[2]}};
+        int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
+        if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
+        if (V == 2)
+            hipLaunchKernelGGL(zf_gemv_rows_kernel<2>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, s->ctl, d.A, xr, s->sring,
+                               1, m, n);
+        else
+            hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, s->ctl, d.A, xr, s->sring,
+                               1, m, n);
+        hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1, d.b,
+                           d.scale, m, s->ls_scal + 1);
+        zf_launch_finalize(s, false);
+        ZF_HIP(hipGetLastError());
+        return ZF_OK;
+    }
     hipLaunchKernelGGL(zf_sum_parts_kernel, dim3(zf_grid_for(m)), dim3(ZF_BLOCK), 0, s->stream, s->ctl, s->s_all,
                        (int)d.world, m, s->sring, 1);
     hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1, d.b,
@@ -567,6 +621,7 @@ static int zf_init_ls_tail(zf_solver* s) {
     I.lam = d.lam;
     I.f_ext = s->ls_scal + 1;
     I.pack = s->pack_local;
+    I.contribute_g = (d.world == 1 || !d.row_sharded || d.rank == 0) ? 1 : 0;
     hipLaunchKernelGGL(zf_init_finalize_kernel, dim3(1), dim3(ZF_FIN_BLOCK), 0, s->stream, I);
     ZF_HIP(hipGetLastError());
     if (d.world == 1)
@@ -586,7 +641,7 @@ extern "C" int zf_solver_set_svec_buffers(zf_solver* s, double* s_part_dev, doub
     ZF_REQUIRE(s && s_part_dev && s_all_dev, "zf_solver_set_svec_buffers: null argument");
     ZF_REQUIRE(!s->initialised, "zf_solver_set_svec_buffers: call before zf_solver_enqueue_init");
     ZF_REQUIRE(s->desc.kind == ZF_PROBLEM_LEAST_SQUARES_L1 && s->desc.world > 1,
-               "zf_solver_set_svec_buffers: only for sharded least squares");
+               "zf_solver_set_svec_buffers: only for sharded least squares (m doubles per rank for column blocks, n for row blocks)");
     if (s->own_svec) {
         if (s->s_part) (void)hipFree(s->s_part);
         if (s->s_all) (void)hipFree(s->s_all);
@@ -630,6 +685,7 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
     I.lam = d.lam;
     I.pack = s->pack_local;
     I.f_ext = nullptr;
+    I.contribute_g = 1;
     const int g = zf_grid_for(n);
     I.nblocks = g;
     if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
@@ -646,7 +702,7 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
         const int64_t m = d.m_rows;
         const int V = (n % 2 == 0) ? 2 : 1;
         zf_ring3 xr = {{s->xb[0], s->xb[0], s->xb[0]}};
-        double* dst = (d.world > 1) ? s->s_part : s->sring.p[0];
+        double* dst = (d.world > 1 && !d.row_sharded) ? s->s_part : s->sring.p[0];   // row blocks: A_p x0 is local
         zf_ring3 s0 = {{dst, dst, dst}};
         int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
         if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
@@ -657,7 +713,7 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
             hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
                                s0, -1, m, n);
         ZF_HIP(hipGetLastError());
-        if (d.world > 1) return ZF_OK;
+        if (d.world > 1 && !d.row_sharded) return ZF_OK;
         return zf_init_ls_tail(s);
     }
     hipLaunchKernelGGL(zf_init_finalize_kernel, dim3(1), dim3(ZF_FIN_BLOCK), 0, s->stream, I);
@@ -745,7 +801,7 @@ extern "C" int zf_solver_get_x_prev(zf_solver* s, double* x_host) {
 extern "C" int zf_solver_enqueue_init_finish(zf_solver* s) {
     ZF_REQUIRE(s, "zf_solver_enqueue_init_finish: null solver");
     const zf_problem_desc& d = s->desc;
-    if (d.kind != ZF_PROBLEM_LEAST_SQUARES_L1 || d.world == 1) return ZF_OK;
+    if (d.kind != ZF_PROBLEM_LEAST_SQUARES_L1 || d.world == 1 || d.row_sharded) return ZF_OK;
     zf_ring3 s0 = {{s->sring.p[0], s->sring.p[0], s->sring.p[0]}};
     hipLaunchKernelGGL(zf_sum_parts_kernel, dim3(zf_grid_for(d.m_rows)), dim3(ZF_BLOCK), 0, s->stream, nullptr,
                        s->s_all, (int)d.world, d.m_rows, s0, -1);
@@ -755,7 +811,8 @@ extern "C" int zf_solver_enqueue_init_finish(zf_solver* s) {
 
 extern "C" int zf_solver_enqueue_init_commit(zf_solver* s) {
     ZF_REQUIRE(s, "zf_solver_enqueue_init_commit: null solver");
-    const int f_repl = (s->desc.kind == ZF_PROBLEM_LEAST_SQUARES_L1) ? 1 : 0;
+    // column-sharded least squares: f(x0) is replicated (taken once); row blocks and P-diag: partial sums
+    const int f_repl = (s->desc.kind == ZF_PROBLEM_LEAST_SQUARES_L1 && !s->desc.row_sharded) ? 1 : 0;
     hipLaunchKernelGGL(zf_init_commit_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, f_repl,
                        s->sub * ZF_PACK_LEN);
     ZF_HIP(hipGetLastError());
@@ -855,8 +912,12 @@ extern "C" int zf_solver_set_comm(zf_solver* s, zf_comm* comm) {
 static int zf_gather_packs(zf_solver* s, int64_t packs) {
     return zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, s->stream);
 }
-static int zf_gather_svec(zf_solver* s) {
+static int zf_gather_svec(zf_solver* s, bool at_init = false) {
     if (s->desc.kind != ZF_PROBLEM_LEAST_SQUARES_L1 || s->desc.world == 1) return ZF_OK;
+    if (s->desc.row_sharded) {   // the n-vector A_p^T r_p of a trial; the init has nothing to exchange
+        if (at_init) return ZF_OK;
+        return zf_comm_all_gather(s->comm, s->s_part, s->s_all, s->desc.n, s->stream);
+    }
     return zf_comm_all_gather(s->comm, s->s_part, s->s_all, s->desc.m_rows, s->stream);
 }
 
@@ -866,7 +927,7 @@ extern "C" int zf_solver_enqueue_init_all(zf_solver* s, const double* x0_dev) {
     int rc = zf_solver_enqueue_init(s, x0_dev);
     if (rc) return rc;
     if (s->comm) {
-        if ((rc = zf_gather_svec(s))) return rc;
+        if ((rc = zf_gather_svec(s, true))) return rc;
         if ((rc = zf_solver_enqueue_init_finish(s))) return rc;
         // the init pack sits at the head of this rank's pack buffer; ranks are sub x ZF_PACK_LEN apart in
         // pack_all (zf_init_commit_kernel's stride), so the whole buffer is gathered

@@ -71,6 +71,7 @@ class DeviceSolver:
         self.n = int(desc_fields["n"])
         self.kind = int(desc_fields["kind"])
         self.m_rows = int(desc_fields.get("m_rows", 0) or 0)
+        self.row_sharded = bool(desc_fields.get("row_sharded", 0))
         if stream is None:
             import torch
 
@@ -132,9 +133,11 @@ class DeviceSolver:
             self.handle, C.c_void_p(self._pack_local.data_ptr()), C.c_void_p(self._pack_all.data_ptr())))
         self._s_part = self._s_all = None
         if self.kind == _lib.ZF_PROBLEM_LEAST_SQUARES_L1 and self.world > 1:
-            # C2: the m-vector A_p x_p of every rank, gathered once per trial
-            self._s_part = torch.zeros(self.m_rows, dtype=torch.float64, device="cuda")
-            self._s_all = torch.zeros(self.m_rows * self.world, dtype=torch.float64, device="cuda")
+            # C2: the m-vector A_p x_p of every rank (column blocks) or the n-vector
+            # A_p^T r_p (row blocks), gathered once per trial
+            length = self.n if self.row_sharded else self.m_rows
+            self._s_part = torch.zeros(length, dtype=torch.float64, device="cuda")
+            self._s_all = torch.zeros(length * self.world, dtype=torch.float64, device="cuda")
             _lib.check(self.lib.zf_solver_set_svec_buffers(
                 self.handle, C.c_void_p(self._s_part.data_ptr()), C.c_void_p(self._s_all.data_ptr())))
 
@@ -175,7 +178,8 @@ class DeviceSolver:
             return
         self.init_begin(x0_dev_ptr)
         if self.split:
-            self._gather_svec()
+            if not self.row_sharded:   # (row blocks: A_p x0 is local, nothing to exchange at the start)
+                self._gather_svec()
             self.init_finish()
             self._gather()
         self.init_commit()

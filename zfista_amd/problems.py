@@ -143,11 +143,17 @@ class LeastSquaresL1(NativeProblem):
 
     kind = _lib.ZF_PROBLEM_LEAST_SQUARES_L1
 
-    def __init__(self, A, b, lam, scale=0.5, bounds=None, group=None):
-        """With ``group`` set, ``A`` is this rank's column block A_p (m x n_p, row-major) of a
-        matrix whose columns - and the decision vector - are partitioned over the ranks of
-        that process group; ``b`` is replicated.  ``f`` / ``jac_f`` as plain callables then
-        refer to the local block only; the solve exchanges A_p x_p once per trial."""
+    def __init__(self, A, b, lam, scale=0.5, bounds=None, group=None, shard="columns"):
+        """With ``group`` set and ``shard="columns"`` (default), ``A`` is this rank's column block A_p
+        (m x n_p, row-major) of a matrix whose columns - and the decision vector - are partitioned
+        over the ranks of that process group; ``b`` is replicated; the solve exchanges the m-vector
+        A_p x_p once per trial.  ``shard="rows"``: ``A`` (m_p x n) and ``b`` (m_p) are this rank's ROW
+        block, x is replicated on every rank (pass the whole x0) and the n-vector A_p^T r_p is
+        exchanged instead - the layout for tall matrices.  ``f`` / ``jac_f`` as plain callables
+        refer to the local block only."""
+        if shard not in ("columns", "rows"):
+            raise ValueError("shard must be 'columns' or 'rows'")
+        self.shard = shard
         self.A = _to_device(A, "A")
         self.b = _to_device(b, "b")
         if self.A.ndim != 2 or self.b.ndim != 1 or self.A.shape[0] != self.b.shape[0]:
@@ -187,6 +193,7 @@ class LeastSquaresL1(NativeProblem):
 
         rank, world = rank_world(self.group)
         fields = dict(kind=self.kind, world=world, rank=rank, n=self.n_features, m_rows=self.m_rows,
+                      row_sharded=int(self.shard == "rows" and world > 1),
                       d=None, c=None, A=self.A.data_ptr(), b=self.b.data_ptr(),
                       scale=self.scale, lam=self.lam, box_lo=self.box[0], box_hi=self.box[1])
         return fields, (self.A, self.b)
