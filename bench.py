@@ -16,7 +16,7 @@ until at least ``--min-seconds`` (default 0.6 s) of timed work has run (at most 
 and ``value`` / ``ms_per_step`` are the MEDIAN block: the sustained rate on a warm device.  The
 first and last block are reported beside it.
 
-One launch ("pass") of the fused kernel carries a chain of up to S = 8 iterations (temporal
+One launch ("pass") of the fused kernel carries a chain of up to S = 16 iterations (temporal
 blocking), so K iterations take about K / S passes.  Rank 0 prints ONE JSON line.
 
 value = (N * K) / t : iterations per second in units of one 10^8-element shard.
@@ -25,11 +25,13 @@ N > 1 (weak scaling: n = N x 10^8) the full-problem rate K / t is reported besid
 it as ``config.iters_per_sec_full_problem``.
 
 roofline (dominant kernel: zf_trial_kernel, full-chain passes only, HIP events on the solver's
-stream):  ``achieved`` = HBM bytes one pass MOVES (48 B x n for a chain: four streams read, two
-iterates written; 40 B x n for S = 1; checked against the PMC counters in profiles/) / mean
-duration; ``frac`` = achieved / 8 TB/s <= 1.  The fp64 VALU roof of the same kernel is reported
-beside it (instructions per element and trial from the ISA, profiles/r02_isa_mix_*.json);
-``bound`` names the larger of the two fractions.  SURVEY 8d's per-iteration figure (40 B per
+stream), two roofs side by side: ``hbm`` = HBM bytes one pass MOVES (48 B x n for a chain: four
+streams read, two iterates written; 40 B x n for S = 1; checked against the PMC counters in
+profiles/) / mean duration / 8 TB/s, and ``fp64_valu`` = fp64 VALU issue slots the chain needs
+(instructions per element and trial from the ISA, profiles/r02_isa_mix_*.json) / slots available
+in that duration at 2.4 GHz.  ``bound`` names the larger fraction and ``achieved`` / ``peak`` /
+``unit`` / ``frac`` repeat that roof (<= 1); the chain of 16 is bound by the fp64 vector pipe, the
+chains of 8 and shorter by HBM.  SURVEY 8d's per-iteration figure (40 B per
 element and ITERATION) divided by the same duration is ``equivalent_one_iteration_GBps``: what a
 one-iteration-per-pass kernel would have to sustain to match - it exceeds the HBM peak because
 the chain avoids that traffic, it is not a bandwidth.
@@ -132,7 +134,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=0.6,
                     help="repeat the W + K block until this much timed work has run (sustained clocks)")
     ap.add_argument("--max-blocks", type=int, default=400)
-    ap.add_argument("--sub-iters", type=int, default=0, help="chain length S (0 = library default 8)")
+    ap.add_argument("--sub-iters", type=int, default=0, help="chain length S: 1 / 2 / 4 / 8 / 16 (0 = library default)")
     ap.add_argument("--libcomm", action="store_true",
                     help="N = 1 only: run the sharded step sequence over a 1-rank RCCL communicator created "
                          "inside the library (zf_comm): what the per-pass exchange costs without a second GPU")
@@ -288,29 +290,39 @@ def main():
                 valu_ms = vpe * n * S / (FP64_LANES_PER_CYCLE * CLOCK_GHZ * 1e9) * 1e3
                 valu_frac = valu_ms / ker_ms
             bound = "hbm" if valu_frac is None or hbm_frac >= valu_frac else "fp64_valu"
+            hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+                   "bytes_per_launch": pass_bytes,
+                   "bytes_note": "HBM bytes a full-chain pass moves: 4 streams read + 2 iterates written = 48 B per "
+                                 "element (S > 1), 40 B for S = 1"}
+            valu = None if vpe is None else {
+                "achieved": vpe * n * S / (ker_ms * 1e-3) / 1e12,
+                "peak": FP64_LANES_PER_CYCLE * CLOCK_GHZ * 1e9 / 1e12,
+                "unit": "T lane-instructions/s",
+                "frac": valu_frac,
+                "valu_instructions_per_element_trial": vpe,
+                "source": "profiles/" + ISA_PROFILE.format(S=S),
+                "min_ms_at_2.4GHz": valu_ms,
+                "note": "fp64 VALU issue slots (256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz; a wave64 fp64 "
+                        "instruction of any kind - add, mul, fma, max - takes one slot of 4 cycles) used by the chain / "
+                        "available in the measured duration at the NOMINAL clock; the clock drops under this load "
+                        "(power limit, profiles/r02_s*_pmc_traffic.json), so the fraction of the slots at the running "
+                        "clock is higher",
+            }
+            top = hbm if bound == "hbm" else valu
             line["roofline"] = {
                 "bound": bound,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": hbm_frac,
+                "achieved": top["achieved"],
+                "peak": top["peak"],
+                "unit": top["unit"],
+                "frac": top["frac"],
                 "traffic": traffic,
                 "traffic_source": f"profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                   "passes, bytes per full-chain launch)" if traffic else None,
-                "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}>",
+                "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (full-chain passes)",
                 "kernel_avg_ms": ker_ms,
                 "kernel_launches_timed": full_n if full_n else part_n,
-                "bytes_per_launch": pass_bytes,
-                "bytes_note": "HBM bytes a full-chain pass moves: 4 streams read + 2 iterates written = 48 B per "
-                              "element (S > 1), 40 B for S = 1",
-                "fp64_valu": None if vpe is None else {
-                    "valu_instructions_per_element_trial": vpe,
-                    "source": "profiles/" + ISA_PROFILE.format(S=S),
-                    "min_ms_at_2.4GHz": valu_ms,
-                    "frac": valu_frac,
-                    "note": "VALU issue time of the chain at the nominal clock / measured duration; the clock "
-                            "drops under this load (power limit), so the real VALU fraction is higher",
-                },
+                "hbm": hbm,
+                "fp64_valu": valu,
                 "other_passes_avg_ms": part_ms / part_n if part_n else None,
                 "equivalent_one_iteration_GBps": ALG_BYTES_PER_ELEM * n * S / (ker_ms * 1e-3) / 1e9,
                 "equivalent_note": "40 B x n x S (SURVEY 8d's per-iteration bytes x iterations per pass) / duration: "

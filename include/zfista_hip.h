@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ZF_ABI_VERSION 2
+#define ZF_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------ */
 #define ZF_OK 0
@@ -45,7 +45,8 @@ extern "C" {
 #define ZF_PROBLEM_LEAST_SQUARES_L1 2 /* f = scale |Ax-b|^2,          g = lam |x|_1 (+box) */
 
 #define ZF_PACK_LEN 8    /* doubles in one per-trial scalar pack */
-#define ZF_MAX_SUB_ITERS 8 /* packs per pass: a rank's pack buffer holds sub_iters x ZF_PACK_LEN doubles */
+#define ZF_MAX_SUB_ITERS 16 /* packs per pass: a rank's pack buffer holds sub_iters x ZF_PACK_LEN doubles */
+#define ZF_DEFAULT_SUB_ITERS 16
 #define ZF_MAX_LAG (2 * ZF_MAX_SUB_ITERS - 2) /* accepted iterations a solve may run ahead of its stored iterates */
 #define ZF_PEND_FLUSH (-1) /* zf_control.pend_status: materialise the lagging iterates, then keep running */
 #define ZF_TRACE_COLS 8  /* doubles per accepted iteration in the trace ring */
@@ -130,7 +131,7 @@ typedef struct zf_options {  /* keyword arguments of proximal_gradient.py:317-33
     int32_t deprecated;
     int32_t sub_iters;   /* S: trials one pass over the data chains in registers, for separable
                             problems (temporal blocking): 0 = library default (ZF_SUB_ITERS in the
-                            environment, else 8), 1 / 2 / 4 / 8 explicit.  Results do not depend on it;
+                            environment, else ZF_DEFAULT_SUB_ITERS), 1 / 2 / 4 / 8 / 16 explicit.  Results do not depend on it;
                             lam >= 0, lr > 0, decay_rate > 0 are required by the fused kernels.     */
     int32_t reserved;
 } zf_options;

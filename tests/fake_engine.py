@@ -86,11 +86,15 @@ class FakeSolver:
         if c.pend_status == _lib.ZF_MAXITER and c.nit < max_iter:
             c.pend_status = 0
 
-    def _fresh_len(self):
-        c = self.ctl
+    def _fresh_len(self):   # csrc/zf_decide.h: zf_fresh_len
+        c, S = self.ctl, self.sub_iters
         if c.pend_status != 0:
             return 0
-        return max(1, min(self.sub_iters, 2 * self.sub_iters - 1 - c.lag, c.max_iter - c.nit))
+        left = c.max_iter - c.nit
+        if c.lag == 0 and left >= S:
+            return S
+        short = S // 2 if S >= 16 else S
+        return max(1, min(short, 2 * S - 1 - c.lag, left))
 
     def _chain_packs(self):
         """One pass: replay of the lagging iterations, then the fresh trials, from the stored

@@ -25,12 +25,12 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in zfista_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.zf_abi_version() == 2
+    assert lib.zf_abi_version() == 3
 
 
 def test_struct_mirrors():
     lib = _lib.load()
-    assert lib.zf_sizeof_control() == C.sizeof(_lib.Control) == 288
+    assert lib.zf_sizeof_control() == C.sizeof(_lib.Control) == 416
     assert C.sizeof(_lib.ProblemDesc) == 96
     assert C.sizeof(_lib.Options) == 64
 

@@ -33,15 +33,19 @@ def test_bench_json_line():
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] in ("hbm", "fp64_valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    # a fraction of a roof: bytes the pass really moves over its duration, never above the peak
-    assert 0 < r["frac"] <= 1.0 and r["achieved"] == r["bytes_per_launch"] / (r["kernel_avg_ms"] * 1e-3) / 1e9
-    assert r["bytes_per_launch"] == 48 * 2000000 and r["equivalent_one_iteration_GBps"] > r["achieved"]
-    # 21 iterations in chains of 8: at least 3 passes per block; the block is repeated (sustained clocks)
+    assert r["bound"] in ("hbm", "fp64_valu") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    top = r[r["bound"]]
+    assert (r["achieved"], r["peak"], r["unit"], r["frac"]) == (top["achieved"], top["peak"], top["unit"], top["frac"])
+    # fractions of roofs: bytes the pass really moves (issue slots it really needs) over its duration
+    h, v = r["hbm"], r["fp64_valu"]
+    assert h["unit"] == "GB/s" and h["peak"] == 8000.0 and 0 < h["frac"] <= 1.0
+    assert h["achieved"] == h["bytes_per_launch"] / (r["kernel_avg_ms"] * 1e-3) / 1e9 and h["bytes_per_launch"] == 48 * 2000000
+    assert v is None or 0 < v["frac"] <= 1.0
+    assert r["frac"] == max(h["frac"], v["frac"] if v else 0.0) and r["equivalent_one_iteration_GBps"] > h["achieved"]
+    # 21 iterations in chains of 16: 2 passes per block; the block is repeated (sustained clocks)
     cfg = d["config"]
-    assert cfg["passes_per_block"] >= 3 and cfg["blocks"] >= 2 and cfg["temporal_blocking_chain"] == 8
-    assert cfg["full_chain_passes"] >= 2 * cfg["blocks"]
+    assert cfg["passes_per_block"] >= 2 and cfg["blocks"] >= 2 and cfg["temporal_blocking_chain"] == 16
+    assert cfg["full_chain_passes"] >= cfg["blocks"]
     assert cfg["ms_per_step_min_block"] <= cfg["ms_per_step_median_block"] == d["ms_per_step"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
@@ -75,6 +79,6 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert (d["n_gpus"], d["steps"], d["scaling"]) == (2, 24, "weak") and "cpu_baseline" not in d
-    assert d["config"]["n_total"] == 4000000 and d["config"]["passes_per_block"] >= 3
+    assert d["config"]["n_total"] == 4000000 and d["config"]["passes_per_block"] >= 2
     # whole-job aggregate: two shards' worth of iterations per unit time
     assert abs(d["value"] - 2 * 24 / (d["ms_per_step"] * 24 / 1e3) * (2000000 / 1e8)) < 1e-6 * d["value"]

@@ -51,7 +51,7 @@ def _pdiag(n, seed=1, box=None):
     return DiagQuadL1(d, c, lam, bounds=box)
 
 
-@pytest.mark.parametrize("sub", [1, 2, 4, 8])
+@pytest.mark.parametrize("sub", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("tag", list(RUNS))
 def test_temporal_blocking_matches_reference_golden(tag, sub, golden):
     from zfista_amd import _lib
@@ -95,7 +95,7 @@ def test_temporal_blocking_invariance(case):
     x0 = np.random.default_rng(case).standard_normal(n)
     ref = _run(prob, x0, opts, 1)
     assert ref["nit"] >= 1 or ref["status"] != 0
-    for sub in (2, 4, 8):
+    for sub in (2, 4, 8, 16):
         for chunk in (1, 7):
             r = _run(prob, x0, opts, sub, chunk=chunk)
             assert (r["nit"], r["status"]) == (ref["nit"], ref["status"]), (sub, chunk)
@@ -112,7 +112,7 @@ def test_temporal_blocking_box(nesterov):
     x0 = np.zeros(n)
     opts = dict(lr=2.0, nesterov=nesterov, tol=1e-9, max_iter=150)
     ref = _run(prob, x0, opts, 1)
-    for sub in (2, 4, 8):
+    for sub in (2, 4, 8, 16):
         r = _run(prob, x0, opts, sub)
         assert (r["nit"], r["status"]) == (ref["nit"], ref["status"])
         assert np.array_equal(r["rows"], ref["rows"])
@@ -127,7 +127,7 @@ def test_temporal_blocking_long_run_ring_wrap():
     prob = _pdiag(n, seed=5)
     opts = dict(lr=0.45, nesterov=True, tol=0.0, max_iter=2 * _lib.ZF_RING + 13)
     ref = _run(prob, np.zeros(n), opts, 1, chunk=256)
-    for sub in (4, 8):
+    for sub in (4, 8, 16):
         r = _run(prob, np.zeros(n), opts, sub, chunk=256)
         assert r["nit"] == ref["nit"] == 2 * _lib.ZF_RING + 13
         assert np.array_equal(r["rows"], ref["rows"])
@@ -170,7 +170,8 @@ def test_large_n_geometry_is_a_function_of_n_only():
     ref = _run(prob, x0, opts, 1, chunk=64)
     again = _run(prob, x0, opts, 8, chunk=64)
     third = _run(prob, x0, opts, 8, chunk=3)
-    for r in (again, third):
+    fourth = _run(prob, x0, opts, 16, chunk=5)
+    for r in (again, third, fourth):
         assert (r["nit"], r["status"], r["lr"], r["F"], r["trials"]) == \
             (ref["nit"], ref["status"], ref["lr"], ref["F"], ref["trials"])
         assert np.array_equal(r["rows"], ref["rows"])

@@ -348,7 +348,7 @@ def test_chained_passes_do_not_change_results(case):
     x0 = np.random.default_rng(case).standard_normal(n)
     kw = CHAIN_CASES[case]
     ref = _chain_run(prob, x0, kw, 1, 64)
-    for sub in (2, 4, 8):
+    for sub in (2, 4, 8, 16):
         for chunk in (1, 9):
             r = _chain_run(prob, x0, kw, sub, chunk)
             for key in ("nit", "status", "lr", "F", "trials"):

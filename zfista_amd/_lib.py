@@ -22,7 +22,7 @@ ZF_RUNNING, ZF_CONVERGED, ZF_MAXITER, ZF_BACKTRACK_FAILED = 0, 1, 2, 3
 ZF_PROBLEM_DIAG_QUAD_L1, ZF_PROBLEM_LEAST_SQUARES_L1 = 1, 2
 ZF_MO_GENERIC, ZF_MO_JOS1, ZF_MO_FDS = 0, 1, 2
 ZF_PACK_LEN, ZF_TRACE_COLS, ZF_RING = 8, 8, 1024
-ZF_MAX_SUB_ITERS = 8
+ZF_MAX_SUB_ITERS = 16
 ZF_MAX_LAG = 2 * ZF_MAX_SUB_ITERS - 2
 ZF_PEND_FLUSH = -1
 TR_ERR, TR_F, TR_LR, TR_FUN, TR_TRIALS, TR_FX, TR_GX, TR_FY = range(8)

@@ -70,15 +70,19 @@ ZF_HD inline void zf_free_bufs(int cur, int prev, int ring, int* first, int* sec
     *second = (m > 1) ? f[1] : f[0];
 }
 
-// FRESH trials of the next pass: S, bounded by the chain capacity 2 S - 1 (lagging iterations are
-// replayed in front of them), by the iterations left (:539), and 0 for a materialise-only pass
+// FRESH trials of the next pass: S when a full chain fits (nothing lagging, S iterations left);
+// otherwise a SHORT chain - at most S, or S / 2 for S = 16, whose longest chain runs only in its
+// branch-free form (the other shapes reuse the 8-trial bodies) - bounded by the chain capacity
+// 2 S - 1 (lagging iterations are replayed in front), by the iterations left (:539), and 0 for a
+// materialise-only pass
 ZF_HD inline int zf_fresh_len(const zf_control* c) {
     if (c->pend_status != 0) return 0;
     const int sub = c->sub_iters > 0 ? c->sub_iters : 1;
-    int64_t n = sub;
+    const int64_t left = c->max_iter - c->nit;
+    if (c->lag == 0 && left >= sub) return sub;
+    int64_t n = sub >= 16 ? sub / 2 : sub;
     const int64_t cap = (int64_t)(2 * sub - 1) - c->lag;
     if (n > cap) n = cap;
-    const int64_t left = c->max_iter - c->nit;
     if (n > left) n = left;
     if (n < 1) n = 1;
     return (int)n;

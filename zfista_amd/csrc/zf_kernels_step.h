@@ -132,6 +132,12 @@ template <bool NT> __device__ __forceinline__ void zf_st2(zf_d2* p, zf_d2 v) {
 }
 
 constexpr int ZF_MAX_SUB = ZF_MAX_SUB_ITERS;   // trials chained per pass (temporal blocking), upper bound
+// levels of the transposing wave butterfly for a chain of S = 2^h trials: slot q < 5 of lane j * (64 >> h)
+// ends up with quantity q of trial j
+constexpr int zf_chain_h(int S) { return S >= 16 ? 4 : S >= 8 ? 3 : S >= 4 ? 2 : S >= 2 ? 1 : 0; }
+#ifndef ZF_S16_UB
+#define ZF_S16_UB 1   // units per load batch of the 16-trial chain (192 VGPRs of running sums leave room for one)
+#endif
 constexpr int ZF_MAX_RING = 4;
 
 struct zf_step_args {
@@ -194,8 +200,8 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     if (b1 > F.nblocks) b1 = F.nblocks;
     // GT trials (6 GT quantities) per round: bounded registers; their wave reductions run as one
     // transposing butterfly (zf_wave_reduce_multi - the same pairing as a butterfly per quantity)
-    constexpr int GT = S;   // (256 threads per workgroup: registers allow all 6 S loads of an index in flight)
-    constexpr int GH = (GT >= 8) ? 3 : (GT >= 4) ? 2 : (GT >= 2) ? 1 : 0;
+    constexpr int GT = S < 8 ? S : 8;   // (registers allow 48 loads of an index in flight: 8 trials per round)
+    constexpr int GH = zf_chain_h(GT);
 #pragma unroll
     for (int j0 = 0; j0 < S; j0 += GT) {
         double sums[5 * GT], maxs[GT];
@@ -227,19 +233,19 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     }
     __syncthreads();
     const bool single = (gridDim.x == 1);   // small problems: one finalize workgroup, no hand-over needed
-    if (threadIdx.x < 64) {
-        if (threadIdx.x < NQ) {
-            const int k = threadIdx.x;
-            double r = lds[k];
-            for (int w = 1; w < NW; ++w)
-                r = (k % ZF_NPART == ZF_NPART - 1) ? fmax(r, lds[w * NQ + k]) : r + lds[w * NQ + k];
-            if (single) s_single[k] = r;
-            else zf_publish(F.slice_part + (int64_t)k * ZF_FIN_WGS + blockIdx.x, r);
-        }
-        if (single) {
-            if (threadIdx.x == 0) s_last = 1;
-        } else {
+    if (threadIdx.x < NQ) {   // (NQ = 6 S <= 96 quantities: threads of the first two waves)
+        const int k = threadIdx.x;
+        double r = lds[k];
+        for (int w = 1; w < NW; ++w)
+            r = (k % ZF_NPART == ZF_NPART - 1) ? fmax(r, lds[w * NQ + k]) : r + lds[w * NQ + k];
+        if (single) s_single[k] = r;
+        else zf_publish(F.slice_part + (int64_t)k * ZF_FIN_WGS + blockIdx.x, r);
+    }
+    if (single) {
+        if (threadIdx.x == 0) s_last = 1;
+    } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NQ > 64) __syncthreads();   // publishers in two waves: all published before the ticket
         if (threadIdx.x == 0) {
             const unsigned t = __hip_atomic_fetch_add(F.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (t == (unsigned)(gridDim.x - 1));
@@ -249,7 +255,6 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             s_last = last;
-        }
         }
     }
     __syncthreads();
@@ -264,7 +269,8 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
                         : (lane < nsl) ? zf_consume(F.slice_part + (int64_t)k * ZF_FIN_WGS + lane) : 0.0;
     // one transposing butterfly for all 6 S totals (same pairing as a shuffle tree per quantity):
     // the totals of trial j end in lane j * (64 / S), which builds, keeps and stores pack j
-    constexpr int LSTR = 64 >> GH;
+    constexpr int SH = zf_chain_h(S);   // (all S trials at once here; the gather above went 8 trials per round)
+    constexpr int LSTR = 64 >> SH;
     double sums[5 * S], maxs[S];
 #pragma unroll
     for (int j = 0; j < S; ++j) {
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
         for (int k = 0; k < 5; ++k) sums[j * 5 + k] = tot[j * ZF_NPART + k];
         maxs[j] = tot[j * ZF_NPART + 5];
     }
-    zf_wave_reduce_multi<5 * S, GH, false>(sums, lane);
-    zf_wave_reduce_multi<S, GH, true>(maxs, lane);
+    zf_wave_reduce_multi<5 * S, SH, false>(sums, lane);
+    zf_wave_reduce_multi<S, SH, true>(maxs, lane);
     const int trial = lane / LSTR;   // slot q of this lane = quantity q of trial `trial`
     double pk[ZF_PACK_LEN];
     pk[ZF_PK_FY] = F.f_y_ext ? (F.contribute_f ? *F.f_y_ext : 0.0) : F.scale[0] * sums[0];
@@ -316,7 +322,9 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 // HIST: every fresh trial also stores its iterate into the history ring (streaming return_all: the
 // iterates of a chain never exist anywhere else).  A trial that turns out rejected leaves garbage in a
 // slot that the retry overwrites; replayed trials wrote theirs when they were fresh.
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST>
+// SP: packs per pass of the solver (rows of partials written, S <= SP: a 16-chain solver runs its short
+// passes through the 8-trial bodies and leaves the packs of trials 8 .. 15 zero)
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST, int SP = S>
 __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds, const int lag, const int nf) {
     constexpr bool FULL = (MODE == 0);          // nothing replayed, S fresh trials
     constexpr bool FRESH_FULL = (MODE <= 1);    // S fresh trials
@@ -385,7 +393,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     const int64_t full_tiles = n2 / ZF_TILE_UNITS;
     const int64_t G = gridDim.x;
     // UB units are loaded, then computed, at a time
-    constexpr int UB = (S >= 8) ? ZF_S8_UB : ZF_TILE_U;
+    constexpr int UB = (S >= 16) ? ZF_S16_UB : (S >= 8) ? ZF_S8_UB : ZF_TILE_U;
     auto load_batch = [&](int64_t first_unit, zf_d2 (&a)[UB], zf_d2 (&o)[UB], zf_d2 (&q)[UB], zf_d2 (&cc)[UB]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -422,7 +430,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
 #pragma unroll
         for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], first_unit + u * ZF_BLOCK);
     };
-    if constexpr (UB == ZF_TILE_U || MODE == 1 || HIST) {
+    if constexpr (UB == ZF_TILE_U || MODE == 1 || HIST || S >= 16) {
         // short chains (<= 148 VGPRs, three or more waves per SIMD): the other waves of the SIMD
         // cover a wave's load latency; all loads of a batch in flight, then its arithmetic.
         // (Also the replay + S fresh trials body of long chains and the history-recording kernels:
@@ -502,7 +510,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     // workgroup partials of every fresh trial of the chain: rows j * ZF_NPART + k.  All 6 S wave
     // reductions run as ONE transposing butterfly (zf_wave_reduce_multi: same pairing, hence the
     // same bits, as a butterfly per quantity), then the four wave totals are added in wave order.
-    constexpr int H = (S >= 8) ? 3 : (S >= 4) ? 2 : (S >= 2) ? 1 : 0;
+    constexpr int H = zf_chain_h(S);
     constexpr int NQ = S * ZF_NPART;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double sums[5 * S], maxs[S];
@@ -526,31 +534,52 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
         lds[wave * NQ + zf_wave_reduce_multi_index<S, H>(0, lane) * ZF_NPART + 5] = maxs[0];
     }
     __syncthreads();
-    if (threadIdx.x < NQ) {
+    if (threadIdx.x < SP * ZF_NPART) {
         const int t = threadIdx.x;
-        double v = lds[t];
+        double v = 0.0;   // (rows of trials S .. SP - 1: no such trial in this pass)
+        if (t < NQ) {
+            v = lds[t];
 #pragma unroll
-        for (int w = 1; w < ZF_WAVES; ++w) v = (t % ZF_NPART == 5) ? fmax(v, lds[w * NQ + t]) : v + lds[w * NQ + t];
+            for (int w = 1; w < ZF_WAVES; ++w) v = (t % ZF_NPART == 5) ? fmax(v, lds[w * NQ + t]) : v + lds[w * NQ + t];
+        }
         A.blk_part[(int64_t)t * gridDim.x + blockIdx.x] = v;
     }
 }
 
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false>
+// PART (chains only, S > 1): a pass is launched as TWO kernels, each of which exits at once unless the
+// pass has its shape - 0: the full chain (nothing replayed, S fresh trials: the hot, branch-free
+// body), 1: every other shape (replays, shorter chains, materialise-only).  One kernel holding all
+// bodies needs the registers of the largest plus what the compiler hoists across the branches
+// (S = 16: 274 instead of 250 VGPRs - one wave per SIMD instead of two; S = 8: 207 instead of 190);
+// the second launch costs a kernel boundary (~1.5 us) per pass.
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false, int PART = 0>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
     // wave-uniform control reads (scalar loads); written by the previous step's decide
     if (A.ctl->status != ZF_RUNNING) return;
-    if (S == 1) {
+    if constexpr (S == 1) {
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = 1;
         zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, 1);
     } else {
         const int lag = A.ctl->lag;
         const int nf = zf_fresh_len(A.ctl);   // fresh trials of this chain (0: materialise only)
+        const bool full = (lag == 0 && nf == S);
+        if (full != (PART == 0)) return;
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = (lag << 8) | nf;
-        if (lag == 0 && nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, S);
-        else if (nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1, HIST>(A, lds, lag, S);
-        else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, lag, nf);
+        if constexpr (PART == 0) {
+            zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, S);
+        } else if constexpr (S >= 16) {
+            // every shape but the full 16-chain goes through the 8-trial bodies (zf_fresh_len: at most
+            // S / 2 fresh trials then); the pack rows of trials 8 .. 15 are written as zeros
+            constexpr int SS = S / 2;
+            if (lag == 0 && nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 0, HIST, S>(A, lds, 0, SS);
+            else if (nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 1, HIST, S>(A, lds, lag, SS);
+            else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 2, HIST, S>(A, lds, lag, nf);
+        } else {
+            if (nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1, HIST>(A, lds, lag, S);
+            else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, lag, nf);
+        }
     }
 }
 

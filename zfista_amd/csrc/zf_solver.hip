@@ -250,9 +250,9 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         int sub = opt->sub_iters;
         const char* se = getenv("ZF_SUB_ITERS");
         if (sub <= 0 && se) sub = atoi(se);
-        if (sub <= 0) sub = ZF_MAX_SUB;
+        if (sub <= 0) sub = ZF_DEFAULT_SUB_ITERS;
         if (sub > ZF_MAX_SUB) sub = ZF_MAX_SUB;
-        s->sub = sub >= 8 ? 8 : sub >= 4 ? 4 : sub >= 2 ? 2 : 1;
+        s->sub = sub >= 16 ? 16 : sub >= 8 ? 8 : sub >= 4 ? 4 : sub >= 2 ? 2 : 1;
     }
     s->ring = s->sub > 1 ? 4 : 3;   // x_k, x_{k-1} + the one or two iterates a pass stores
     ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * s->ring * n_pad));
@@ -322,29 +322,37 @@ extern "C" int zf_solver_destroy(zf_solver* s) {
 }
 
 // ---- launches ---------------------------------------------------------------
+// one pass = the full-chain kernel + (chains only) the kernel for every other shape; each exits at
+// once when the pass has not its shape (zf_trial_kernel, PART)
+template <bool GI, bool NEST, bool BOX, bool NT, int S, bool HIST>
+static void zf_launch_trial_parts(zf_solver* s, const zf_step_args& a) {
+    dim3 g(s->grid), b(ZF_BLOCK);
+    hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 0>), g, b, 0, s->stream, a);
+    if constexpr (S > 1) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 1>), g, b, 0, s->stream, a);
+}
+
 // history-recording variants (nontemporal policy only: the history is write-once)
 template <bool GI, int S>
 static void zf_launch_trial_hist(zf_solver* s, const zf_step_args& a) {
     const bool nest = s->opt.nesterov != 0;
-    dim3 g(s->grid), b(ZF_BLOCK);
-    if (nest && s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, true, true, true, S, true>), g, b, 0, s->stream, a);
-    else if (nest) hipLaunchKernelGGL((zf_trial_kernel<GI, true, false, true, S, true>), g, b, 0, s->stream, a);
-    else if (s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, false, true, true, S, true>), g, b, 0, s->stream, a);
-    else hipLaunchKernelGGL((zf_trial_kernel<GI, false, false, true, S, true>), g, b, 0, s->stream, a);
+    if (nest && s->box) zf_launch_trial_parts<GI, true, true, true, S, true>(s, a);
+    else if (nest) zf_launch_trial_parts<GI, true, false, true, S, true>(s, a);
+    else if (s->box) zf_launch_trial_parts<GI, false, true, true, S, true>(s, a);
+    else zf_launch_trial_parts<GI, false, false, true, S, true>(s, a);
 }
 
 template <bool GI, bool NT, int S>
 static void zf_launch_trial_t3(zf_solver* s, const zf_step_args& a) {
     const bool nest = s->opt.nesterov != 0;
-    dim3 g(s->grid), b(ZF_BLOCK);
-    if (nest && s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, true, true, NT, S>), g, b, 0, s->stream, a);
-    else if (nest) hipLaunchKernelGGL((zf_trial_kernel<GI, true, false, NT, S>), g, b, 0, s->stream, a);
-    else if (s->box) hipLaunchKernelGGL((zf_trial_kernel<GI, false, true, NT, S>), g, b, 0, s->stream, a);
-    else hipLaunchKernelGGL((zf_trial_kernel<GI, false, false, NT, S>), g, b, 0, s->stream, a);
+    if (nest && s->box) zf_launch_trial_parts<GI, true, true, NT, S, false>(s, a);
+    else if (nest) zf_launch_trial_parts<GI, true, false, NT, S, false>(s, a);
+    else if (s->box) zf_launch_trial_parts<GI, false, true, NT, S, false>(s, a);
+    else zf_launch_trial_parts<GI, false, false, NT, S, false>(s, a);
 }
 template <bool GI, bool NT>
 static void zf_launch_trial_t2(zf_solver* s, const zf_step_args& a) {
     if constexpr (GI) {   // temporal blocking needs the gradient inline (separable f)
+        if (s->sub == 16) return zf_launch_trial_t3<GI, NT, 16>(s, a);
         if (s->sub == 8) return zf_launch_trial_t3<GI, NT, 8>(s, a);
         if (s->sub == 4) return zf_launch_trial_t3<GI, NT, 4>(s, a);
         if (s->sub == 2) return zf_launch_trial_t3<GI, NT, 2>(s, a);
@@ -396,7 +404,8 @@ static void zf_launch_finalize(zf_solver* s, bool decide) {
     int wgs = (s->grid + ZF_FIN_THREADS - 1) / ZF_FIN_THREADS;   // no more workgroups than slices of work
     if (wgs > ZF_FIN_WGS) wgs = ZF_FIN_WGS;
     if (wgs < 1) wgs = 1;
-    if (s->sub == 8) hipLaunchKernelGGL(zf_finalize_kernel<8>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
+    if (s->sub == 16) hipLaunchKernelGGL(zf_finalize_kernel<16>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
+    else if (s->sub == 8) hipLaunchKernelGGL(zf_finalize_kernel<8>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
     else if (s->sub == 4) hipLaunchKernelGGL(zf_finalize_kernel<4>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
     else if (s->sub == 2) hipLaunchKernelGGL(zf_finalize_kernel<2>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
     else hipLaunchKernelGGL(zf_finalize_kernel<1>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);

@@ -108,8 +108,9 @@ def minimize_proximal_gradient(
         own simplex Newton / bracketing solver (host loop, one kernel per evaluation); "device"
         runs that same search inside one persistent kernel per trial (recognised problems only).
         The default can be set with the environment variable ZF_DUAL_SOLVER.
-    sub_iters : {1, 2, 4, 8}, separable single-objective problems only: iterations chained per
-        pass over the data (temporal blocking).  Results do not depend on it.  Default 8.
+    sub_iters : {1, 2, 4, 8, 16}, separable single-objective problems only: iterations chained per
+        pass over the data (temporal blocking).  Results do not depend on it.  Default 16 (8 with
+        ``return_all``).
     """
     if deprecated:
         warn(_MSG_DEPRECATED, stacklevel=2)
@@ -163,9 +164,10 @@ class NativeRun:
             max_backtrack_iter=int(opts["max_backtrack_iter"]),
             nesterov=int(bool(opts["nesterov"])), deprecated=int(bool(opts["deprecated"])),
             # return_all records every iterate into a ring in HBM as the trial computes it
-            # (zf_solver_set_history): chains stay 8 long; chain lengths 2 / 4 have no recording kernel
+            # (zf_solver_set_history): recording kernels exist for chains of 8 and of 1
             sub_iters=(int(opts.get("sub_iters", 0) or 0) if not opts.get("return_all")
-                       else (1 if int(opts.get("sub_iters", 0) or 0) in (1, 2, 4) else 0)),
+                       else (1 if (int(opts.get("sub_iters", 0) or 0) in (1, 2, 4) or solver_factory is not None)
+                             else 8)),   # (test stand-ins have no history ring: one iterate per pass)
         )
         if solver_factory is not None:
             # test seam: a stand-in with DeviceSolver's interface (tests/fake_engine.py)
