@@ -60,7 +60,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_LANES_PER_CYCLE = 256 * 4 * 16
 CLOCK_GHZ = 2.4
 LR, LAM = 0.45, 0.1
-PMC_PROFILE = "r02_pmc_traffic.json"
+PMC_PROFILE = "r02_s{S}_pmc_traffic.json"
 ISA_PROFILE = "r02_isa_mix_trial_kernel_s{S}.json"
 
 
@@ -85,10 +85,19 @@ def measured_traffic(n, sub_iters):
     """HBM bytes per full-chain launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same command, gfx950 corrections applied;
     tools/profile_bench.sh).  None when no profile for this n and chain length is committed."""
-    prof = _profile(PMC_PROFILE)
+    prof = _profile(PMC_PROFILE.format(S=sub_iters))
     if not prof or prof.get("n") != n or prof.get("sub_iters", 1) != sub_iters:
         return None
     return prof["hbm_bytes_per_launch"]
+
+
+def measured_clock_ghz(n, sub_iters):
+    """Median engine clock under the full-chain kernel from the committed GRBM_GUI_ACTIVE pass of the
+    same command (tools/profile_bench.sh step 5), or None."""
+    prof = _profile(PMC_PROFILE.format(S=sub_iters))
+    if not prof or prof.get("n") != n or "engine_clock_GHz" not in prof:
+        return None
+    return prof["engine_clock_GHz"]["median"]
 
 
 def valu_per_element_trial(sub_iters):
@@ -286,6 +295,7 @@ def main():
             hbm_frac = achieved / HBM_PEAK_GBS
             vpe = valu_per_element_trial(S)
             valu_ms = valu_frac = None
+            clk = measured_clock_ghz(n, S)
             if vpe:
                 valu_ms = vpe * n * S / (FP64_LANES_PER_CYCLE * CLOCK_GHZ * 1e9) * 1e3
                 valu_frac = valu_ms / ker_ms
@@ -302,11 +312,13 @@ def main():
                 "valu_instructions_per_element_trial": vpe,
                 "source": "profiles/" + ISA_PROFILE.format(S=S),
                 "min_ms_at_2.4GHz": valu_ms,
+                "engine_clock_GHz_under_this_kernel": clk,
+                "frac_at_that_clock": None if clk is None else valu_frac * CLOCK_GHZ / clk,
                 "note": "fp64 VALU issue slots (256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz; a wave64 fp64 "
                         "instruction of any kind - add, mul, fma, max - takes one slot of 4 cycles) used by the chain / "
                         "available in the measured duration at the NOMINAL clock; the clock drops under this load "
-                        "(power limit, profiles/r02_s*_pmc_traffic.json), so the fraction of the slots at the running "
-                        "clock is higher",
+                        "(power limit; median clock from the GRBM_GUI_ACTIVE pass in profiles/r02_s*_pmc_traffic.json), "
+                        "so the fraction of the slots at the running clock - frac_at_that_clock - is higher",
             }
             top = hbm if bound == "hbm" else valu
             line["roofline"] = {
@@ -316,7 +328,7 @@ def main():
                 "unit": top["unit"],
                 "frac": top["frac"],
                 "traffic": traffic,
-                "traffic_source": f"profiles/{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                "traffic_source": f"profiles/{PMC_PROFILE.format(S=S)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                   "passes, bytes per full-chain launch)" if traffic else None,
                 "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (full-chain passes)",
                 "kernel_avg_ms": ker_ms,

@@ -67,8 +67,11 @@ valu = counter_rows("clock", "SQ_INSTS_VALU", with_time=True)
 if gui and valu:
     import collections
 
-    mode = collections.Counter(round(v[0] / 1e6) for v in valu).most_common(1)[0][0]
-    full_ids = {v[3] for v in valu if round(v[0] / 1e6) == mode}
+    # (a pass of a 16-chain solver is two launches, one of which exits at once: the launches that did
+    #  no work - also those enqueued after the solve stopped - are left out by their duration)
+    busy = [v for v in valu if v[2] - v[1] > 100_000]
+    mode = collections.Counter(round(v[0] / 1e6) for v in busy).most_common(1)[0][0]
+    full_ids = {v[3] for v in busy if round(v[0] / 1e6) == mode}
     full_valu = [v[0] for v in valu if v[3] in full_ids]
     clocks = sorted(cyc / 8 / (t1 - t0) for cyc, t0, t1, did in gui if did in full_ids and t1 > t0)
     durs = sorted((t1 - t0) / 1e6 for cyc, t0, t1, did in gui if did in full_ids and t1 > t0)

@@ -153,7 +153,21 @@ __device__ __forceinline__ double zf_soft_threshold(double u, double tau) {
 // at creation; hosts route other inputs through the general form above.
 __device__ __forceinline__ double zf_soft_threshold_nn(double u, double tau) {
     const double t = fmin(fmax(u, -tau), tau);
-    return copysign(u - t, u);
+    // copysign(u - t, u) as ONE v_bfi on the high word, in place.  (The library lowering - and the same
+    // bit operations written in C - built the result in a fresh register pair, because the compiler
+    // keeps m alive for the |x+| sum that follows: one v_bfi + one v_mov per element and trial.)
+    const double m = u - t;
+    int mhi = __double2hiint(m);
+    asm("v_bfi_b32 %0, %2, %0, %1" : "+v"(mhi) : "v"(__double2hiint(u)), "s"(0x7fffffff));
+    return __hiloint2double(mhi, __double2loint(m));
+}
+// running maximum of |x|: v_max_f64 acc, acc, |x| with no canonicalisation of the accumulator (the
+// compiler re-quiets a loop-carried fmax operand once per trip: one more v_max per element pair and
+// trial).  Drops a NaN x like fmax does; the accumulator is never a signalling NaN.
+__device__ __forceinline__ double zf_max_abs(double acc, double x) {
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(acc), "v"(x));
+    return r;
 }
 // np.clip(u, lo, hi) = minimum(maximum(u, lo), hi)  (jaxopt projection_box, problems.py:137)
 __device__ __forceinline__ double zf_clip(double u, double lo, double hi) {

@@ -52,7 +52,7 @@ __device__ __forceinline__ double zf_elem_diag(double xk, double xo, double d, d
     a.l1 += fabs(xn);
     const double rn = xn - c;
     a.fx = __builtin_fma(d * rn, rn, a.fx);
-    a.mx = fmax(a.mx, fabs(dx));
+    a.mx = zf_max_abs(a.mx, dx);
     return xn;
 }
 
@@ -82,7 +82,7 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
     a.dot = __builtin_fma(grad, dx, a.dot);
     a.ss = __builtin_fma(dx, dx, a.ss);
     a.l1 += fabs(xn);
-    a.mx = fmax(a.mx, fabs(dx));
+    a.mx = zf_max_abs(a.mx, dx);
     return xn;
 }
 
