@@ -131,6 +131,38 @@ template <bool NT> __device__ __forceinline__ void zf_st2(zf_d2* p, zf_d2 v) {
     else *p = v;
 }
 
+// LDS-DMA: one 16-byte global load per lane straight into LDS (no VGPR destination).  The wave's 64
+// pieces land lane-linear at the wave-uniform byte address `lds_dst` (M0) + lane * 16.  hipcc does not
+// count an asm load in its s_waitcnt bookkeeping: the caller waits with zf_wait_vm<N>() before the
+// LDS is read.  M0 is compiler-reserved: saved and restored inside the statement (guide, 5 / asm notes).
+template <bool NT> __device__ __forceinline__ void zf_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    if (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// wait until at most N vector-memory operations of this wave are outstanding (they retire in issue order)
+template <int N> __device__ __forceinline__ void zf_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+typedef __attribute__((address_space(3))) void* zf_lds_ptr;
+// The full 16-trial chain holds 192 VGPRs of running sums (248 in all, two waves per SIMD): no registers
+// are left for a second load batch, and with one batch the fp64 pipe idles while a wave waits for HBM
+// (measured: 84 % of the issue slots at the running clock).  Its loads therefore go through LDS by DMA:
+// the four 16-byte pieces of the NEXT unit are in flight while the chain of the current one computes.
+// Each wave reads back only what it loaded itself: no barrier.
+#ifndef ZF_S16_GLDS
+#define ZF_S16_GLDS 1
+#endif
+template <int S, int MODE, bool HIST, bool GRAD_INLINE> constexpr bool zf_uses_glds() {
+    return ZF_S16_GLDS != 0 && S >= 16 && MODE == 0 && !HIST && GRAD_INLINE;
+}
+constexpr int ZF_GLDS_STREAMS = 4;                                   // x_k, x_{k-1}, d, c
+constexpr int ZF_GLDS_STAGE_UNITS = ZF_GLDS_STREAMS * ZF_BLOCK;      // 16-byte units per stage (16 KiB)
+
 constexpr int ZF_MAX_SUB = ZF_MAX_SUB_ITERS;   // trials chained per pass (temporal blocking), upper bound
 // levels of the transposing wave butterfly for a chain of S = 2^h trials: slot q < 5 of lane j * (64 >> h)
 // ends up with quantity q of trial j
@@ -325,7 +357,8 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 // SP: packs per pass of the solver (rows of partials written, S <= SP: a 16-chain solver runs its short
 // passes through the 8-trial bodies and leaves the packs of trials 8 .. 15 zero)
 template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST, int SP = S>
-__device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds, const int lag, const int nf) {
+__device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds, const int lag, const int nf,
+                                              zf_d2* stage = nullptr) {
     constexpr bool FULL = (MODE == 0);          // nothing replayed, S fresh trials
     constexpr bool FRESH_FULL = (MODE <= 1);    // S fresh trials
     const int cur = A.ctl->cur;
@@ -430,7 +463,46 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
 #pragma unroll
         for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], first_unit + u * ZF_BLOCK);
     };
-    if constexpr (UB == ZF_TILE_U || MODE == 1 || HIST || S >= 16) {
+    if constexpr (zf_uses_glds<S, MODE, HIST, GRAD_INLINE>()) {
+        // LDS-DMA pipeline over this workgroup's units (tile-major, ZF_TILE_U units per tile): stage k & 1
+        // holds unit k.  Per unit: read the stage into registers, start the DMA of unit k + 1 into the
+        // other stage, run the chain, store the two iterates, and only then wait for the DMA - which by
+        // then has had a whole chain (~1.4 us) to land; the two stores issued after it may stay in flight
+        // (vector-memory operations retire in issue order: vmcnt(2)).
+        int my_tiles = 0;
+        for (int t = 0; t < A.tiles_per_wg; ++t)
+            if ((int64_t)t * G + blockIdx.x < full_tiles) my_tiles = t + 1;
+        const int total = my_tiles * ZF_TILE_U;
+        const int wave = threadIdx.x >> 6;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(zf_lds_ptr)stage + wave * 1024u);
+        auto unit_of = [&](int k) -> int64_t {
+            return ((int64_t)(k / ZF_TILE_U) * G + blockIdx.x) * ZF_TILE_UNITS + (k % ZF_TILE_U) * ZF_BLOCK + threadIdx.x;
+        };
+        auto issue = [&](int k) {
+            const int64_t i = unit_of(k);
+            const unsigned base = lds0 + (unsigned)(k & 1) * (ZF_GLDS_STAGE_UNITS * 16u);
+            zf_glds16<NT && (ZF_X_NT != 0)>(xk2 + i, base);
+            if (NESTEROV) zf_glds16<NT && (ZF_X_NT != 0)>(xo2 + i, base + ZF_BLOCK * 16u);
+            zf_glds16<NT>(p02 + i, base + 2 * ZF_BLOCK * 16u);
+            zf_glds16<NT>(p12 + i, base + 3 * ZF_BLOCK * 16u);
+        };
+        if (total > 0) {
+            issue(0);
+            zf_wait_vm<0>();
+#pragma unroll 1
+            for (int k = 0; k < total; ++k) {
+                const zf_d2* sp = stage + (k & 1) * ZF_GLDS_STAGE_UNITS + threadIdx.x;
+                const zf_d2 a = sp[0];
+                const zf_d2 o = NESTEROV ? sp[ZF_BLOCK] : a;
+                const zf_d2 q = sp[2 * ZF_BLOCK];
+                const zf_d2 cc = sp[3 * ZF_BLOCK];
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < total) issue(k + 1);
+                advance(a, o, q, cc, unit_of(k));   // the chain + the two iterate stores
+                zf_wait_vm<2>();
+            }
+        }
+    } else if constexpr (UB == ZF_TILE_U || MODE == 1 || HIST || S >= 16) {
         // short chains (<= 148 VGPRs, three or more waves per SIMD): the other waves of the SIMD
         // cover a wave's load latency; all loads of a batch in flight, then its arithmetic.
         // (Also the replay + S fresh trials body of long chains and the history-recording kernels:
@@ -556,6 +628,8 @@ template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST =
 __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
+    constexpr bool GLDS = (PART == 0) && zf_uses_glds<S, 0, HIST, GRAD_INLINE>();
+    __shared__ zf_d2 stage[GLDS ? 2 * ZF_GLDS_STAGE_UNITS : 1];   // two stages of the LDS-DMA pipeline (32 KiB)
     // wave-uniform control reads (scalar loads); written by the previous step's decide
     if (A.ctl->status != ZF_RUNNING) return;
     if constexpr (S == 1) {
@@ -568,7 +642,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
         if (full != (PART == 0)) return;
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = (lag << 8) | nf;
         if constexpr (PART == 0) {
-            zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, S);
+            zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, S, stage);
         } else if constexpr (S >= 16) {
             // every shape but the full 16-chain goes through the 8-trial bodies (zf_fresh_len: at most
             // S / 2 fresh trials then); the pack rows of trials 8 .. 15 are written as zeros
