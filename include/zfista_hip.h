@@ -336,6 +336,11 @@ int zf_mo_prepare(zf_mo* s, double* f_y_out /* m */);           /* J = jac_f(y),
  * formed and kept on the device for zf_mo_solve_dual_device, which hands it back with its result;
  * zf_mo_get_f_y fetches it otherwise (synchronises) */
 int zf_mo_prepare_async(zf_mo* s);
+/* Fused outer iteration (built-in problems, unsharded x, m <= 3), on / off: zf_mo_commit and
+ * zf_mo_prepare_async only record what is due and the next zf_mo_solve_dual_device forms y = x_k +
+ * beta (x_k - x_{k-1}) (:534), f(y) (:140) and J = jac_f(y) (:142) inside its one kernel: one launch and one
+ * read-back per trial.  Every other entry point first brings the buffers up to date, so results do not change. */
+int zf_mo_set_fused(zf_mo* s, int32_t on);
 int zf_mo_get_f_y(zf_mo* s, double* f_y_out /* m */);
 int zf_mo_set_jac(zf_mo* s, const double* J_host);              /* generic kind         :142 */
 /* out[0..m) = g_i(p), out[m] = |p-v|^2, out[m+1] = |w@J|^2, out[m+2..2m+2) = J_i.(p-y)   :162-173 */

@@ -151,6 +151,7 @@ SIGNATURES = {
                                          C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int64), C.POINTER(C.c_double), _P, _P, _P]),
     "zf_mo_prepare_async": (C.c_int, [_P]),
+    "zf_mo_set_fused": (C.c_int, [_P, C.c_int32]),
     "zf_mo_get_f_y": (C.c_int, [_P, _P]),
     "zf_mo_solve_stats": (C.c_int, [_P, _P]),
     "zf_mo_recover": (C.c_int, [_P, C.c_double, _P, _P]),

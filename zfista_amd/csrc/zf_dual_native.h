@@ -57,6 +57,16 @@ struct evaluator {
 // every array index is a constant after unrolling, so on the device the whole object lives in the
 // registers of the one lane that advances it (dynamically indexed members would be sent to scratch
 // or LDS: measured 80 us per Newton step for m = 3 against ~2 us of arithmetic).
+// state of the m = 2 root finder; empty for m >= 3 (the machine is copied LDS -> registers -> LDS around
+// every step on the device: fields that are never used would still occupy registers all along)
+template <bool ON>
+struct bracket_state {
+    double a, b, pa, pb, s, fs;
+    int side;
+};
+template <>
+struct bracket_state<false> {};
+
 template <int M>
 struct machine {
     static_assert(M >= 2 && M <= MAXM, "2 <= m <= 8");
@@ -75,8 +85,7 @@ struct machine {
     double w[M], fun;
     // state
     double grad[M], h, d[M], step, slope, t_base, t_acc;
-    double a, b, pa, pb, s, fs;   // m = 2 bracket
-    int side;
+    bracket_state<M == 2> br;     // m = 2 bracket
     double T[M][M];               // column i = e_i - w (directions of the curvature probes)
 
     ZF_DHD bool done() const { return phase == P_DONE; }
@@ -171,64 +180,111 @@ struct machine {
 
     // w_new = argmin over the unit simplex of q.w + 1/2 w'Qw by enumerating supports (KKT check).
     // For a support S the KKT system is written at full size - rows outside S pin w_i = 0 - so
-    // that every index is a constant.
+    // that every index is a constant.  qp_candidate examines ONE support: false if it yields no
+    // KKT point, else the point and its model value.
+    ZF_DHD_INLINE static bool qp_candidate(const double (&q)[M], const double (&Q)[M][M], const int mask,
+                                           double (&wq)[M], double& val) {
+        double K[N][N], rhs[N], sol[N];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const bool in_i = (mask >> i) & 1;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const bool in_j = (mask >> j) & 1;
+                K[i][j] = in_i ? (in_j ? Q[i][j] : 0.0) : (i == j ? 1.0 : 0.0);
+            }
+            K[i][M] = in_i ? 1.0 : 0.0;
+            K[M][i] = in_i ? 1.0 : 0.0;
+            rhs[i] = in_i ? -q[i] : 0.0;
+        }
+        K[M][M] = 0.0;
+        rhs[M] = 1.0;
+        bool good = solve_kkt(K, rhs, sol);
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+            if (((mask >> i) & 1) && sol[i] < -1e-14) good = false;   // infeasible
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            wq[i] = (((mask >> i) & 1) && sol[i] > 0.0) ? sol[i] : 0.0;
+            sum += wq[i];
+        }
+        if (!(sum > 0.0)) good = false;
+        const double inv = good ? sum : 1.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) wq[i] /= inv;
+        const double mu = sol[M];
+        double red[M], redmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double t = q[i] + mu;
+#pragma unroll
+            for (int j = 0; j < M; ++j) t += Q[i][j] * wq[j];
+            red[i] = t;
+            redmax = fabs(t) > redmax ? fabs(t) : redmax;
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+            if (!((mask >> i) & 1) && red[i] < -1e-10 * (1.0 + redmax)) good = false;   // not a KKT point
+        val = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) t += Q[i][j] * wq[j];
+            val += q[i] * wq[i] + 0.5 * wq[i] * t;
+        }
+        return good;
+    }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    ZF_DHD_INLINE static double lane_value(double v, int k) {   // v of lane k (k wave-uniform), in every lane
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+        return __hiloint2double(hi, lo);
+    }
+#endif
+
     ZF_DHD_INLINE static void simplex_qp(const double (&q)[M], const double (&Q)[M][M], double (&w_new)[M]) {
         double best_val = INFINITY;
         bool have = false;
-        for (int mask = 1; mask < (1 << M); ++mask) {
-            double K[N][N], rhs[N], sol[N];
+        constexpr int NSUP = (1 << M) - 1;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZF_QP_SEQ)
+        // On the device the machine is advanced by ALL lanes of one wave on identical copies of the state
+        // (mo_machine_step): lane l examines support l + 1 - the 2^M - 1 KKT systems are solved side by
+        // side instead of one after the other (each is a few hundred dependent instructions) - and every
+        // lane then walks the candidates in support order, exactly the host loop's selection.
+        const int lane = (int)(threadIdx.x & 63u);
+        for (int base = 0; base < NSUP; base += 64) {
+            const int mask = base + lane + 1;
+            const bool mine = mask <= NSUP;
+            double wq[M], val;
+            const bool good = qp_candidate(q, Q, mine ? mask : 1, wq, val) && mine;
+            const int good_i = good ? 1 : 0;
+            // (the walk runs on wave-uniform values - scalar registers - and only the winner's point is
+            //  fetched: keeping a running w_new in vector registers beside wq spilled)
+            int best_k = -1;
 #pragma unroll
-            for (int i = 0; i < M; ++i) {
-                const bool in_i = (mask >> i) & 1;
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    const bool in_j = (mask >> j) & 1;
-                    K[i][j] = in_i ? (in_j ? Q[i][j] : 0.0) : (i == j ? 1.0 : 0.0);
+            for (int k = 0; k < (NSUP < 64 ? NSUP : 64); ++k) {
+                if (base + k < NSUP) {
+                    const bool good_k = __builtin_amdgcn_readlane(good_i, k) != 0;
+                    const double val_k = lane_value(val, k);
+                    if (good_k && val_k < best_val) {
+                        best_val = val_k;
+                        best_k = k;
+                    }
                 }
-                K[i][M] = in_i ? 1.0 : 0.0;
-                K[M][i] = in_i ? 1.0 : 0.0;
-                rhs[i] = in_i ? -q[i] : 0.0;
             }
-            K[M][M] = 0.0;
-            rhs[M] = 1.0;
-            if (!solve_kkt(K, rhs, sol)) continue;
-            bool feasible = true;
+            if (best_k >= 0) {
+                have = true;
 #pragma unroll
-            for (int i = 0; i < M; ++i)
-                if (((mask >> i) & 1) && sol[i] < -1e-14) feasible = false;
-            if (!feasible) continue;
-            double wq[M], sum = 0.0;
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                wq[i] = (((mask >> i) & 1) && sol[i] > 0.0) ? sol[i] : 0.0;
-                sum += wq[i];
+                for (int i = 0; i < M; ++i) w_new[i] = lane_value(wq[i], best_k);
             }
-            if (!(sum > 0.0)) continue;
-#pragma unroll
-            for (int i = 0; i < M; ++i) wq[i] /= sum;
-            const double mu = sol[M];
-            double red[M], redmax = 0.0;
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                double t = q[i] + mu;
-#pragma unroll
-                for (int j = 0; j < M; ++j) t += Q[i][j] * wq[j];
-                red[i] = t;
-                redmax = fabs(t) > redmax ? fabs(t) : redmax;
-            }
-            bool kkt = true;
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-                if (!((mask >> i) & 1) && red[i] < -1e-10 * (1.0 + redmax)) kkt = false;
-            if (!kkt) continue;
-            double val = 0.0;
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                double t = 0.0;
-#pragma unroll
-                for (int j = 0; j < M; ++j) t += Q[i][j] * wq[j];
-                val += q[i] * wq[i] + 0.5 * wq[i] * t;
-            }
+        }
+#else
+        for (int mask = 1; mask <= NSUP; ++mask) {
+            double wq[M], val;
+            if (!qp_candidate(q, Q, mask, wq, val)) continue;
             if (val < best_val) {
                 best_val = val;
                 have = true;
@@ -236,6 +292,7 @@ struct machine {
                 for (int i = 0; i < M; ++i) w_new[i] = wq[i];
             }
         }
+#endif
         if (!have) {   // numerically degenerate: the best vertex
             int v = 0;
             double bv = INFINITY;
@@ -279,12 +336,14 @@ struct machine {
         phase = P_LS;
     }
     ZF_DHD_INLINE void request_bracket_point() {
-        s = (a * pb - b * pa) / (pb - pa);   // secant point of the bracket
-        if (!(a < s && s < b)) s = 0.5 * (a + b);
-        npts = 1;
-        pts[0][0] = s;
-        pts[0][1] = 1.0 - s;
-        phase = P_BRACKET;
+        if constexpr (M == 2) {
+            br.s = (br.a * br.pb - br.b * br.pa) / (br.pb - br.pa);   // secant point of the bracket
+            if (!(br.a < br.s && br.s < br.b)) br.s = 0.5 * (br.a + br.b);
+            npts = 1;
+            pts[0][0] = br.s;
+            pts[0][1] = 1.0 - br.s;
+            phase = P_BRACKET;
+        }
     }
     ZF_DHD_INLINE void finish(long nit_value) {
         nit = nit_value;
@@ -313,8 +372,10 @@ struct machine {
         h = 1e-5;
         fun = 0.0;
         step = slope = t_base = t_acc = 0.0;
-        a = b = pa = pb = s = fs = 0.0;
-        side = 0;
+        if constexpr (M == 2) {
+            br.a = br.b = br.pa = br.pb = br.s = br.fs = 0.0;
+            br.side = 0;
+        }
         double sum = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
@@ -363,52 +424,61 @@ struct machine {
             return request_curvature();
         }
         case P_ENDS: {
-            pa = jacs[0][0] - jacs[0][1];
-            pb = jacs[1][0] - jacs[1][1];
-            if (pa >= 0.0) {
-                w[0] = 0.0, w[1] = 1.0, fun = funs[0];
-                return finish(1);
+            if constexpr (M == 2) {
+                br.pa = jacs[0][0] - jacs[0][1];
+                br.pb = jacs[1][0] - jacs[1][1];
+                if (br.pa >= 0.0) {
+                    w[0] = 0.0, w[1] = 1.0, fun = funs[0];
+                    return finish(1);
+                }
+                if (br.pb <= 0.0) {
+                    w[0] = 1.0, w[1] = 0.0, fun = funs[1];
+                    return finish(2);
+                }
+                br.a = 0.0, br.b = 1.0, br.side = 0, br.fs = funs[0];
+                nit = 3;
+                return request_bracket_point();
             }
-            if (pb <= 0.0) {
-                w[0] = 1.0, w[1] = 0.0, fun = funs[1];
-                return finish(2);
-            }
-            a = 0.0, b = 1.0, side = 0, fs = funs[0];
-            nit = 3;
-            return request_bracket_point();
+            return;
         }
         case P_BRACKET: {
-            fs = funs[0];
-            const double ps = jacs[0][0] - jacs[0][1];
-            const bool stop = (ps == 0.0 || (b - a) <= tol);
-            if (!stop) {
-                // the new point replaces the end of its sign; Illinois: an end that stays for the
-                // second time in a row has its derivative halved.  (Written with selects: the
-                // compiler turned the branchy form into a dynamically indexed stack slot.)
-                const bool neg = ps < 0.0;
-                const double pa_kept = (side == 1) ? pa * 0.5 : pa;
-                const double pb_kept = (side == -1) ? pb * 0.5 : pb;
-                a = neg ? s : a;
-                b = neg ? b : s;
-                pa = neg ? ps : pa_kept;
-                pb = neg ? pb_kept : ps;
-                side = neg ? -1 : 1;
-                if ((b - a) <= tol) {
-                    s = 0.5 * (a + b);
-                    npts = 1;
-                    pts[0][0] = s, pts[0][1] = 1.0 - s;
-                    phase = P_FINAL;
-                    return;
+            if constexpr (M == 2) {
+                br.fs = funs[0];
+                const double ps = jacs[0][0] - jacs[0][1];
+                const bool stop = (ps == 0.0 || (br.b - br.a) <= tol);
+                if (!stop) {
+                    // the new point replaces the end of its sign; Illinois: an end that stays for the
+                    // second time in a row has its derivative halved.  (Written with selects: the
+                    // compiler turned the branchy form into a dynamically indexed stack slot.)
+                    const bool neg = ps < 0.0;
+                    const double pa_kept = (br.side == 1) ? br.pa * 0.5 : br.pa;
+                    const double pb_kept = (br.side == -1) ? br.pb * 0.5 : br.pb;
+                    br.a = neg ? br.s : br.a;
+                    br.b = neg ? br.b : br.s;
+                    br.pa = neg ? ps : pa_kept;
+                    br.pb = neg ? pb_kept : ps;
+                    br.side = neg ? -1 : 1;
+                    if ((br.b - br.a) <= tol) {
+                        br.s = 0.5 * (br.a + br.b);
+                        npts = 1;
+                        pts[0][0] = br.s, pts[0][1] = 1.0 - br.s;
+                        phase = P_FINAL;
+                        return;
+                    }
+                    nit += 1;
+                    if (nit < max_iter + 3) return request_bracket_point();
                 }
-                nit += 1;
-                if (nit < max_iter + 3) return request_bracket_point();
+                w[0] = br.s, w[1] = 1.0 - br.s, fun = br.fs;
+                return finish(nit);
             }
-            w[0] = s, w[1] = 1.0 - s, fun = fs;
-            return finish(nit);
+            return;
         }
         case P_FINAL: {
-            w[0] = s, w[1] = 1.0 - s, fun = funs[0];
-            return finish(nit);
+            if constexpr (M == 2) {
+                w[0] = br.s, w[1] = 1.0 - br.s, fun = funs[0];
+                return finish(nit);
+            }
+            return;
         }
         case P_CURV: {
             double HT[M][M], Q[M][M], q[M], w_new[M];

@@ -239,18 +239,21 @@ __global__ __launch_bounds__(64 * MO_RED_WAVES) void k_mo_reduce(const double* _
 
 // f(y) from the raw sums, on the device (zf_mo_prepare_async: no host round trip between the sums
 // of f(y), the Jacobian kernel that needs sum(y), and the dual search that needs f(y))
-__global__ void k_f_from_sums(int kind, double dn, const double* __restrict__ t, double* __restrict__ f_out) {
-    if (threadIdx.x || blockIdx.x) return;
+__host__ __device__ inline void mo_f_from_sums(int kind, double dn, const double* t, double* f_out) {
     if (kind == ZF_MO_JOS1) {
         const double n0 = sqrt(t[0]), n1 = sqrt(t[1]);
-        f_out[0] = n0 * n0 / dn;
+        f_out[0] = n0 * n0 / dn;   // np.linalg.norm(x) ** 2 / n
         f_out[1] = n1 * n1 / dn;
     } else {
         const double nx = sqrt(t[2]);
-        f_out[0] = t[0] / (dn * dn);
-        f_out[1] = exp(t[1] / dn) + nx * nx;
-        f_out[2] = t[3] / (dn * (dn + 1));
+        f_out[0] = t[0] / (dn * dn);                    // inner(idx, (x-idx)**4) / n**2
+        f_out[1] = exp(t[1] / dn) + nx * nx;            // exp(x.sum()/n) + norm(x)**2
+        f_out[2] = t[3] / (dn * (dn + 1));              // inner(conv, exp(-x)) / (n (n+1))
     }
+}
+__global__ void k_f_from_sums(int kind, double dn, const double* __restrict__ t, double* __restrict__ f_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    mo_f_from_sums(kind, dn, t, f_out);
 }
 
 // ---- the whole dual search of one trial in ONE persistent kernel (dual_solver="device") ---------
@@ -305,6 +308,17 @@ struct mo_solve_args {
     mo_u64* totals;       // [2][MAXB * NQ] records
     unsigned nonce;       // launch number: part of the records' key (stale records of earlier launches fail the check)
     mo_solve_result* out;
+    // fused outer iteration (zf_mo_set_fused): the kernel forms its own inputs first -
+    int prep_kind;        // ZF_MO_JOS1 / ZF_MO_FDS: f(y) and J = jac_f(y) are computed here (problems.py:193-205,
+                          // :312-328: what zf_mo_prepare_async enqueues as four launches); 0: they are given
+    int make_y;           // 1: y = x_k + beta (x_k - x_{k-1}) first (:534) - the commit of the previous
+    int nesterov;         //    accepted trial, deferred into this launch (zf_mo_commit); 0: y is given
+    double beta;
+    const double* xk;
+    const double* xo;
+    double* y_w;          // writable y, J (= y, J above) and f(y) on the device: everything formed here is also
+    double* J_w;          //   stored, so every other entry point finds the state zf_mo_prepare_async leaves
+    double* f_y_w;
 };
 
 template <int M>
@@ -451,8 +465,9 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
     return *lds_flag != 0;
 }
 
-// One step of the solver's state machine, by ONE lane: LDS -> registers -> advance -> LDS (constant
-// indices throughout: ~80 registers, no scratch, no dependent LDS round trips in the dense helpers).
+// One step of the solver's state machine, by the lanes of ONE wave on identical register copies:
+// LDS -> registers -> advance -> LDS (constant indices throughout: ~80 registers, no scratch, no
+// dependent LDS round trips in the dense helpers; the lanes differ only inside the simplex QP).
 // (A first version kept the resident elements in 64 registers per thread: together with this step
 // the kernel needed > 256 VGPRs and spilled; the elements now live in LDS.)
 template <int M>
@@ -486,6 +501,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
     __shared__ double s_mine[NB * NQ], s_tot[NB * NQ];
     __shared__ double s_fun[NB], s_jac[NB][M];
     __shared__ int s_flag;
+    __shared__ double s_fy[M];   // f(y): given (host value / zf_mo_prepare_async) or formed by the prologue below
     const int tid = threadIdx.x;
     const int64_t n = A.n;
     const int64_t stride = (int64_t)gridDim.x * MO_SOLVE_TPB;
@@ -494,11 +510,116 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
     // this workgroup's first ER rows of elements stay in LDS for the whole search; element (e, tid)
     // is j = j0 + e * stride and sits at [row e][tid] of every plane: conflict-free
     const int ER = A.resident_rows;
-    for (int e = 0; e < ER; ++e) {
-        const int64_t j = j0 + e * stride;
-        s_data[((int64_t)M * ER + e) * MO_SOLVE_TPB + tid] = j < n ? A.y[j] : 0.0;
+    unsigned epoch = 0;
+    int timed_out = 0;
+    const int64_t c_begin = clock64();
+    if (A.prep_kind == 0) {
+        for (int e = 0; e < ER; ++e) {
+            const int64_t j = j0 + e * stride;
+            s_data[((int64_t)M * ER + e) * MO_SOLVE_TPB + tid] = j < n ? A.y[j] : 0.0;
 #pragma unroll
-        for (int i = 0; i < M; ++i) s_data[((int64_t)i * ER + e) * MO_SOLVE_TPB + tid] = j < n ? A.J[(int64_t)i * n + j] : 0.0;
+            for (int i = 0; i < M; ++i) s_data[((int64_t)i * ER + e) * MO_SOLVE_TPB + tid] = j < n ? A.J[(int64_t)i * n + j] : 0.0;
+        }
+        if (tid < M) s_fy[tid] = A.f_y_dev ? A.f_y_dev[tid] : A.f_y[tid];
+    } else {
+        // Fused outer iteration: this launch forms its own inputs.  Pass 1 - y (the deferred commit of the
+        // previous accepted trial, k_commit's expression) and the raw sums of f(y) (k_jos1_sums /
+        // k_fds_sums' terms); one grid-wide hand-over; pass 2 - the rows of J = jac_f(y) (k_jos1_jac /
+        // k_fds_jac's expressions; FDS needs sum(y) first) straight into LDS.  y, J and f(y) are also
+        // stored, so the other entry points find what zf_mo_prepare_async + zf_mo_commit would have left.
+        const double dn = (double)n;
+        constexpr int NP = (M == 2) ? 2 : 4;
+        double ps[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) ps[q] = 0.0;
+        auto pass1 = [&](int64_t j) -> double {
+            double yj;
+            if (A.make_y) {
+                const double xv = A.xk[j];
+                yj = A.nesterov ? xv + A.beta * (xv - A.xo[j]) : xv;
+                A.y_w[j] = yj;
+            } else {
+                yj = A.y[j];
+            }
+            if constexpr (M == 2) {            // JOS1
+                const double t = yj - 2;
+                ps[0] += yj * yj;
+                ps[1] += t * t;
+            } else {                           // FDS (x unsharded here: global index = j)
+                const double idx = (double)(j + 1);
+                const double conv = (double)((j + 1) * (n - j));
+                const double t = yj - idx, t2 = t * t;
+                ps[0] += idx * (t2 * t2);
+                ps[1] += yj;
+                ps[2] += yj * yj;
+                ps[3] += conv * exp(-yj);
+            }
+            return yj;
+        };
+        for (int e = 0; e < ER; ++e) {
+            const int64_t j = j0 + e * stride;
+            s_data[((int64_t)M * ER + e) * MO_SOLVE_TPB + tid] = j < n ? pass1(j) : 0.0;
+        }
+        for (int64_t j = j0 + ER * stride; j < n; j += stride) (void)pass1(j);
+        {
+            const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const double v = zf_wave_sum(ps[q]);
+                if (lane == 0) s_red[wave * NP + q] = v;
+            }
+            __syncthreads();
+            if (tid < NP) {
+                double v = s_red[tid];
+#pragma unroll
+                for (int wv = 1; wv < MO_SOLVE_WAVES; ++wv) v += s_red[wv * NP + tid];
+                s_mine[tid] = v;
+            }
+            __syncthreads();
+        }
+        if (!mo_grid_combine<1>(s_mine, NP, -1, A.partials, A.totals, A.nonce, epoch, s_tot, &s_flag)) timed_out = 1;
+        epoch += 1;
+        if (tid == 0) {
+            double t4[4] = {0.0, 0.0, 0.0, 0.0}, fy[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < NP; ++q) t4[q] = s_tot[q];
+            mo_f_from_sums(M == 2 ? ZF_MO_JOS1 : ZF_MO_FDS, dn, t4, fy);
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                s_fy[i] = fy[i];
+                if (blockIdx.x == 0) A.f_y_w[i] = fy[i];
+            }
+        }
+        const double e_mean = (M == 2) ? 0.0 : exp(s_tot[1] / dn);
+        const double c1 = 4 / (dn * dn), den = dn * (dn + 1);
+        auto pass2 = [&](double yj, int64_t j, double (&Jc)[M]) {
+            if constexpr (M == 2) {
+                Jc[0] = 2 * yj / dn;
+                Jc[1] = 2 * (yj - 2) / dn;
+            } else {
+                const double idx = (double)(j + 1);
+                const double conv = (double)((j + 1) * (n - j));
+                const double t = yj - idx;
+                Jc[0] = c1 * idx * (t * t * t);
+                Jc[1] = e_mean / dn + 2 * yj;
+                Jc[M - 1] = -conv * exp(-yj) / den;
+            }
+#pragma unroll
+            for (int i = 0; i < M; ++i) A.J_w[(int64_t)i * n + j] = Jc[i];
+        };
+        for (int e = 0; e < ER; ++e) {
+            const int64_t j = j0 + e * stride;
+            double Jc[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) Jc[i] = 0.0;
+            if (j < n) pass2(s_data[((int64_t)M * ER + e) * MO_SOLVE_TPB + tid], j, Jc);
+#pragma unroll
+            for (int i = 0; i < M; ++i) s_data[((int64_t)i * ER + e) * MO_SOLVE_TPB + tid] = Jc[i];
+        }
+        for (int64_t j = j0 + ER * stride; j < n; j += stride) {   // (streamed part: read back from y, J below)
+            double Jc[M];
+            pass2(A.make_y ? A.y_w[j] : A.y[j], j, Jc);
+        }
     }
     if (tid == 0) {
         zf_dual::machine<M> mach;
@@ -507,12 +628,9 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
     }
     __syncthreads();
 
-    unsigned epoch = 0;
     int64_t evals = 0, batches = 0;
-    int timed_out = 0;
     int64_t c_eval = 0, c_comb = 0, c_step = 0;
-    const int64_t c_begin = clock64();
-    while (!s_mach.done()) {
+    while (!timed_out && !s_mach.done()) {
         const int64_t c0 = clock64();
         const int npts = s_mach.npts;
         if (tid < npts) {   // weights of point `tid` (proximal_gradient.py:164, problems.py:127)
@@ -618,7 +736,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             for (int i = 0; i < M; ++i) {
                 double jv = -g_p[i] - t[M + 2 + i];
                 if (!A.deprecated) {
-                    const double dF = A.F_old[i] - (A.f_y_dev ? A.f_y_dev[i] : A.f_y[i]);
+                    const double dF = A.F_old[i] - s_fy[i];
                     corr += s_w[tid][i] * dF;
                     jv += dF;
                 }
@@ -628,7 +746,9 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             s_fun[tid] = f;
         }
         __syncthreads();
-        if (tid == 0) mo_machine_step<M>(&s_mach, s_fun, s_jac);   // (inlined: see above)
+        // wave 0, all 64 lanes on identical copies of the state (same LDS words in, same words out):
+        // the support enumeration of the simplex QP runs lane-parallel (zf_dual::machine::simplex_qp)
+        if (tid < 64) mo_machine_step<M>(&s_mach, s_fun, s_jac);   // (inlined: see above)
         __syncthreads();
         c_step += clock64() - c2;
     }
@@ -732,7 +852,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
 #pragma unroll
         for (int q = 0; q < MO_MAX_M + 1; ++q) r.g_sums[q] = (q <= M && r.has_F) ? s_tot[5 + (q <= M ? q : 0)] : 0.0;
 #pragma unroll
-        for (int i = 0; i < MO_MAX_M; ++i) r.f_y[i] = (i < M) ? (A.f_y_dev ? A.f_y_dev[i < M ? i : 0] : A.f_y[i]) : 0.0;
+        for (int i = 0; i < MO_MAX_M; ++i) r.f_y[i] = (i < M) ? s_fy[i < M ? i : 0] : 0.0;
         r.nit = s_mach.nit;
         r.evals = evals;
         r.batches = batches;
@@ -779,7 +899,31 @@ struct zf_mo {
     int solve_grid = 0;
     double* f_y_dev = nullptr;                 // f(y) of zf_mo_prepare_async (device, MO_MAX_M)
     bool f_y_on_device = false;
+    // fused outer iteration (zf_mo_set_fused): zf_mo_commit and zf_mo_prepare_async only RECORD what is
+    // due; the next zf_mo_solve_dual_device forms y, f(y) and J inside its one kernel.  Every other
+    // entry point first brings the buffers up to date (mo_flush), so the deferral is invisible.
+    bool fused = false;
+    bool y_pending = false;      // y = x_k + beta (x_k - x_{k-1}) not formed yet
+    bool prep_pending = false;   // f(y), J not formed yet
+    double pend_beta = 0.0;
+    int pend_nesterov = 0;
 };
+
+static int mo_prepare_async_now(zf_mo* s);
+// pending work of the fused mode, done the unfused way (k_commit; the four launches of prepare_async)
+static int mo_flush(zf_mo* s) {
+    if (s->y_pending) {
+        s->y_pending = false;
+        hipLaunchKernelGGL(k_commit, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->xb[s->cur],
+                           s->xb[(s->cur + 2) % 3], s->pend_beta, s->pend_nesterov, s->n);
+        ZF_HIP(hipGetLastError());
+    }
+    if (s->prep_pending) {
+        s->prep_pending = false;
+        return mo_prepare_async_now(s);
+    }
+    return ZF_OK;
+}
 
 
 // launch KERNEL<m> for m = 2 .. MO_MAX_M
@@ -926,6 +1070,7 @@ extern "C" int zf_mo_destroy(zf_mo* s) {
 // x_k = x_{k-1} = y = x0   (proximal_gradient.py:463-465)
 extern "C" int zf_mo_set_x0(zf_mo* s, const double* x0_host) {
     ZF_REQUIRE(s && x0_host, "zf_mo_set_x0: null argument");
+    s->y_pending = s->prep_pending = false;
     s->cur = 0;
     const size_t bytes = sizeof(double) * s->n;
     ZF_HIP(hipMemcpyAsync(s->xb[0], x0_host, bytes, hipMemcpyHostToDevice, s->stream));
@@ -936,19 +1081,6 @@ extern "C" int zf_mo_set_x0(zf_mo* s, const double* x0_host) {
 }
 
 // f from the raw sums of k_jos1_sums / k_fds_sums (also produced by the tail of k_dual_solve)
-static void mo_f_from_sums(int kind, double dn, const double* t, double* f_out) {
-    if (kind == ZF_MO_JOS1) {
-        const double n0 = sqrt(t[0]), n1 = sqrt(t[1]);
-        f_out[0] = n0 * n0 / dn;   // np.linalg.norm(x) ** 2 / n
-        f_out[1] = n1 * n1 / dn;
-    } else {
-        const double nx = sqrt(t[2]);
-        f_out[0] = t[0] / (dn * dn);                    // inner(idx, (x-idx)**4) / n**2
-        f_out[1] = exp(t[1] / dn) + nx * nx;            // exp(x.sum()/n) + norm(x)**2
-        f_out[2] = t[3] / (dn * (dn + 1));              // inner(conv, exp(-x)) / (n (n+1))
-    }
-}
-
 static int mo_builtin_f(zf_mo* s, const double* x, double* f_out) {
     const double dn = (double)s->n_global;
     double t[4];
@@ -986,6 +1118,7 @@ static int mo_g_values(zf_mo* s, const double* x, double* g_out) {
 // f(x), g(x) at which = 0: x_k, 1: y, 2: x+ ; f_out may be NULL (generic kind: host callback)
 extern "C" int zf_mo_eval_F(zf_mo* s, int32_t which, double* f_out, double* g_out) {
     ZF_REQUIRE(s && g_out, "zf_mo_eval_F: null argument");
+    if (int rc = mo_flush(s)) return rc;
     const double* x = mo_which(s, which);
     ZF_REQUIRE(x, "zf_mo_eval_F: bad point selector");
     if (f_out) {
@@ -998,7 +1131,10 @@ extern "C" int zf_mo_eval_F(zf_mo* s, int32_t which, double* f_out, double* g_ou
 // J = jac_f(y), f_y = f(y) for the built-in problems
 extern "C" int zf_mo_prepare(zf_mo* s, double* f_y_out) {
     ZF_REQUIRE(s && f_y_out, "zf_mo_prepare: null argument");
-    int rc = mo_builtin_f(s, s->y, f_y_out);   // leaves the raw sums in s->totals (FDS needs sum x)
+    s->prep_pending = false;   // (formed right here)
+    int rc = mo_flush(s);
+    if (rc) return rc;
+    rc = mo_builtin_f(s, s->y, f_y_out);   // leaves the raw sums in s->totals (FDS needs sum x)
     if (rc) return rc;
     s->f_y_on_device = false;
     if (s->kind == ZF_MO_JOS1)
@@ -1019,6 +1155,28 @@ extern "C" int zf_mo_prepare_async(zf_mo* s) {
     ZF_REQUIRE(s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS, "zf_mo_prepare_async: f is a host callback for this kind");
     ZF_REQUIRE(!s->exchange, "zf_mo_prepare_async: x is sharded over ranks (use zf_mo_prepare)");
     if (!s->f_y_dev) ZF_HIP(hipMalloc(&s->f_y_dev, sizeof(double) * MO_MAX_M));
+    if (s->fused && s->m <= 3) {   // formed by the next zf_mo_solve_dual_device (or by mo_flush)
+        s->prep_pending = true;
+        s->f_y_on_device = true;
+        return ZF_OK;
+    }
+    if (int rc = mo_flush(s)) return rc;
+    return mo_prepare_async_now(s);
+}
+
+// Fused outer iteration on / off.  On: zf_mo_commit and zf_mo_prepare_async defer their work into the
+// next zf_mo_solve_dual_device, whose one kernel then forms y (:534), f(y) and J = jac_f(y) itself -
+// one launch and one read-back per trial instead of six launches.  Results of every entry point are
+// unchanged (deferred work is done the unfused way whenever something else needs it).
+extern "C" int zf_mo_set_fused(zf_mo* s, int32_t on) {
+    ZF_REQUIRE(s, "zf_mo_set_fused: null argument");
+    if (!on)
+        if (int rc = mo_flush(s)) return rc;
+    s->fused = on != 0;
+    return ZF_OK;
+}
+
+static int mo_prepare_async_now(zf_mo* s) {
     int nq = 2;
     if (s->kind == ZF_MO_JOS1) {
         hipLaunchKernelGGL(k_jos1_sums, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->n, s->partials);
@@ -1043,6 +1201,7 @@ extern "C" int zf_mo_prepare_async(zf_mo* s) {
 // was not attempted and the host continues)
 extern "C" int zf_mo_get_f_y(zf_mo* s, double* f_y_out) {
     ZF_REQUIRE(s && f_y_out && s->f_y_dev && s->f_y_on_device, "zf_mo_get_f_y: no zf_mo_prepare_async result");
+    if (int rc = mo_flush(s)) return rc;
     ZF_HIP(hipMemcpyAsync(s->h_totals, s->f_y_dev, sizeof(double) * s->m, hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
     memcpy(f_y_out, s->h_totals, sizeof(double) * s->m);
@@ -1052,6 +1211,8 @@ extern "C" int zf_mo_get_f_y(zf_mo* s, double* f_y_out) {
 // generic kind: J (m x n, row-major) computed by a host callback
 extern "C" int zf_mo_set_jac(zf_mo* s, const double* J_host) {
     ZF_REQUIRE(s && J_host, "zf_mo_set_jac: null argument");
+    s->prep_pending = false;
+    if (int rc = mo_flush(s)) return rc;
     ZF_HIP(hipMemcpyAsync(s->J, J_host, sizeof(double) * s->m * s->n, hipMemcpyHostToDevice, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
     return ZF_OK;
@@ -1060,6 +1221,7 @@ extern "C" int zf_mo_set_jac(zf_mo* s, const double* J_host) {
 // out: [0..m) g_i(p)  [m] |p-v|^2  [m+1] |w@J|^2  [m+2 .. 2m+2) J_i . (p - y)
 extern "C" int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double* out) {
     ZF_REQUIRE(s && w_host && out, "zf_mo_dual_eval: null argument");
+    if (int rc = mo_flush(s)) return rc;
     mo_w W;
     mo_fill_w(s, lr, w_host, &W);
     const int m = s->m;
@@ -1118,6 +1280,7 @@ extern "C" int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const do
                                 int64_t* nit_out, int32_t* ok_out, int64_t* evals_out) {
     ZF_REQUIRE(s && f_y && F_old && w_out && fun_out && nit_out && ok_out, "zf_mo_solve_dual: null argument");
     ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_solve_dual: lr must be > 0 and max_iter >= 1");
+    if (int rc = mo_flush(s)) return rc;
     mo_dual_ctx ctx = {s, lr, f_y, F_old, (int)deprecated};
     zf_dual::evaluator E = {mo_dual_fn, &ctx, 0};
     long nit = 0;
@@ -1150,6 +1313,11 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
     ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_solve_dual_device: lr must be > 0 and max_iter >= 1");
     *ok_out = 0;
     if (evals_out) *evals_out = 0;
+    // fused outer iteration: y (deferred commit), f(y) and J are formed by this launch itself
+    const bool fuse = s->fused && s->prep_pending && !f_y && !s->exchange && s->m <= 3 &&
+                      (s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS);
+    if (!fuse)
+        if (int rc = mo_flush(s)) return rc;
     if (s->exchange) return ZF_OK;   // x sharded over ranks: every evaluation needs an exchange (host loop)
     if (!s->solve_partials) {
         int dev = 0, cus = 0;
@@ -1190,6 +1358,18 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
     A.totals = s->solve_totals;
     A.nonce = ++s->solve_nonce;
     A.out = s->solve_out;
+    if (fuse) {
+        A.prep_kind = s->kind;
+        A.make_y = s->y_pending ? 1 : 0;
+        A.nesterov = s->pend_nesterov;
+        A.beta = s->pend_beta;
+        A.xk = s->xb[s->cur];
+        A.xo = s->xb[(s->cur + 2) % 3];
+        A.y_w = s->y;
+        A.J_w = s->J;
+        A.f_y_w = s->f_y_dev;
+        s->y_pending = s->prep_pending = false;   // (this launch leaves y, J and f(y) behind in their buffers)
+    }
     const dim3 grid(s->solve_grid), block(MO_SOLVE_TPB);
     // rows of MO_SOLVE_TPB elements a workgroup owns / can keep in LDS
     const int64_t per_wg = (s->n + (int64_t)s->solve_grid * MO_SOLVE_TPB - 1) / ((int64_t)s->solve_grid * MO_SOLVE_TPB);
@@ -1248,6 +1428,7 @@ extern "C" int zf_mo_solve_stats(zf_mo* s, int64_t out[6]) {
 // x+ = prox(lr w, y - lr w@J) ; *err_out = max|x+ - y|
 extern "C" int zf_mo_recover(zf_mo* s, double lr, const double* w_host, double* err_out) {
     ZF_REQUIRE(s && w_host && err_out, "zf_mo_recover: null argument");
+    if (int rc = mo_flush(s)) return rc;
     mo_w W;
     mo_fill_w(s, lr, w_host, &W);
     double* xn = s->xb[(s->cur + 1) % 3];
@@ -1259,6 +1440,14 @@ extern "C" int zf_mo_recover(zf_mo* s, double lr, const double* w_host, double* 
 // accept x+: x_{k-1} <- x_k <- x+ ; y = x_k + beta (x_k - x_{k-1})  (or y = x_k)   :530-538
 extern "C" int zf_mo_commit(zf_mo* s, double beta, int32_t nesterov) {
     ZF_REQUIRE(s, "zf_mo_commit: null argument");
+    if (int rc = mo_flush(s)) return rc;   // (a commit still pending belongs to the OLD x_k, x_{k-1})
+    if (s->fused) {
+        s->cur = (s->cur + 1) % 3;
+        s->y_pending = true;
+        s->pend_beta = beta;
+        s->pend_nesterov = (int)nesterov;
+        return ZF_OK;
+    }
     s->cur = (s->cur + 1) % 3;
     hipLaunchKernelGGL(k_commit, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->y, s->xb[s->cur],
                        s->xb[(s->cur + 2) % 3], beta, (int)nesterov, s->n);
@@ -1269,6 +1458,7 @@ extern "C" int zf_mo_commit(zf_mo* s, double beta, int32_t nesterov) {
 // which = 0: x_k, 1: y, 2: x+, 3: x_{k-1}
 extern "C" int zf_mo_get(zf_mo* s, int32_t which, double* host) {
     ZF_REQUIRE(s && host, "zf_mo_get: null argument");
+    if (int rc = mo_flush(s)) return rc;
     const double* x = mo_which(s, which);
     ZF_REQUIRE(x, "zf_mo_get: bad point selector");
     ZF_HIP(hipMemcpyAsync(host, x, sizeof(double) * s->n, hipMemcpyDeviceToHost, s->stream));
@@ -1278,6 +1468,7 @@ extern "C" int zf_mo_get(zf_mo* s, int32_t which, double* host) {
 
 extern "C" int zf_mo_get_jac(zf_mo* s, double* J_host) {
     ZF_REQUIRE(s && J_host, "zf_mo_get_jac: null argument");
+    if (int rc = mo_flush(s)) return rc;
     ZF_HIP(hipMemcpyAsync(J_host, s->J, sizeof(double) * s->m * s->n, hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
     return ZF_OK;
@@ -1286,6 +1477,7 @@ extern "C" int zf_mo_get_jac(zf_mo* s, double* J_host) {
 // upload a host point into slot which = 1 (y) or 2 (x+): used when a host callback produced it
 extern "C" int zf_mo_put(zf_mo* s, int32_t which, const double* host) {
     ZF_REQUIRE(s && host && (which == 1 || which == 2 || which == 0), "zf_mo_put: bad argument");
+    if (int rc = mo_flush(s)) return rc;
     ZF_HIP(hipMemcpyAsync(mo_which(s, which), host, sizeof(double) * s->n, hipMemcpyHostToDevice, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
     return ZF_OK;
@@ -1342,6 +1534,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_post_terms(const double* __restric
 
 extern "C" int zf_mo_post_terms(zf_mo* s, double lr, const double* w_host, const double* p_host, double* out) {
     ZF_REQUIRE(s && w_host && p_host && out, "zf_mo_post_terms: null argument");
+    if (int rc = mo_flush(s)) return rc;
     mo_w W;
     mo_fill_w(s, lr, w_host, &W);
     double* pd = s->xb[(s->cur + 1) % 3];

@@ -150,6 +150,11 @@ class MoEngine:
         """prepare() without the host round trip: f(y) stays on the device for solve_dual_device."""
         self._check(self.lib.zf_mo_prepare_async(self.h), "zf_mo_prepare_async")
 
+    def set_fused(self, on):
+        """Fused outer iteration (zf_mo_set_fused): commit() and prepare_async() are deferred into the
+        next solve_dual_device(), whose one kernel forms y, f(y) and J itself."""
+        self._check(self.lib.zf_mo_set_fused(self.h, int(bool(on))), "zf_mo_set_fused")
+
     def get_f_y(self):
         f_y = np.zeros(self.m)
         self._check(self.lib.zf_mo_get_f_y(self.h, C.c_void_p(_lib.ptr(f_y))), "zf_mo_get_f_y")
@@ -491,6 +496,9 @@ def solve_native(problem, x0, o):
     # dual_solver="device" on a built-in problem: f(y), J are enqueued without a host round trip and
     # f(y) comes back with the result of the trial's one kernel
     lazy_f_y = dual_solver == "device" and not host_f and eng.group is None and m <= 3
+    # ... and in the same kernel: the momentum update of the previous iteration, f(y) and J (one launch
+    # and one read-back per trial; zf_mo_set_fused)
+    eng.set_fused(lazy_f_y)
 
     def prepare():
         if lazy_f_y:
