@@ -72,7 +72,10 @@ struct machine {
     static_assert(M >= 2 && M <= MAXM, "2 <= m <= 8");
     enum { P_INIT, P_ENDS, P_BRACKET, P_FINAL, P_CURV, P_LS, P_REEVAL, P_DONE };
     static constexpr int N = M + 1;   // KKT systems of the simplex QP
-    static constexpr int NB = M > LS_BATCH ? M : LS_BATCH;   // largest batch: the M curvature probes
+    // largest batch: the start point together with its M curvature probes (m >= 3; the probes do not
+    // depend on the values at the start point, and on the device a batch costs one grid-wide hand-over
+    // whatever its size)
+    static constexpr int NB = M >= 3 ? M + 1 : LS_BATCH;
     // problem
     double tol;
     long max_iter;
@@ -310,18 +313,26 @@ struct machine {
     }
 
     // ---- requests ----------------------------------------------------------------------------
+    // OFF = 1: the probes follow the point w itself in the same batch (the start, P_INIT)
+    template <int OFF = 0>
     ZF_DHD_INLINE void request_curvature() {
         // curvature on the tangent space: (grad(w + h (e_i - w)) - grad(w)) / h = H (e_i - w)
 #pragma unroll
         for (int r = 0; r < M; ++r)
 #pragma unroll
             for (int i = 0; i < M; ++i) T[r][i] = (r == i ? 1.0 : 0.0) - w[r];   // column i = e_i - w
-        npts = M;
+        npts = M + OFF;
+        if constexpr (OFF == 1) {
 #pragma unroll
-        for (int i = 0; i < M; ++i)
+            for (int r = 0; r < M; ++r) pts[0][r] = w[r];
+        }
+        if constexpr (OFF + M <= NB) {
 #pragma unroll
-            for (int r = 0; r < M; ++r) pts[i][r] = w[r] + h * T[r][i];
-        phase = P_CURV;
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int r = 0; r < M; ++r) pts[OFF + i][r] = w[r] + h * T[r][i];
+        }
+        phase = OFF == 1 ? P_INIT : P_CURV;
     }
     ZF_DHD_INLINE void request_line_search(double t0) {
         t_base = t0;
@@ -362,6 +373,54 @@ struct machine {
         request_curvature();
     }
 
+    // The Newton model from the gradients at the M probes jacs[OFF .. OFF + M) (finite-difference
+    // curvature on the tangent space), the exact simplex QP, and the request for its line search.
+    template <int OFF>
+    ZF_DHD_INLINE void newton_step(const double (&jacs)[NB][M]) {
+        double HT[M][M], Q[M][M], q[M], w_new[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int r = 0; r < M; ++r) HT[r][i] = (jacs[(OFF + i) % NB][r] - grad[r]) / h;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double t = 0.0;
+#pragma unroll
+                for (int r = 0; r < M; ++r) t += T[r][i] * HT[r][j];
+                Q[i][j] = t;
+            }
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = i + 1; j < M; ++j) Q[i][j] = Q[j][i] = 0.5 * (Q[i][j] + Q[j][i]);
+        const double ev = min_eigenvalue(Q);
+        if (ev < 0.0)   // keep the model convex against finite-difference noise
+#pragma unroll
+            for (int i = 0; i < M; ++i) Q[i][i] += 1e-12 - ev;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) t += T[r][i] * grad[r];
+            q[i] = t;
+            w_new[i] = 0.0;
+        }
+        simplex_qp(q, Q, w_new);
+        step = 0.0, slope = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            d[i] = w_new[i] - w[i];
+            step = fabs(d[i]) > step ? fabs(d[i]) : step;
+            slope += grad[i] * d[i];
+        }
+        // stop at `tol` in w, or when the model predicts no decrease resolvable in double precision
+        if (step <= tol || slope >= -4e-16 * (fabs(fun) > 1.0 ? fabs(fun) : 1.0))
+            return finish(nit > max_iter ? max_iter : nit);
+        return request_line_search(1.0);
+    }
+
     // ---- the machine -----------------------------------------------------------------------------
     // w0 may be NULL (uniform start)
     ZF_DHD_INLINE void start(const double* w0, double tol_, long max_iter_) {
@@ -397,6 +456,7 @@ struct machine {
 #pragma unroll
         for (int i = 0; i < M; ++i) pts[0][i] = w[i];
         phase = P_INIT;
+        if constexpr (M >= 3) request_curvature<1>();   // the start point and its curvature probes together
     }
 
     // funs[k], jacs[k][0..M): the dual and its gradient at pts[k], k < npts
@@ -413,15 +473,16 @@ struct machine {
             fun = funs[0];
 #pragma unroll
             for (int i = 0; i < M; ++i) grad[i] = jacs[0][i];
-            if (M == 2) {   // both ends of the segment at once
+            if constexpr (M == 2) {   // both ends of the segment at once
                 npts = 2;
                 pts[0][0] = 0.0, pts[0][1] = 1.0;
                 pts[1][0] = 1.0, pts[1][1] = 0.0;
                 phase = P_ENDS;
                 return;
+            } else {
+                nit = 1;
+                return newton_step<1>(jacs);   // (m >= 3: the probes came with the start point)
             }
-            nit = 1;
-            return request_curvature();
         }
         case P_ENDS: {
             if constexpr (M == 2) {
@@ -480,50 +541,8 @@ struct machine {
             }
             return;
         }
-        case P_CURV: {
-            double HT[M][M], Q[M][M], q[M], w_new[M];
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int r = 0; r < M; ++r) HT[r][i] = (jacs[i][r] - grad[r]) / h;
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int r = 0; r < M; ++r) t += T[r][i] * HT[r][j];
-                    Q[i][j] = t;
-                }
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = i + 1; j < M; ++j) Q[i][j] = Q[j][i] = 0.5 * (Q[i][j] + Q[j][i]);
-            const double ev = min_eigenvalue(Q);
-            if (ev < 0.0)   // keep the model convex against finite-difference noise
-#pragma unroll
-                for (int i = 0; i < M; ++i) Q[i][i] += 1e-12 - ev;
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                double t = 0.0;
-#pragma unroll
-                for (int r = 0; r < M; ++r) t += T[r][i] * grad[r];
-                q[i] = t;
-                w_new[i] = 0.0;
-            }
-            simplex_qp(q, Q, w_new);
-            step = 0.0, slope = 0.0;
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-                d[i] = w_new[i] - w[i];
-                step = fabs(d[i]) > step ? fabs(d[i]) : step;
-                slope += grad[i] * d[i];
-            }
-            // stop at `tol` in w, or when the model predicts no decrease resolvable in double precision
-            if (step <= tol || slope >= -4e-16 * (fabs(fun) > 1.0 ? fabs(fun) : 1.0))
-                return finish(nit > max_iter ? max_iter : nit);
-            return request_line_search(1.0);
-        }
+        case P_CURV:
+            return newton_step<0>(jacs);
         case P_LS: {
             double t = t_base;
             bool picked = false;

@@ -13,6 +13,8 @@
 // prox (:129).  x, y, J stay resident in HBM between calls.
 #include <vector>
 
+#include <atomic>
+
 #include "zf_common.h"
 #include "zf_dual_native.h"
 
@@ -287,6 +289,9 @@ struct mo_solve_result {
     double f_sums[4], g_sums[MO_MAX_M + 1];
     int32_t has_F, reserved2;
     double f_y[MO_MAX_M];   // f(y) the search used (computed on the device after zf_mo_prepare_async)
+    // the record lives in pinned host memory and is written by the kernel itself; `seq` = the launch
+    // number, stored last behind a system-scope fence: the host waits for it instead of a copy + stream sync
+    unsigned long long seq;
 };
 
 struct mo_solve_args {
@@ -475,14 +480,9 @@ __device__ __forceinline__ void mo_machine_step(zf_dual::machine<M>* s_mach, con
                                                           const double (*s_jac)[M]) {
     constexpr int NB = zf_dual::machine<M>::NB;
     zf_dual::machine<M> mach = *s_mach;
-    double funs[NB], jacs[NB][M];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        funs[k] = s_fun[k];
-#pragma unroll
-        for (int i = 0; i < M; ++i) jacs[k][i] = s_jac[k][i];
-    }
-    mach.advance(funs, jacs);
+    // (the values of the batch are read where they are used, at constant indices, straight from LDS:
+    //  a register copy of all NB x (M + 1) of them beside the machine spilled)
+    mach.advance(*reinterpret_cast<const double(*)[NB]>(s_fun), *reinterpret_cast<const double(*)[NB][M]>(s_jac));
     *s_mach = mach;
 }
 
@@ -647,56 +647,68 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         }
         __syncthreads();
         {
-            // one pass over the workgroup's elements for ALL points of the batch: an element is read
-            // from LDS once; NB x NQ running sums per thread
-            double w[NB][M], coef[NB][M], tail[NB], acc[NB * NQ];
+            // the points of the batch in groups of GP: one pass over the workgroup's elements per group
+            // (an element is read from LDS once per group; GP x NQ running sums per thread - all NB points
+            // at once held 120 VGPRs of sums and weights, more than the kernel can spare), the sums of a
+            // group with ONE transposing butterfly per wave (zf_wave_reduce_multi: the pairing of a
+            // shuffle tree per quantity), then the wave totals in wave order
+            constexpr int GP = 2;
+            constexpr int NV = NB * NQ;
+            constexpr int GV = GP * NQ;
+            constexpr int H = (GV % 8 == 0) ? 3 : (GV % 4 == 0) ? 2 : (GV % 2 == 0) ? 1 : 0;
+            const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
+            for (int kb = 0; kb < NB; kb += GP) {
+                if (kb < npts) {
+                    double w[GP][M], coef[GP][M], tail[GP], acc[GV];
 #pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    w[k][i] = s_w[k][i];
-                    coef[k][i] = s_coef[k][i];
-                }
-                tail[k] = s_tail[k];
-            }
+                    for (int k = 0; k < GP; ++k) {
+                        const int kk = (kb + k < NB) ? kb + k : NB - 1;
 #pragma unroll
-            for (int q = 0; q < NB * NQ; ++q) acc[q] = 0.0;
-            auto element = [&](const double (&Jc)[M], double yj, int64_t j) {
+                        for (int i = 0; i < M; ++i) {
+                            w[k][i] = s_w[kk][i];
+                            coef[k][i] = s_coef[kk][i];
+                        }
+                        tail[k] = s_tail[kk];
+                    }
 #pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    if (k < npts) {
-                        double a8[NQ];
+                    for (int q = 0; q < GV; ++q) acc[q] = 0.0;
+                    auto element = [&](const double (&Jc)[M], double yj, int64_t j) {
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) a8[q] = acc[k * NQ + q];
-                        mo_dual_terms<M>(A.G, w[k], coef[k], tail[k], A.lr, Jc, yj, j, a8);
+                        for (int k = 0; k < GP; ++k) {
+                            if (kb + k < npts) {
+                                double a8[NQ];
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) acc[k * NQ + q] = a8[q];
+                                for (int q = 0; q < NQ; ++q) a8[q] = acc[k * NQ + q];
+                                mo_dual_terms<M>(A.G, w[k], coef[k], tail[k], A.lr, Jc, yj, j, a8);
+#pragma unroll
+                                for (int q = 0; q < NQ; ++q) acc[k * NQ + q] = a8[q];
+                            }
+                        }
+                    };
+                    for (int e = 0; e < ER; ++e) {
+                        const int64_t j = j0 + e * stride;
+                        if (j >= n) break;
+                        double Jc[M];
+#pragma unroll
+                        for (int i = 0; i < M; ++i) Jc[i] = s_data[((int64_t)i * ER + e) * MO_SOLVE_TPB + tid];
+                        element(Jc, s_data[((int64_t)M * ER + e) * MO_SOLVE_TPB + tid], j);
+                    }
+                    for (int64_t j = j0 + ER * stride; j < n; j += stride) {   // beyond the LDS-resident part
+                        double Jc[M];
+#pragma unroll
+                        for (int i = 0; i < M; ++i) Jc[i] = A.J[(int64_t)i * n + j];
+                        element(Jc, A.y[j], j);
+                    }
+                    zf_wave_reduce_multi<GV, H, false>(acc, lane);
+                    if ((lane & ((64 >> H) - 1)) == 0) {
+#pragma unroll
+                        for (int q = 0; q < (GV >> H); ++q) {
+                            const int idx = kb * NQ + zf_wave_reduce_multi_index<GV, H>(q, lane);
+                            if (idx < NV) s_red[wave * NV + idx] = acc[q];
+                        }
                     }
                 }
-            };
-            for (int e = 0; e < ER; ++e) {
-                const int64_t j = j0 + e * stride;
-                if (j >= n) break;
-                double Jc[M];
-#pragma unroll
-                for (int i = 0; i < M; ++i) Jc[i] = s_data[((int64_t)i * ER + e) * MO_SOLVE_TPB + tid];
-                element(Jc, s_data[((int64_t)M * ER + e) * MO_SOLVE_TPB + tid], j);
-            }
-            for (int64_t j = j0 + ER * stride; j < n; j += stride) {   // beyond the LDS-resident part
-                double Jc[M];
-#pragma unroll
-                for (int i = 0; i < M; ++i) Jc[i] = A.J[(int64_t)i * n + j];
-                element(Jc, A.y[j], j);
-            }
-            // all NB x NQ workgroup sums with ONE transposing butterfly per wave (zf_wave_reduce_multi:
-            // the pairing of a shuffle tree per quantity), then the wave totals in wave order
-            constexpr int NV = NB * NQ;
-            constexpr int H = (NV % 8 == 0) ? 3 : (NV % 4 == 0) ? 2 : (NV % 2 == 0) ? 1 : 0;
-            const int lane = tid & 63, wave = tid >> 6;
-            zf_wave_reduce_multi<NV, H, false>(acc, lane);
-            if ((lane & ((64 >> H) - 1)) == 0) {
-#pragma unroll
-                for (int q = 0; q < (NV >> H); ++q) s_red[wave * NV + zf_wave_reduce_multi_index<NV, H>(q, lane)] = acc[q];
             }
             __syncthreads();
             if (tid < NV) {
@@ -862,7 +874,10 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         r.cyc_eval = c_eval;
         r.cyc_combine = c_comb;
         r.cyc_step = c_step;
+        r.seq = 0;
         *A.out = r;
+        __threadfence_system();
+        __hip_atomic_store(&A.out->seq, (unsigned long long)A.nonce, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -897,6 +912,7 @@ struct zf_mo {
     mo_solve_result* solve_out = nullptr;      // device
     mo_solve_result* h_solve_out = nullptr;    // pinned host mirror
     int solve_grid = 0;
+    size_t solve_lds_set = (size_t)-1;         // dynamic LDS size last registered for k_dual_solve
     double* f_y_dev = nullptr;                 // f(y) of zf_mo_prepare_async (device, MO_MAX_M)
     bool f_y_on_device = false;
     // fused outer iteration (zf_mo_set_fused): zf_mo_commit and zf_mo_prepare_async only RECORD what is
@@ -1056,7 +1072,6 @@ extern "C" int zf_mo_destroy(zf_mo* s) {
     if (s->bounds_v) (void)hipFree(s->bounds_v);
     if (s->solve_partials) (void)hipFree(s->solve_partials);
     if (s->solve_totals) (void)hipFree(s->solve_totals);
-    if (s->solve_out) (void)hipFree(s->solve_out);
     if (s->f_y_dev) (void)hipFree(s->f_y_dev);
     if (s->h_solve_out) (void)hipHostFree(s->h_solve_out);
     (void)hipFree(s->buf);
@@ -1332,8 +1347,10 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
         ZF_HIP(hipMalloc(&s->solve_totals, 16 * 2 * zf_dual::MAXB * nq));
         ZF_HIP(hipMemsetAsync(s->solve_partials, 0, 16 * 2 * zf_dual::MAXB * nq * s->solve_grid, s->stream));
         ZF_HIP(hipMemsetAsync(s->solve_totals, 0, 16 * 2 * zf_dual::MAXB * nq, s->stream));
-        ZF_HIP(hipMalloc(&s->solve_out, sizeof(mo_solve_result)));
-        ZF_HIP(hipHostMalloc((void**)&s->h_solve_out, sizeof(mo_solve_result), hipHostMallocDefault));
+        // the result record: pinned host memory the kernel writes directly (fine-grained, device-visible)
+        ZF_HIP(hipHostMalloc((void**)&s->h_solve_out, sizeof(mo_solve_result), hipHostMallocMapped));
+        memset(s->h_solve_out, 0, sizeof(mo_solve_result));
+        ZF_HIP(hipHostGetDevicePointer((void**)&s->solve_out, s->h_solve_out, 0));
     }
     mo_solve_args A;
     memset(&A, 0, sizeof(A));
@@ -1376,20 +1393,40 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
     const int64_t cap = MO_SOLVE_LDS_BYTES / ((int64_t)(s->m + 1) * MO_SOLVE_TPB * sizeof(double));
     A.resident_rows = (int)(per_wg < cap ? per_wg : cap);
     const size_t lds = (size_t)A.resident_rows * (s->m + 1) * MO_SOLVE_TPB * sizeof(double);
+    const bool set_attr = s->solve_lds_set != lds;   // (a driver call of several microseconds: once, not per trial)
+    s->solve_lds_set = lds;
     switch (s->m) {
         case 2:
-            ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (set_attr) ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_dual_solve<2>, grid, block, lds, s->stream, A);
             break;
         case 3:
-            ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (set_attr) ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_dual_solve<3>, grid, block, lds, s->stream, A);
             break;
         default: return ZF_OK;   // larger m: host loop (register budget of the resident elements + machine)
     }
     ZF_HIP(hipGetLastError());
-    ZF_HIP(hipMemcpyAsync(s->h_solve_out, s->solve_out, sizeof(mo_solve_result), hipMemcpyDeviceToHost, s->stream));
-    ZF_HIP(hipStreamSynchronize(s->stream));
+    // wait for the record (the kernel stores `seq` last): no copy, no stream synchronisation.  Should the
+    // launch die without writing it, the stream goes idle: checked now and then, reported as an error.
+    {
+        volatile unsigned long long* seq = &s->h_solve_out->seq;
+        unsigned spins = 0;
+        while (*seq != (unsigned long long)A.nonce) {
+            if ((++spins & 0xFFFu) == 0) {
+                const hipError_t q = hipStreamQuery(s->stream);
+                if (q == hipSuccess) {
+                    if (*seq == (unsigned long long)A.nonce) break;
+                    return zf_fail(ZF_ERR_STATE, "zf_mo_solve_dual_device: the kernel ended without a result record%s");
+                }
+                if (q != hipErrorNotReady) return zf_fail(ZF_ERR_HIP, "zf_mo_solve_dual_device: %s", hipGetErrorString(q));
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     const mo_solve_result& r = *s->h_solve_out;
     if (evals_out) *evals_out = r.evals;
     if (f_y_out)

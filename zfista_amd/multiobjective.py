@@ -207,24 +207,29 @@ class MoEngine:
         (after prepare_async()).  Returns (weight, fun, nit, err, f_x, g_x, f_y)
         with x+ left in its buffer (f_x is None when f is a host callback), or None when it was not attempted (non-finite start, sharded x,
         m > 3): the caller continues with solve_dual() / the reference's calls and recover()."""
-        f_y = None if f_y is None else np.ascontiguousarray(f_y, dtype=np.float64)
-        F_old = np.ascontiguousarray(F_old, dtype=np.float64)
-        w0 = None if w0 is None else np.ascontiguousarray(w0, dtype=np.float64)
-        w, f_x, g_x, f_y_used = np.zeros(self.m), np.zeros(self.m), np.zeros(self.m), np.zeros(self.m)
-        fun, nit, ok, evals, err = C.c_double(0.0), C.c_int64(0), C.c_int32(0), C.c_int64(0), C.c_double(0.0)
-        rc = self.lib.zf_mo_solve_dual_device(self.h, float(lr), None if f_y is None else C.c_void_p(_lib.ptr(f_y)),
-                                              C.c_void_p(_lib.ptr(F_old)),
-                                              int(bool(deprecated)), None if w0 is None else C.c_void_p(_lib.ptr(w0)),
-                                              float(tol), int(max_iter), C.c_void_p(_lib.ptr(w)), C.byref(fun),
-                                              C.byref(nit), C.byref(ok), C.byref(evals), C.byref(err),
-                                              C.c_void_p(_lib.ptr(f_x)), C.c_void_p(_lib.ptr(g_x)),
-                                              C.c_void_p(_lib.ptr(f_y_used)))
+        # (once per trial on the solver's critical path: buffers and their ctypes pointers are kept)
+        st = self.__dict__.get("_solve_bufs")
+        if st is None:
+            arrs = [np.zeros(self.m) for _ in range(7)]   # f_y, F_old, w0, w, f_x, g_x, f_y_used
+            scal = (C.c_double(0.0), C.c_int64(0), C.c_int32(0), C.c_int64(0), C.c_double(0.0))
+            st = self._solve_bufs = (arrs, [C.c_void_p(_lib.ptr(a)) for a in arrs], scal, [C.byref(v) for v in scal])
+        (b_fy, b_Fold, b_w0, w, f_x, g_x, f_y_used), ptrs, (fun, nit, ok, evals, err), refs = st
+        if f_y is not None:
+            b_fy[:] = f_y
+        b_Fold[:] = F_old
+        if w0 is not None:
+            b_w0[:] = w0
+        rc = self.lib.zf_mo_solve_dual_device(self.h, float(lr), None if f_y is None else ptrs[0], ptrs[1],
+                                              int(bool(deprecated)), None if w0 is None else ptrs[2],
+                                              float(tol), int(max_iter), ptrs[3], refs[0], refs[1], refs[2], refs[3],
+                                              refs[4], ptrs[4], ptrs[5], ptrs[6])
         self.n_dual_evals += int(evals.value)
-        self._check(rc, "zf_mo_solve_dual_device")
+        if rc != _lib.ZF_OK:
+            self._check(rc, "zf_mo_solve_dual_device")
         if not ok.value:
             return None
-        return (w, np.float64(fun.value), int(nit.value), np.float64(err.value),
-                None if np.isnan(f_x[0]) else f_x, g_x, f_y_used)
+        return (w.copy(), np.float64(fun.value), int(nit.value), np.float64(err.value),
+                None if np.isnan(f_x[0]) else f_x.copy(), g_x.copy(), f_y_used.copy())
 
     def solve_stats(self):
         """Diagnostics of the last solve_dual_device(): batches, evaluations and the shader-clock
@@ -518,6 +523,7 @@ def solve_native(problem, x0, o):
     if o["return_all"]:
         allvecs, allfuns, allerrs = [x0], [f0 + g0], []
     t_state = None
+    betas = []
     status = _lib.ZF_MAXITER
     nit = 0
     for nit in range(1, o["max_iter"] + 1):
@@ -571,8 +577,10 @@ def solve_native(problem, x0, o):
             _print_row(nit, nit_int, err, fun, lr)
         beta = 0.0
         if o["nesterov"]:
-            b, t_state = momentum_factors(1, o["nesterov_ratio"], t_state)
-            beta = b[0]
+            if not betas:   # (the recursion in blocks: same NumPy scalar expressions, fewer Python calls)
+                b, t_state = momentum_factors(64, o["nesterov_ratio"], t_state)
+                betas = list(b[::-1])
+            beta = betas.pop()
         eng.commit(beta, o["nesterov"])     # x_{k-1} <- x_k <- x+ ; y_{k+1}
         F_old = F_new
         if o["return_all"]:
