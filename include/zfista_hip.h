@@ -288,6 +288,15 @@ int zf_dev_model_terms_async(const double* jac_dev, const double* x_dev, const d
                              double* out3_dev, void* stream);   /* no synchronisation; scalars stay on the device */
 int zf_dev_momentum(double* y_out_dev, const double* x_dev, const double* x_old_dev, double beta, int64_t n,
                     void* stream);
+/* Multi-objective trial with callbacks on device tensors (m >= 2): the solver's own expressions of
+ * _dual_minimized_fun_jac (:162-173) around the caller's prox_wsum_g and g.
+ *   zf_dev_mo_combine:    v = y - lr (w @ J) (:164), ss_dev[0] = |w @ J|^2 (:171); J m x n row-major, w on the host
+ *   zf_dev_mo_post_terms: out_dev[0..m) = J_i . (p - y) (:173), out_dev[m] = |p - v|^2 (:168)
+ * stream-ordered, nothing synchronised (the caller fetches the scalars with its own in one transfer) */
+int zf_dev_mo_combine(double* v_dev, const double* y_dev, const double* J_dev, const double* w_host, double lr,
+                      int32_t m, int64_t n, double* ss_dev, void* stream);
+int zf_dev_mo_post_terms(const double* J_dev, const double* y_dev, const double* p_dev, const double* v_dev,
+                         int32_t m, int64_t n, double* out_dev /* m + 1 */, void* stream);
 
 /* ---- operator evaluations at a host point ---------------------------------
  * The callback contract of proximal_gradient.py rows f / g / jac_f /

@@ -105,9 +105,6 @@ def test_tensor_callbacks_error_and_warning_shapes(capsys):
     assert "Backtracking failed" in capsys.readouterr().out
     assert res.success is False and res.message.startswith("Error: ") and res.nit == 0 and "status" not in res
     assert torch.equal(res.x, x0)
-    # two objectives are not supported on the tensor path
-    with pytest.raises(NotImplementedError):
-        minimize_proximal_gradient(lambda x: torch.stack([f(x), f(x)]), g, jac_f, prox, x0)
     with pytest.raises(TypeError):
         minimize_proximal_gradient(f, g, jac_f, prox, x0.float())
 
@@ -148,3 +145,145 @@ def test_operator_form_lasso_example_matches_numpy_callbacks():
     for a, e in zip(res.allvecs, exp.allvecs):
         assert rel_err(a.cpu().numpy(), e) <= 1e-10
     np.testing.assert_allclose(np.asarray(res.allfuns, float).ravel(), np.asarray(exp.allfuns, float).ravel(), rtol=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------------
+# m >= 2 on device tensors (an extension: the reference takes NumPy arrays only; the contract is its
+# m-agnostic one, proximal_gradient.py:143,:467 - f, g -> (m,), jac_f -> (m, n), weight = lr * w)
+# ---------------------------------------------------------------------------------------------------
+def _jos1_numpy(n, ratios, shifts):
+    """JOS1 with shifted-l1 terms as plain NumPy closures (zfista/problems.py:101-138,193-205)."""
+    def f(x):
+        return np.array([np.linalg.norm(x) ** 2 / n, np.linalg.norm(x - 2) ** 2 / n])
+
+    def g(x):
+        return np.array([r * np.linalg.norm(x - s, ord=1) for r, s in zip(ratios, shifts)])
+
+    def jac_f(x):
+        return np.vstack([2 * x / n, 2 * (x - 2) / n])
+
+    def st(v, t):
+        return np.sign(v) * np.maximum(np.abs(v) - t, 0)
+
+    def prox(weight, x):
+        coef = weight * ratios
+        x = st(x + coef[1:].sum() - shifts[0] + shifts[0], coef[0])
+        for c, s in zip(coef[1:], shifts[1:]):
+            x = st(x - c - s, c) + s
+        return x
+
+    return f, g, jac_f, prox
+
+
+def _jos1_torch(n, ratios, shifts):
+    import torch
+
+    rt = torch.tensor(ratios, dtype=torch.float64, device="cuda")
+
+    def f(x):
+        return torch.stack([torch.linalg.norm(x) ** 2 / n, torch.linalg.norm(x - 2) ** 2 / n])
+
+    def g(x):
+        return torch.stack([r * torch.sum(torch.abs(x - s)) for r, s in zip(ratios, shifts)])
+
+    def jac_f(x):
+        return torch.stack([2 * x / n, 2 * (x - 2) / n])
+
+    def st(v, t):
+        return torch.sign(v) * torch.clamp(torch.abs(v) - t, min=0)
+
+    def prox(weight, x):
+        assert weight.is_cuda and weight.shape == (2,)
+        coef = weight * rt
+        x = st(x + coef[1:].sum() - shifts[0] + shifts[0], coef[0])
+        for c, s in zip(coef[1:], shifts[1:]):
+            x = st(x - c - s, c) + s
+        return x
+
+    return f, g, jac_f, prox
+
+
+@pytest.mark.parametrize("nesterov", [False, True])
+def test_two_objectives_on_device_tensors_match_the_oracle(nesterov):
+    """JOS1 + shifted l1 (m = 2) written against device tensors: iterates, errors and function values
+    of every iteration against the oracle driven by the same problem in NumPy (SciPy's bounded Brent on
+    both sides, as the reference)."""
+    import torch
+
+    from oracle import cpu_ref
+    from zfista_amd import minimize_proximal_gradient
+
+    n = 2000
+    ratios, shifts = np.array([1 / n, 2 / n]), np.array([0.0, 1.0])
+    x0 = np.random.default_rng(4).uniform(-2, 4, n)
+    kw = dict(lr=1.0, nesterov=nesterov, tol=1e-6, max_iter=12, return_all=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize_proximal_gradient(*_jos1_torch(n, ratios, shifts), torch.from_numpy(x0).cuda(), **kw)
+        exp = cpu_ref.minimize_proximal_gradient(*_jos1_numpy(n, ratios, shifts), x0, **kw)
+    assert res.nit == exp.nit and res.status == exp.status and res.message == exp.message
+    assert torch.is_tensor(res.x) and res.x.is_cuda
+    # the reference's own reproducibility for m >= 2 (tests/golden/g10: SciPy's end point moves with
+    # the last bits of the dual values) bounds what "equal" can mean: 1e-7 on this problem
+    for a, e in zip(res.allvecs, exp.allvecs):
+        assert rel_err(a.cpu().numpy(), e) <= 1e-7
+    np.testing.assert_allclose(np.asarray(res.allfuns), np.asarray(exp.allfuns), rtol=1e-7)
+    np.testing.assert_allclose(np.asarray(res.allerrs), np.asarray(exp.allerrs), rtol=1e-5, atol=1e-9)
+    assert np.asarray(res.fun).shape == (2,)
+
+
+@pytest.mark.parametrize("m", [2, 3])
+@pytest.mark.parametrize("dual_solver", ["scipy", "native"])
+def test_stacked_toy_lasso_on_device_tensors(m, dual_solver):
+    """The reference's multi-objective toy test (tests/test_proximal_gradient.py:104-219: the LASSO toy
+    stacked m times; known answers to 3 decimals) with callbacks on device tensors."""
+    import torch
+
+    from zfista_amd import minimize_proximal_gradient
+
+    A = torch.tensor([[-1.0], [0.0], [1.0]], dtype=torch.float64, device="cuda")
+    b = torch.tensor([-1.0, 0.0, 1.0], dtype=torch.float64, device="cuda")
+    x0 = torch.tensor([0.3], dtype=torch.float64, device="cuda")
+    for l1_ratio, expected in [(1e-8, 1), (0.1, 0.85), (0.5, 0.25), (1, 0)]:
+        def f(x):
+            return torch.stack([torch.linalg.norm(A @ x - b) ** 2 / 6] * m)
+
+        def g(x, l1_ratio=l1_ratio):
+            return torch.stack([l1_ratio * torch.sum(torch.abs(x))] * m)
+
+        def jac_f(x):
+            return torch.stack([A.T @ (A @ x - b) / 3] * m)
+
+        def prox(weight, x, l1_ratio=l1_ratio):
+            return torch.sign(x) * torch.clamp(torch.abs(x) - l1_ratio * weight.sum(), min=0)
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = minimize_proximal_gradient(f, g, jac_f, prox, x0, dual_solver=dual_solver)
+            res_n = minimize_proximal_gradient(f, g, jac_f, prox, x0, nesterov=True, dual_solver=dual_solver)
+        np.testing.assert_array_almost_equal(res.x.cpu().numpy(), [expected], decimal=3)
+        np.testing.assert_array_almost_equal(res_n.x.cpu().numpy(), [expected], decimal=3)
+
+
+def test_multiobjective_tensor_vector_kernels_against_numpy():
+    """zf_dev_mo_combine / zf_dev_mo_post_terms (the solver's own expressions of :162-173) against NumPy,
+    m = 1 .. 8, sizes around the block and grid boundaries."""
+    import torch
+
+    from zfista_amd.proximal_gradient import _DevOps
+
+    ops = _DevOps()
+    rng = np.random.default_rng(9)
+    for m, n in [(1, 1), (2, 255), (3, 4097), (5, 100003), (8, 600001)]:
+        J, y, p, w = rng.standard_normal((m, n)), rng.standard_normal(n), rng.standard_normal(n), rng.random(m)
+        lr = 0.37
+        Jt, yt, pt = (torch.from_numpy(a).cuda() for a in (J, y, p))
+        v, ss = ops.mo_combine(yt, Jt, w, lr)
+        wJ = np.zeros(n)
+        for i in range(m):
+            wJ = wJ + w[i] * J[i]
+        assert np.array_equal(v.cpu().numpy(), y - lr * wJ)          # elementwise: bit for bit
+        np.testing.assert_allclose(ss.item(), np.sum(wJ * wJ), rtol=1e-12)
+        out = ops.mo_post_terms(Jt, yt, pt, v).cpu().numpy()
+        np.testing.assert_allclose(out[:m], J @ (p - y), rtol=1e-11, atol=1e-11 * np.abs(J).sum(axis=1).max())
+        np.testing.assert_allclose(out[m], np.sum((p - (y - lr * wJ)) ** 2), rtol=1e-12)

@@ -131,6 +131,8 @@ SIGNATURES = {
     "zf_dev_model_terms": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
     "zf_dev_model_terms_async": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
     "zf_dev_momentum": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64, _P]),
+    "zf_dev_mo_combine": (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int32, C.c_int64, _P, _P]),
+    "zf_dev_mo_post_terms": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, _P, _P]),
     "zf_eval_diag_l1": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64, _P, _P]),
     "zf_host_prox_l1_box": (C.c_int, [_P, _P, C.c_double, C.c_double, C.c_double, C.c_int64]),
     "zf_host_asum": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_double)]),

@@ -73,7 +73,7 @@ int zf_ws_reserve(int64_t n) {
         g_ws_all.push_back(g_ws_cur);
     }
     if (!g_ws.partials) {
-        ZF_HIP(hipMalloc(&g_ws.partials, sizeof(double) * 4 * ZF_MAX_GRID));
+        ZF_HIP(hipMalloc(&g_ws.partials, sizeof(double) * 12 * ZF_MAX_GRID));
         ZF_HIP(hipMalloc(&g_ws.out, sizeof(double) * 8));
     }
     if (n <= g_ws.cap) return ZF_OK;
@@ -141,10 +141,64 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_eval_diag(const double* __restrict
     if (threadIdx.x < 2) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
 }
 
+// ---- multi-objective trial with callbacks on device tensors (m >= 2) --------------------------------
+// the two vector expressions of _dual_minimized_fun_jac (proximal_gradient.py:162-173) that are the
+// solver's own; prox_wsum_g and g in between are the caller's
+constexpr int ZF_DEV_MO_MAX_M = 8;
+struct zf_dev_mo_w {
+    double w[ZF_DEV_MO_MAX_M];
+};
+// v = y - lr * (w @ J)   (:164, the prox argument);  partial [0] = |w @ J|^2   (:171)
+__global__ __launch_bounds__(ZF_BLOCK) void k_dev_mo_combine(double* __restrict__ v, const double* __restrict__ y,
+                                                             const double* __restrict__ J, zf_dev_mo_w W, double lr,
+                                                             int m, int64_t n, double* partials) {
+    __shared__ double lds[ZF_WAVES];
+    double ss = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        double wJ = 0.0;
+#pragma unroll
+        for (int i = 0; i < ZF_DEV_MO_MAX_M; ++i)
+            if (i < m) wJ += W.w[i] * J[(int64_t)i * n + j];
+        v[j] = y[j] - lr * wJ;
+        ss += wJ * wJ;
+    }
+    const double sums[1] = {ss};
+    const double maxs[1] = {0.0};
+    double out = 0.0;
+    zf_block_reduce<1, 0, ZF_WAVES>(sums, maxs, lds, out);
+    if (threadIdx.x == 0) partials[blockIdx.x] = out;
+}
+// partials [0 .. m) = J_i . (p - y)   (:173),  [m] = |p - v|^2   (:168)
+__global__ __launch_bounds__(ZF_BLOCK) void k_dev_mo_post(const double* __restrict__ J, const double* __restrict__ y,
+                                                          const double* __restrict__ p, const double* __restrict__ v,
+                                                          int m, int64_t n, double* partials) {
+    constexpr int NS = ZF_DEV_MO_MAX_M + 1;
+    __shared__ double lds[ZF_WAVES * NS];
+    double acc[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) acc[q] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        const double pj = p[j];
+        const double dy = pj - y[j], dv = pj - v[j];
+#pragma unroll
+        for (int i = 0; i < ZF_DEV_MO_MAX_M; ++i)
+            if (i < m) acc[i] += J[(int64_t)i * n + j] * dy;
+        acc[ZF_DEV_MO_MAX_M] += dv * dv;
+    }
+    const double maxs[1] = {0.0};
+    double out = 0.0;
+    zf_block_reduce<NS, 0, ZF_WAVES>(acc, maxs, lds, out);
+    // rows 0 .. m-1: the dots, row m: |p - v|^2 (compacted: the reduce kernel reads m + 1 rows)
+    if (threadIdx.x < m) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+    if (threadIdx.x == ZF_DEV_MO_MAX_M) partials[(int64_t)m * gridDim.x + blockIdx.x] = out;
+}
+
 // one-block fixed-order reduce of `nq` quantities; quantity max_index is a max
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partials, int nblocks, int nq,
                                                          int max_index, double* out) {
-    __shared__ double lds[4 * 8];
+    __shared__ double lds[4 * 12];   // (nq <= 12)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = 0; k < nq; ++k) {
         const bool is_max = (k == max_index);
@@ -154,13 +208,13 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
             v = is_max ? fmax(v, p) : v + p;
         }
         v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
-        if (lane == 0) lds[wave * 8 + k] = v;
+        if (lane == 0) lds[wave * 12 + k] = v;
     }
     __syncthreads();
     if (threadIdx.x < nq) {
         const int k = threadIdx.x;
         double v = lds[k];
-        for (int w = 1; w < 4; ++w) v = (k == max_index) ? fmax(v, lds[w * 8 + k]) : v + lds[w * 8 + k];
+        for (int w = 1; w < 4; ++w) v = (k == max_index) ? fmax(v, lds[w * 12 + k]) : v + lds[w * 12 + k];
         out[k] = v;
     }
 }
@@ -272,6 +326,41 @@ extern "C" int zf_dev_momentum(double* y_out_dev, const double* x_dev, const dou
     if (n == 0) return ZF_OK;
     hipLaunchKernelGGL(k_momentum, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, (hipStream_t)stream, y_out_dev, x_dev,
                        x_old_dev, beta, n);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+// Multi-objective trial on device tensors (m >= 2): v = y - lr (w @ J) and |w @ J|^2 (ss_dev[0]); J is m x n
+// row-major on the device, w comes from the host (m doubles).  Stream-ordered, nothing synchronised.
+extern "C" int zf_dev_mo_combine(double* v_dev, const double* y_dev, const double* J_dev, const double* w_host,
+                                 double lr, int32_t m, int64_t n, double* ss_dev, void* stream) {
+    ZF_REQUIRE(v_dev && y_dev && J_dev && w_host && ss_dev && n >= 1, "zf_dev_mo_combine: bad argument");
+    ZF_REQUIRE(m >= 1 && m <= ZF_DEV_MO_MAX_M, "zf_dev_mo_combine: 1 <= m <= 8");
+    int rc = zf_ws_reserve(1);
+    if (rc) return rc;
+    zf_dev_mo_w W;
+    for (int i = 0; i < ZF_DEV_MO_MAX_M; ++i) W.w[i] = i < m ? w_host[i] : 0.0;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = zf_grid_for(n);
+    hipLaunchKernelGGL(k_dev_mo_combine, dim3(g), dim3(ZF_BLOCK), 0, st, v_dev, y_dev, J_dev, W, lr, (int)m, n,
+                       g_ws.partials);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, g_ws.partials, g, 1, -1, ss_dev);
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
+// out_dev[0 .. m) = J_i . (p - y), out_dev[m] = |p - v|^2 after the caller's prox produced p from v
+extern "C" int zf_dev_mo_post_terms(const double* J_dev, const double* y_dev, const double* p_dev,
+                                    const double* v_dev, int32_t m, int64_t n, double* out_dev, void* stream) {
+    ZF_REQUIRE(J_dev && y_dev && p_dev && v_dev && out_dev && n >= 1, "zf_dev_mo_post_terms: bad argument");
+    ZF_REQUIRE(m >= 1 && m <= ZF_DEV_MO_MAX_M, "zf_dev_mo_post_terms: 1 <= m <= 8");
+    int rc = zf_ws_reserve(1);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = zf_grid_for(n);
+    hipLaunchKernelGGL(k_dev_mo_post, dim3(g), dim3(ZF_BLOCK), 0, st, J_dev, y_dev, p_dev, v_dev, (int)m, n,
+                       g_ws.partials);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, g_ws.partials, g, (int)m + 1, -1, out_dev);
     ZF_HIP(hipGetLastError());
     return ZF_OK;
 }

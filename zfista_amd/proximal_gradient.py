@@ -470,6 +470,35 @@ class _DevOps:
                                             C.c_void_p(x_old.data_ptr()), float(beta), x.numel(), self._stream()))
         return out
 
+    # -- m >= 2 (:162-173): the two vector expressions around the caller's prox and g --------------
+    def _jac(self, J, n):
+        if J.dtype != self.torch.float64 or not J.is_cuda or J.dim() != 2 or J.shape[1] != n:
+            raise TypeError(f"jac_f must return a float64 CUDA tensor of shape (m, {n})")
+        return J.contiguous()
+
+    def mo_combine(self, y, J, w, lr):
+        """v = y - lr (w @ J) and |w @ J|^2 (a 1-element device tensor); w is a host array."""
+        y = self._v(y)
+        J = self._jac(J, y.numel())
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        v = self.torch.empty_like(y)
+        ss = self.torch.empty(1, dtype=self.torch.float64, device=y.device)
+        _lib.check(self.lib.zf_dev_mo_combine(C.c_void_p(v.data_ptr()), C.c_void_p(y.data_ptr()),
+                                              C.c_void_p(J.data_ptr()), C.c_void_p(_lib.ptr(w)), float(lr),
+                                              int(J.shape[0]), y.numel(), C.c_void_p(ss.data_ptr()), self._stream()))
+        return v, ss
+
+    def mo_post_terms(self, J, y, p, v):
+        """(J_i . (p - y))_i and |p - v|^2 as one (m + 1)-element device tensor."""
+        y, p, v = self._v(y), self._v(p), self._v(v)
+        J = self._jac(J, y.numel())
+        m = int(J.shape[0])
+        out = self.torch.empty(m + 1, dtype=self.torch.float64, device=y.device)
+        _lib.check(self.lib.zf_dev_mo_post_terms(C.c_void_p(J.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                 C.c_void_p(p.data_ptr()), C.c_void_p(v.data_ptr()), m, y.numel(),
+                                                 C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
 
 def _scalar(v):
     """A callback's objective value as a NumPy float (0-dim / 1-element tensors allowed)."""
@@ -480,8 +509,129 @@ def _scalar(v):
     return np.float64(v)
 
 
+def _values(v, m):
+    """A callback's (m,) objective values as a host array (device tensors, NumPy arrays and lists allowed)."""
+    if hasattr(v, "detach"):
+        v = v.detach().reshape(-1).cpu().numpy()
+    v = np.asarray(v, dtype=np.float64).reshape(-1)
+    if v.size != m:
+        raise ValueError(f"expected {m} objective values, got {v.size}")
+    return v
+
+
+def _solve_tensor_multi(f, g, jac_f, prox, x0, o, f0, m):
+    """The loop of proximal_gradient.py:463-554 with the m >= 2 trial (:161-209) for callbacks on device
+    tensors: f, g return (m,) tensors, jac_f an (m, n) tensor, prox_wsum_g(weight, x) receives the weight
+    lr * w as an (m,) device tensor.  Iterates, J and every O(n) expression stay in HBM; the solver's own
+    vector expressions (v = y - lr w@J, |w@J|^2, J(p - y), |p - v|^2, max|x+ - y|) are HIP kernels
+    (zf_dev_mo_*), the m-dimensional dual search runs on the host exactly as for NumPy callbacks
+    (``dual_solver=``), and one transfer of 2m + 2 scalars per dual evaluation crosses PCIe.
+    f(y), jac_f(y) are evaluated once per line search and F(x_k) is carried over from its acceptance
+    (the reference re-evaluates them per trial, :140-142, :279: the same numbers for deterministic callbacks)."""
+    import torch
+
+    from . import multiobjective
+
+    ops = _DevOps()
+    t0 = time.time()
+    res = OptimizeResult(x0=x0, tol=o["tol"], tol_internal=o["tol_internal"],
+                         nesterov=o["nesterov"], nesterov_ratio=o["nesterov_ratio"])
+    if o["verbose"]:
+        _print_header()
+    x_old = x_cur = y = x0
+    f_old = _values(f0, m)
+    F_old = f_old + _values(g(x0), m)
+    w0 = np.ones(m) / m
+    lr = o["lr"]
+    solver = o.get("dual_solver", "scipy")
+    if solver == "device":
+        solver = "native"   # (the persistent-kernel search needs the library's own prox: built-in problems)
+    allvecs = allfuns = allerrs = None
+    if o["return_all"]:
+        allvecs, allfuns, allerrs = [x0], [F_old], []
+    t_state = None
+    status = _lib.ZF_MAXITER
+    nit = 0
+    for nit in range(1, o["max_iter"] + 1):
+        try:
+            f_y = f_old if y is x_old else _values(f(y), m)   # :140
+            J = jac_f(y)                                       # :142
+            accepted = False
+            for _ in range(o["max_backtrack_iter"]):
+                def dual(w, lr=lr, f_y=f_y, J=J):              # _dual_minimized_fun_jac, :162-177
+                    v, ss_wJ = ops.mo_combine(y, J, w, lr)
+                    p = prox(torch.as_tensor(lr * w, dtype=torch.float64, device=x0.device), v)   # :164
+                    g_p = g(p)                                                                     # :165
+                    post = ops.mo_post_terms(J, y, p, v)
+                    if _is_device_tensor(g_p):
+                        host = torch.cat([ss_wJ, post, g_p.reshape(-1).to(torch.float64)]).cpu().numpy()
+                        g_pv = host[m + 2:]
+                    else:
+                        host = torch.cat([ss_wJ, post]).cpu().numpy()
+                        g_pv = _values(g_p, m)
+                    ss_w, dots, ss_pv = np.float64(host[0]), host[1:m + 1], np.float64(host[m + 1])
+                    fun = -np.inner(w, g_pv) - np.sqrt(ss_pv) ** 2 / 2 / lr + lr / 2 * np.sqrt(ss_w) ** 2
+                    jac = -g_pv - dots
+                    if not o["deprecated"]:
+                        fun += np.inner(w, F_old - f_y)
+                        jac = jac + (F_old - f_y)
+                    return fun, jac
+
+                weight, dual_fun, nit_int = multiobjective.solve_dual(dual, m, w0, o["tol_internal"],
+                                                                      o["max_iter_internal"], solver)
+                v, _ = ops.mo_combine(y, J, weight, lr)
+                x_cur = prox(torch.as_tensor(lr * weight, dtype=torch.float64, device=x0.device), v)   # :206
+                fun = -dual_fun                                                                          # :207
+                err = np.float64(ops.model_terms_dev(v, x_cur, y).cpu().numpy()[2])                      # :510
+                f_new, g_new = _values(f(x_cur), m), _values(g(x_cur), m)
+                F_new = f_new + g_new                                                                    # :295
+                if o["warm_start"]:
+                    w0 = weight
+                if o["decay_rate"] == 1:
+                    accepted = True
+                elif o["deprecated"]:
+                    accepted = bool(np.all(f_new - f_y <= fun + o["tol_internal"]))
+                else:
+                    accepted = bool(np.all(F_new - F_old <= fun + o["tol_internal"]))
+                if accepted:
+                    break
+                lr *= o["decay_rate"]
+            if not accepted:
+                raise RuntimeError(_MSG_BACKTRACK)
+        except Exception as exc:   # :493-509
+            print(f"An error occurred: {exc}")
+            bad = OptimizeResult()
+            bad.update(success=False, message=f"Error: {str(exc)}", x=x_old, fun=F_old,
+                       nit=nit - 1, time=time.time() - t0,
+                       allvecs=allvecs, allfuns=allfuns, allerrs=allerrs)
+            return bad, _lib.ZF_BACKTRACK_FAILED
+        if o["verbose"]:
+            _print_row(nit, nit_int, err, fun, lr)
+        if o["return_all"]:
+            allvecs.append(x_cur)
+            allfuns.append(F_new)
+            allerrs.append(err)
+        F_old, f_old = F_new, f_new
+        if err < o["tol"]:   # :525
+            res.status, res.message, res.success = 1, _MSG_OK, True
+            status = _lib.ZF_CONVERGED
+            break
+        if o["nesterov"]:
+            beta, t_state = momentum_factors(1, o["nesterov_ratio"], t_state)
+            y = ops.momentum(x_cur, x_old, beta[0])
+        else:
+            y = x_cur
+        x_old = x_cur
+    if status == _lib.ZF_MAXITER:
+        res.status, res.message, res.success = 0, _MSG_MAXITER, False
+    res.update(x=x_cur, fun=F_old, nit=nit, allvecs=allvecs, allfuns=allfuns, allerrs=allerrs,
+               time=time.time() - t0)
+    return res, status
+
+
 def _solve_tensor(f, g, jac_f, prox, x0, o):
-    """The loop of proximal_gradient.py:463-554 for callbacks on device tensors (m = 1).
+    """The loop of proximal_gradient.py:463-554 for callbacks on device tensors (m = 1; m >= 2:
+    _solve_tensor_multi).
 
     Call structure: f(y) and jac_f(y) are evaluated once per line search (y is fixed while lr
     shrinks) and F(x_k) is the value obtained when x_k was accepted - the reference re-evaluates
@@ -497,7 +647,11 @@ def _solve_tensor(f, g, jac_f, prox, x0, o):
     if o["verbose"]:
         _print_header()
     x_old = x_cur = y = x0
-    f_old = _scalar(f(x0))
+    f0 = f(x0)
+    m = int(f0.numel()) if hasattr(f0, "numel") else (f0.shape[0] if isinstance(f0, np.ndarray) else 1)   # :143,:467
+    if m > 1:
+        return _solve_tensor_multi(f, g, jac_f, prox, x0, o, f0, m)
+    f_old = _scalar(f0)
     F_old = f_old + _scalar(g(x0))
     lr = o["lr"]
     allvecs = allfuns = allerrs = None
