@@ -116,7 +116,7 @@ constexpr int ZF_TILE_U = 4;
 #define ZF_S8_UB 2   // units per load batch of the 8-trial chain: half a tile, software-pipelined (4 = whole tile, no pipeline)
 #endif
 constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per tile
-constexpr int ZF_MAX_TILES_PER_WG = 8;                // upper bound of zf_step_args.tiles_per_wg
+constexpr int ZF_MAX_TILES_PER_WG = 24;               // upper bound of zf_step_args.tiles_per_wg
 constexpr int ZF_FIN_WGS = 48;                        // workgroups of the finalize kernel
 constexpr int ZF_FIN_THREADS = 256;
 

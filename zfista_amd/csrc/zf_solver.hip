@@ -979,17 +979,43 @@ static void zf_set_tiles(zf_solver* s, int tiles) {
 // Launch geometry of the trial kernel: T interleaved tiles per workgroup.  T decides which
 // elements a thread accumulates, hence the rounding of the six sums and, at a knife edge, an
 // accept / reject decision - so it is a FUNCTION OF n ONLY (never of a timing measurement, the
-// chain length or the device): the same problem takes the same decisions in every process, on
-// every rank layout with equal shard sizes, for every S and after every restore.  T = 8 amortises
-// the per-workgroup reduction of long chains once the grid still fills the chip (>= 4096 tiles =
-// 64 MiB per stream); below that the launch is latency-bound and T = 1.  (Round 1 picked T by
-// timing; tools/tune_trial.hip keeps that experiment.)  ZF_TILES_PER_WG=<n> overrides it for
-// experiments and changes the rounding of the sums with it.
+// chain length or the device found at run time): the same problem takes the same decisions in every
+// process, on every rank layout with equal shard sizes, for every S and after every restore.
+// Below 4096 tiles (64 MiB per stream) the launch is latency-bound: T = 1.  From there T = 8 amortises
+// the per-workgroup reduction of long chains (6 S wave reductions, ~5 % of a 16-chain workgroup's
+// instructions at T = 8).  From 16384 tiles on (n >= 3.4e7) the grid is many rounds deep and T follows
+// the rounds: the chained kernels keep two workgroups per CU resident - 512 on the 256 CUs of an
+// MI355X - and a workgroup costs its T tiles plus ~0.3 of a tile for its start and epilogue, so a pass
+// takes  rounds(T) x (T + 0.3)  tile times with rounds = ceil(ceil(tiles / T) / 512); T is the smallest
+// minimiser in 8 .. 24 (n = 1e8: 4 rounds of 24 tiles instead of 12 of 8: 1.285 -> 1.26 ms per 16-chain
+// pass; the sweep T = 2 .. 96 is in DESIGN.md 4.1).  Whole rounds were also tried for n = 1e7 (489
+// workgroups of 10 tiles instead of 611 of 8): no faster - that size is bound by launch, start and
+// epilogue, not by the second round - so the smaller sizes keep the geometry they were measured with.
+// (Round 1 picked T by timing; tools/tune_trial.hip keeps that experiment.)  ZF_TILES_PER_WG=<n>
+// overrides it for experiments and changes the rounding of the sums with it.
+static int zf_tiles_for(int64_t ntiles) {
+    if (ntiles < 4096) return 1;
+    if (ntiles < 16384) return 8;
+    constexpr int64_t SLOTS = 512;
+    int best_t = 8;
+    double best_cost = 0.0;
+    for (int t = 8; t <= ZF_MAX_TILES_PER_WG; ++t) {
+        const int64_t wgs = (ntiles + t - 1) / t;
+        const int64_t rounds = (wgs + SLOTS - 1) / SLOTS;
+        const double cost = (double)rounds * ((double)t + 0.3);
+        if (t == 8 || cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best_t = t;
+        }
+    }
+    return best_t;
+}
+
 extern "C" int zf_solver_autotune(zf_solver* s, int32_t* chosen_tiles) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_autotune: solver not initialised");
     const char* env = getenv("ZF_TILES_PER_WG");
     if (env) zf_set_tiles(s, atoi(env));
-    else if (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->ntiles >= 4096) zf_set_tiles(s, ZF_MAX_TILES_PER_WG);
+    else if (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1) zf_set_tiles(s, zf_tiles_for(s->ntiles));
     else zf_set_tiles(s, 1);
     if (chosen_tiles) *chosen_tiles = s->tiles;
     return ZF_OK;
