@@ -210,6 +210,7 @@ def main():
     run = NativeRun(prob, x0, opts, timing=timing)
     S = run.sub_iters
     blocks, full_ms, full_n, part_ms, part_n, passes = [], 0.0, 0, 0.0, 0, 0
+    part_fresh = part_lag = 0
     timed = 0.0
     while True:
         while W > 0 and run.status == _lib.ZF_RUNNING:   # warm-up: exactly W iterations, then MAXITER
@@ -230,8 +231,9 @@ def main():
         assert run.status == _lib.ZF_MAXITER and run.nit_seen - nit0 == K, \
             f"expected {K} accepted iterations, got {run.nit_seen - nit0} (status {run.status})"
         if timing:
-            (fm, fn), (pm, pn) = run.solver.pass_stats()
+            (fm, fn), (pm, pn), (pf, pl) = run.solver.pass_stats_ex()
             full_ms, full_n, part_ms, part_n = full_ms + fm * fn, full_n + fn, part_ms + pm * pn, part_n + pn
+            part_fresh, part_lag = part_fresh + pf, part_lag + pl
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,8 +289,13 @@ def main():
             },
         }
         if timing and (full_n or part_n):
-            # the dominant kernel on full-chain passes (every pass when S = 1)
-            ker_ms = full_ms / full_n if full_n else part_ms / part_n
+            # the dominant kernel: the full-chain passes (every pass when S = 1) when they hold most of the
+            # kernel time, else the other passes - K < 2 S iterations are shared by two passes of about K / 2
+            # trials each (zf_fresh_len) and no full chain runs at all
+            on_full = full_n > 0 and full_ms >= part_ms
+            ker_ms = full_ms / full_n if on_full else part_ms / part_n
+            trials = float(S) if on_full else part_fresh / part_n      # fresh trials per pass
+            replays = 0.0 if on_full else part_lag / part_n             # replayed iterations per pass
             pass_bytes = (PASS_BYTES_PER_ELEM if S > 1 else ALG_BYTES_PER_ELEM) * n
             traffic = measured_traffic(n, S)
             achieved = pass_bytes / (ker_ms * 1e-3) / 1e9
@@ -296,8 +303,10 @@ def main():
             vpe = valu_per_element_trial(S)
             valu_ms = valu_frac = None
             clk = measured_clock_ghz(n, S)
+            # a replayed iteration is the iterate arithmetic alone: 11 fp64 operations + the sign copy
+            inst_per_elem = None if not vpe else vpe * trials + 12.0 * replays
             if vpe:
-                valu_ms = vpe * n * S / (FP64_LANES_PER_CYCLE * CLOCK_GHZ * 1e9) * 1e3
+                valu_ms = inst_per_elem * n / (FP64_LANES_PER_CYCLE * CLOCK_GHZ * 1e9) * 1e3
                 valu_frac = valu_ms / ker_ms
             bound = "hbm" if valu_frac is None or hbm_frac >= valu_frac else "fp64_valu"
             hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
@@ -305,7 +314,7 @@ def main():
                    "bytes_note": "HBM bytes a full-chain pass moves: 4 streams read + 2 iterates written = 48 B per "
                                  "element (S > 1), 40 B for S = 1"}
             valu = None if vpe is None else {
-                "achieved": vpe * n * S / (ker_ms * 1e-3) / 1e12,
+                "achieved": inst_per_elem * n / (ker_ms * 1e-3) / 1e12,
                 "peak": FP64_LANES_PER_CYCLE * CLOCK_GHZ * 1e9 / 1e12,
                 "unit": "T lane-instructions/s",
                 "frac": valu_frac,
@@ -330,14 +339,19 @@ def main():
                 "traffic": traffic,
                 "traffic_source": f"profiles/{PMC_PROFILE.format(S=S)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                   "passes, bytes per full-chain launch)" if traffic else None,
-                "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (full-chain passes)",
+                "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (full-chain passes)" if on_full else
+                          f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (general body: passes of {trials:.1f} fresh "
+                          f"trials + {replays:.1f} replayed iterations on average; no full chain dominates K = {K})",
                 "kernel_avg_ms": ker_ms,
-                "kernel_launches_timed": full_n if full_n else part_n,
+                "kernel_launches_timed": full_n if on_full else part_n,
+                "trials_per_pass": trials,
+                "replayed_iterations_per_pass": replays,
                 "hbm": hbm,
                 "fp64_valu": valu,
                 "other_passes_avg_ms": part_ms / part_n if part_n else None,
-                "equivalent_one_iteration_GBps": ALG_BYTES_PER_ELEM * n * S / (ker_ms * 1e-3) / 1e9,
-                "equivalent_note": "40 B x n x S (SURVEY 8d's per-iteration bytes x iterations per pass) / duration: "
+                "full_chain_passes_avg_ms": full_ms / full_n if full_n else None,
+                "equivalent_one_iteration_GBps": ALG_BYTES_PER_ELEM * n * trials / (ker_ms * 1e-3) / 1e9,
+                "equivalent_note": "40 B x n x trials per pass (SURVEY 8d's per-iteration bytes x iterations per pass) / duration: "
                                    "not a bandwidth - the chain does not move those bytes",
             }
         if world == 1 and not args.no_cpu_baseline:

@@ -266,6 +266,8 @@ int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches);
  * ms and count of full chains (sub_iters fresh trials, nothing replayed); out[2], out[3] = every other
  * pass (shorter chains, replays, materialise-only).  Resets the window. */
 int zf_solver_pass_stats(zf_solver* s, double out4[4]);
+/* the same window plus out[4] = fresh trials and out[5] = replayed iterations the other passes carried */
+int zf_solver_pass_stats_ex(zf_solver* s, double out[6]);
 int zf_solver_set_timing(zf_solver* s, int32_t enabled);
 
 /* ---- vector kernels for opaque (Python) callbacks ------------------------

@@ -91,10 +91,12 @@ class FakeSolver:
         if c.pend_status != 0:
             return 0
         left = c.max_iter - c.nit
-        if c.lag == 0 and left >= S:
-            return S
-        short = S // 2 if S >= 16 else S
-        return max(1, min(short, 2 * S - 1 - c.lag, left))
+        n = S // 2 if S >= 16 else S
+        if c.lag == 0:
+            if left >= 2 * S or left == S:
+                return S
+            n = (left + 1) // 2 if left > S else left
+        return max(1, min(n, 2 * S - 1 - c.lag, left))
 
     def _chain_packs(self):
         """One pass: replay of the lagging iterations, then the fresh trials, from the stored

@@ -70,17 +70,22 @@ ZF_HD inline void zf_free_bufs(int cur, int prev, int ring, int* first, int* sec
     *second = (m > 1) ? f[1] : f[0];
 }
 
-// FRESH trials of the next pass: S when a full chain fits (nothing lagging, S iterations left);
-// otherwise a SHORT chain - at most S, or S / 2 for S = 16, whose longest chain runs only in its
-// branch-free form (the other shapes reuse the 8-trial bodies) - bounded by the chain capacity
-// 2 S - 1 (lagging iterations are replayed in front), by the iterations left (:539), and 0 for a
-// materialise-only pass
+// FRESH trials of the next pass: S when a full chain fits and leaves either nothing or at least another
+// full chain's worth behind it; the last S < left < 2 S iterations before max_iter (:539) are SHARED by
+// two passes of about left / 2 (a pass of 10 + one of 10 costs 2 x 0.85 ms at n = 1e8, a pass of 16 + one of
+// 4 costs 1.2 + 0.85: a short chain is bound by its 48 B per element, not by its trials); after a broken
+// chain up to S (S / 2 for S = 16) behind the lagging iterations, bounded by the chain capacity 2 S - 1; 0
+// for a materialise-only pass.  (Which trials share a pass never changes a result: every decision is taken on
+// the sums of its own trial.)
 ZF_HD inline int zf_fresh_len(const zf_control* c) {
     if (c->pend_status != 0) return 0;
     const int sub = c->sub_iters > 0 ? c->sub_iters : 1;
     const int64_t left = c->max_iter - c->nit;
-    if (c->lag == 0 && left >= sub) return sub;
-    int64_t n = sub >= 16 ? sub / 2 : sub;
+    int64_t n = sub >= 16 ? sub / 2 : sub;   // behind lagging iterations: a short chain (the pass already carries the replays)
+    if (c->lag == 0) {
+        if (left >= 2 * (int64_t)sub || left == sub) return sub;
+        n = left > sub ? (left + 1) / 2 : left;
+    }
     const int64_t cap = (int64_t)(2 * sub - 1) - c->lag;
     if (n > cap) n = cap;
     if (n > left) n = left;

@@ -158,7 +158,7 @@ typedef __attribute__((address_space(3))) void* zf_lds_ptr;
 #define ZF_S16_GLDS 1
 #endif
 template <int S, int MODE, bool HIST, bool GRAD_INLINE> constexpr bool zf_uses_glds() {
-    return ZF_S16_GLDS != 0 && S >= 16 && MODE == 0 && !HIST && GRAD_INLINE;
+    return ZF_S16_GLDS != 0 && S >= 16 && (MODE == 0 || MODE == 2) && !HIST && GRAD_INLINE;
 }
 constexpr int ZF_GLDS_STREAMS = 4;                                   // x_k, x_{k-1}, d, c
 constexpr int ZF_GLDS_STAGE_UNITS = ZF_GLDS_STREAMS * ZF_BLOCK;      // 16-byte units per stage (16 KiB)
@@ -498,8 +498,17 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
                 const zf_d2 cc = sp[3 * ZF_BLOCK];
                 __builtin_amdgcn_sched_barrier(0);
                 if (k + 1 < total) issue(k + 1);
-                advance(a, o, q, cc, unit_of(k));   // the chain + the two iterate stores
-                zf_wait_vm<2>();
+                if constexpr (FULL) {
+                    advance(a, o, q, cc, unit_of(k));   // the chain + the two iterate stores
+                    zf_wait_vm<2>();
+                } else {
+                    // the general shape: replay of the lagging iterations, then the fresh trials; one or two
+                    // iterates are stored behind the DMA
+                    zf_d2 a1[UB] = {a}, o1[UB] = {o}, q1[UB] = {q}, c1[UB] = {cc};
+                    compute_batch(unit_of(k), a1, o1, q1, c1);
+                    if (ntr >= 2) zf_wait_vm<2>();
+                    else zf_wait_vm<1>();
+                }
             }
         }
     } else if constexpr (UB == ZF_TILE_U || MODE == 1 || HIST || S >= 16) {
@@ -618,17 +627,22 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     }
 }
 
-// PART (chains only, S > 1): a pass is launched as TWO kernels, each of which exits at once unless the
-// pass has its shape - 0: the full chain (nothing replayed, S fresh trials: the hot, branch-free
-// body), 1: every other shape (replays, shorter chains, materialise-only).  One kernel holding all
-// bodies needs the registers of the largest plus what the compiler hoists across the branches
-// (S = 16: 274 instead of 250 VGPRs - one wave per SIMD instead of two; S = 8: 207 instead of 190);
-// the second launch costs a kernel boundary (~1.5 us) per pass.
+// PART (chains only, S > 1): a pass is launched as TWO kernels (S = 16: THREE), each of which exits at
+// once unless the pass has its shape -
+//   0: the full chain (nothing replayed, S fresh trials: the hot, branch-free body);
+//   1: every other shape (replays, shorter chains, materialise-only) - for S = 16: of up to 8 fresh
+//      trials, through the 8-trial bodies (pack rows of trials 8 .. 15 written as zeros);
+//   2: S = 16 only: 9 .. 15 fresh trials (the shared tail before max_iter, zf_fresh_len) through the
+//      general 16-trial body - a wave-uniform branch per trial, LDS-DMA loads.
+// One kernel holding all bodies needs the registers of the largest plus what the compiler hoists across
+// the branches (S = 16: 274 VGPRs for parts 0 + 1, ~400 for parts 1 + 2 - one wave per SIMD instead of two;
+// S = 8: 207 instead of 190); every further launch costs a kernel boundary (~1.5-4 us) per pass.
 template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false, int PART = 0>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
+    static_assert(PART <= 1 || S >= 16, "the third kernel exists for chains of 16 only");
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
-    constexpr bool GLDS = (PART == 0) && zf_uses_glds<S, 0, HIST, GRAD_INLINE>();
+    constexpr bool GLDS = PART != 1 && zf_uses_glds<S, PART == 0 ? 0 : 2, HIST, GRAD_INLINE>();
     __shared__ zf_d2 stage[GLDS ? 2 * ZF_GLDS_STAGE_UNITS : 1];   // two stages of the LDS-DMA pipeline (32 KiB)
     // wave-uniform control reads (scalar loads); written by the previous step's decide
     if (A.ctl->status != ZF_RUNNING) return;
@@ -639,13 +653,18 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
         const int lag = A.ctl->lag;
         const int nf = zf_fresh_len(A.ctl);   // fresh trials of this chain (0: materialise only)
         const bool full = (lag == 0 && nf == S);
-        if (full != (PART == 0)) return;
+        const int part = full ? 0 : ((S >= 16 && nf > S / 2) ? 2 : 1);
+        if (part != PART) return;
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = (lag << 8) | nf;
         if constexpr (PART == 0) {
             zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, S, stage);
+        } else if constexpr (PART == 2) {
+            // (nf is laundered through readfirstlane: knowing nf > S / 2 the compiler made the first
+            //  trials unconditional, scheduled across them and needed 379 VGPRs instead of 227; an empty
+            //  asm as the barrier gave 260)
+            const int nf_opaque = __builtin_amdgcn_readfirstlane(nf);
+            zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, lag, nf_opaque, stage);
         } else if constexpr (S >= 16) {
-            // every shape but the full 16-chain goes through the 8-trial bodies (zf_fresh_len: at most
-            // S / 2 fresh trials then); the pack rows of trials 8 .. 15 are written as zeros
             constexpr int SS = S / 2;
             if (lag == 0 && nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 0, HIST, S>(A, lds, 0, SS);
             else if (nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 1, HIST, S>(A, lds, lag, SS);

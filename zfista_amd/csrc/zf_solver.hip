@@ -170,6 +170,7 @@ struct zf_solver {
     int64_t first_uncollected = 0;
     double ms_full = 0.0, ms_part = 0.0;  // S-trial chains without replay / everything else
     int64_t n_full = 0, n_part = 0;
+    int64_t fresh_part = 0, lag_part = 0;   // fresh trials / replayed iterations carried by the other passes
     zf_comm* comm = nullptr;              // RCCL communicator (zf_solver_set_comm): the solver gathers itself
     // streaming return_all: caller-owned ring of iterates in HBM (zf_solver_set_history)
     double* hist = nullptr;
@@ -322,13 +323,14 @@ extern "C" int zf_solver_destroy(zf_solver* s) {
 }
 
 // ---- launches ---------------------------------------------------------------
-// one pass = the full-chain kernel + (chains only) the kernel for every other shape; each exits at
-// once when the pass has not its shape (zf_trial_kernel, PART)
+// one pass = the full-chain kernel + (chains only) the kernel for every other shape (chains of 16: two,
+// for short and for long chains); each exits at once when the pass has not its shape (zf_trial_kernel, PART)
 template <bool GI, bool NEST, bool BOX, bool NT, int S, bool HIST>
 static void zf_launch_trial_parts(zf_solver* s, const zf_step_args& a) {
     dim3 g(s->grid), b(ZF_BLOCK);
     hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 0>), g, b, 0, s->stream, a);
     if constexpr (S > 1) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 1>), g, b, 0, s->stream, a);
+    if constexpr (S >= 16) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 2>), g, b, 0, s->stream, a);
 }
 
 // history-recording variants (nontemporal policy only: the history is write-once)
@@ -1058,6 +1060,8 @@ static int zf_collect_timing(zf_solver* s) {
             } else {
                 s->ms_part += ms;
                 s->n_part += 1;
+                s->fresh_part += shape & 0xff;
+                s->lag_part += shape >> 8;
             }
         }
     }
@@ -1120,9 +1124,23 @@ extern "C" int zf_solver_pass_stats(zf_solver* s, double out[4]) {
     out[3] = (double)s->n_part;
     s->ms_full = s->ms_part = 0.0;
     s->n_full = s->n_part = 0;
+    s->fresh_part = s->lag_part = 0;
     s->ms_total = 0.0;
     s->ms_count = 0;
     return ZF_OK;
+}
+
+// The same window with the work of the other passes: out[4] = fresh trials, out[5] = replayed iterations
+// they carried in total (a pass of the shared tail before max_iter runs about left / 2 fresh trials, a pass
+// after a broken chain replays the lagging iterations first).
+extern "C" int zf_solver_pass_stats_ex(zf_solver* s, double out[6]) {
+    ZF_REQUIRE(s && out, "zf_solver_pass_stats_ex: null argument");
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    int rc = zf_collect_timing(s);
+    if (rc) return rc;
+    out[4] = (double)s->fresh_part;
+    out[5] = (double)s->lag_part;
+    return zf_solver_pass_stats(s, out);
 }
 
 extern "C" int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches) {
@@ -1136,6 +1154,7 @@ extern "C" int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* 
     s->ms_count = 0;
     s->ms_full = s->ms_part = 0.0;
     s->n_full = s->n_part = 0;
+    s->fresh_part = s->lag_part = 0;
     return ZF_OK;
 }
 

@@ -261,6 +261,12 @@ class DeviceSolver:
         _lib.check(self.lib.zf_solver_pass_stats(self.handle, C.c_void_p(_lib.ptr(out))))
         return (out[0], int(out[1])), (out[2], int(out[3]))
 
+    def pass_stats_ex(self):
+        """pass_stats() plus (fresh trials, replayed iterations) the other passes carried in total."""
+        out = np.zeros(6)
+        _lib.check(self.lib.zf_solver_pass_stats_ex(self.handle, C.c_void_p(_lib.ptr(out))))
+        return (out[0], int(out[1])), (out[2], int(out[3])), (int(out[4]), int(out[5]))
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.zf_solver_destroy(self.handle)
