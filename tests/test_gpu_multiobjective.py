@@ -425,3 +425,56 @@ def test_library_dual_solver_matches_the_python_one(tag, golden):
         assert abs(got[0].sum() - 1.0) < 1e-12 and np.all(got[0] >= 0)
     # not attempted when F(x_k) is not finite
     assert eng.solve_dual(lr, f_y, np.full(m, np.inf), False, None, 1e-12, 100) is None
+
+
+@pytest.mark.parametrize("kind", ["jos1", "fds"])
+def test_fused_outer_iteration_is_invisible(kind):
+    """zf_mo_set_fused: commit() and prepare_async() deferred into the next solve_dual_device(), whose
+    kernel forms y, f(y) and J itself.  (a) The deferred work done the unfused way on demand gives the
+    same buffers bit for bit: y after commit(), J and f(y) after prepare_async(), read through the
+    ordinary accessors.  (b) A sequence of trials with and without fusion ends in the same iterates to
+    1e-12 (f(y) is summed in another order inside the kernel: last-bit differences in the dual)."""
+    from zfista_amd.multiobjective import X_K, X_NEW, Y
+    from zfista_amd.problems import FDS, JOS1
+
+    n = 40000 if kind == "fds" else 100003
+    rng = np.random.default_rng(11)
+    if kind == "jos1":
+        make = lambda: JOS1(n, l1_ratios=np.array([1.0, 2.0]) / n, l1_shifts=[0.0, 1.0])   # noqa: E731
+        x0, lr = rng.uniform(-2, 4, n), 1.0
+    else:
+        make = lambda: FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0.0, 1.0, 2.0])   # noqa: E731
+        x0, lr = rng.uniform(-2, 2, n), 1e-4
+    m = 2 if kind == "jos1" else 3
+
+    def run(fused, probe):
+        eng = make()._engine()
+        eng.set_x0(x0)
+        eng.set_fused(fused)
+        f0, g0 = eng.eval_F(X_K)
+        F_old = f0 + g0
+        seen = []
+        for k, beta in enumerate([0.0, 0.28, 0.43, 0.53]):
+            eng.prepare_async()
+            if probe:   # every accessor must see up-to-date buffers while work is still deferred
+                seen.append((eng.get(Y), eng.get_jac(), eng.get_f_y()))   # (this does the deferred work the unfused way)
+            out = eng.solve_dual_device(lr, None, F_old, False, None, 1e-12, 100000)
+            assert out is not None
+            f_x, g_x = out[4], out[5]
+            F_old = f_x + g_x
+            eng.commit(beta, True)
+        xk, y = eng.get(X_K), eng.get(Y)
+        eng.close()
+        return xk, y, F_old, seen
+
+    xa, ya, Fa, _ = run(False, False)
+    xb, yb, Fb, _ = run(True, False)
+    xc, yc, Fc, seen_c = run(True, True)
+    xd, yd, Fd, seen_d = run(False, True)
+    assert rel_err(xb, xa) <= 1e-12 and rel_err(yb, ya) <= 1e-12
+    np.testing.assert_allclose(Fb, Fa, rtol=1e-12)
+    # with the deferred work flushed before every trial the fused mode IS the unfused sequence
+    assert np.array_equal(xc, xd) and np.array_equal(yc, yd) and np.array_equal(Fc, Fd)
+    for (y1, J1, f1), (y2, J2, f2) in zip(seen_c, seen_d):
+        assert np.array_equal(y1, y2) and np.array_equal(J1, J2) and np.array_equal(f1, f2)
+    assert len(seen_c) == 4 and seen_c[0][1].shape == (m, n)
