@@ -352,6 +352,21 @@ int zf_mo_prepare_async(zf_mo* s);
  * beta (x_k - x_{k-1}) (:534), f(y) (:140) and J = jac_f(y) (:142) inside its one kernel: one launch and one
  * read-back per trial.  Every other entry point first brings the buffers up to date, so results do not change. */
 int zf_mo_set_fused(zf_mo* s, int32_t on);
+/* Trials launched AHEAD of their predecessor's result (fused mode; the outer loop :474-538 without the host in its
+ * critical path).  zf_mo_trial_launch enqueues one trial (after zf_mo_prepare_async) and returns a ticket;
+ * zf_mo_trial_wait returns its result and the acceptance decision (:298-303) the kernel took on F(x+) formed on
+ * the device.  A trial launched with gated = 1 - after zf_mo_commit + zf_mo_prepare_async, before the result of
+ * the trial before it is known - runs only if that trial was accepted (else it exits at once having touched
+ * nothing: *skipped_out = 1; call zf_mo_uncommit, then retry with a smaller step) and takes F(x_k) from that
+ * trial's F(x+) on the device (F_old may then be NULL).  At most one trial may be in flight ahead of the one
+ * waited for.  *ticket_out = -1: not a device trial (sharded x, m > 3) - use the host loop. */
+int zf_mo_trial_launch(zf_mo* s, double lr, const double* F_old /* m or NULL */, int32_t deprecated,
+                       const double* w0 /* m or NULL */, double tol, int64_t max_iter, double accept_tol,
+                       int32_t decay_is_one, int32_t gated, int32_t* ticket_out);
+int zf_mo_trial_wait(zf_mo* s, int32_t ticket, double* w_out, double* fun_out, int64_t* nit_out, int32_t* ok_out,
+                     int64_t* evals_out, double* err_out, double* f_x_out, double* g_x_out, double* f_y_out,
+                     int32_t* accepted_out, int32_t* skipped_out);
+int zf_mo_uncommit(zf_mo* s);   /* undo of zf_mo_commit (+ zf_mo_prepare_async) after a skipped gated trial */
 int zf_mo_get_f_y(zf_mo* s, double* f_y_out /* m */);
 int zf_mo_set_jac(zf_mo* s, const double* J_host);              /* generic kind         :142 */
 /* out[0..m) = g_i(p), out[m] = |p-v|^2, out[m+1] = |w@J|^2, out[m+2..2m+2) = J_i.(p-y)   :162-173 */

@@ -478,3 +478,56 @@ def test_fused_outer_iteration_is_invisible(kind):
     for (y1, J1, f1), (y2, J2, f2) in zip(seen_c, seen_d):
         assert np.array_equal(y1, y2) and np.array_equal(J1, J2) and np.array_equal(f1, f2)
     assert len(seen_c) == 4 and seen_c[0][1].shape == (m, n)
+
+
+@pytest.mark.parametrize("case", ["jos1_backtrack", "jos1_converge", "fds_backtrack", "fds_box_outside", "jos1_short",
+                                  "fds_deprecated", "jos1_decay1"])
+def test_trials_launched_ahead_match_the_sequential_loop(case, monkeypatch):
+    """dual_solver="device" launches every trial ahead of its predecessor's result (gated on the decision the
+    kernel takes itself, zf_mo_trial_launch / _wait).  Against the same solve with the host reading every
+    result before the next launch (ZF_MO_LAUNCH_AHEAD=0): line searches that backtrack (closed gates, undone
+    commits), convergence by tol, max_iter 1 / 2 / 3, a start outside the box (the search is not attempted on
+    the device: the host loop takes over), the deprecated test and decay_rate = 1."""
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.problems import FDS, JOS1
+
+    rng = np.random.default_rng(12)
+    kw = dict(nesterov=True, tol=0.0, dual_solver="device")
+    if case.startswith("jos1"):
+        n = 20011
+        prob = lambda: JOS1(n, l1_ratios=np.array([1.0, 2.0]) / n, l1_shifts=[0.0, 1.0])   # noqa: E731
+        x0 = rng.uniform(-2, 4, n)
+        if case == "jos1_backtrack":
+            runs = [dict(kw, lr=64.0 * n, max_iter=15)]            # several halvings in the first line searches
+        elif case == "jos1_converge":
+            runs = [dict(kw, lr=0.5 * n, tol=1e-3, max_iter=500)]
+        elif case == "jos1_short":
+            runs = [dict(kw, lr=0.5 * n, max_iter=k) for k in (1, 2, 3)]
+        else:
+            runs = [dict(kw, lr=0.25 * n, decay_rate=1, max_iter=9)]
+    else:
+        n = 3001
+        if case == "fds_box_outside":
+            prob = lambda: FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0.0, 1.0, 2.0], bounds=(-1.0, 1.0))   # noqa: E731
+            x0 = rng.uniform(-2, 2, n)                             # F(x0) = inf: not attempted on the device
+        else:
+            prob = lambda: FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0.0, 1.0, 2.0])   # noqa: E731
+            x0 = rng.uniform(-2, 2, n)
+        runs = [dict(kw, lr=1.0, max_iter=10, deprecated=(case == "fds_deprecated"))]
+    for opts in runs:
+        out = []
+        for ahead in ("1", "0"):
+            monkeypatch.setenv("ZF_MO_LAUNCH_AHEAD", ahead)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out.append(minimize_proximal_gradient(*prob().callbacks(), x0, **opts))
+        a, b = out
+        assert (a.nit, a.get("status"), a.success, a.message) == (b.nit, b.get("status"), b.success, b.message)
+        if case == "fds_box_outside":   # F(x0) = inf: SciPy refuses the dual on both paths - reported, not raised (:493-509)
+            assert a.success is False and a.message.startswith("Error: ") and np.array_equal(a.x, b.x)
+            continue
+        assert rel_err(a.x, b.x) <= 1e-10 and np.allclose(a.fun, b.fun, rtol=1e-10, atol=0)
+        if case == "jos1_converge":
+            assert a.success and a.nit < 500
+        if case == "jos1_short":
+            assert a.nit == opts["max_iter"]

@@ -155,6 +155,10 @@ SIGNATURES = {
                                          C.POINTER(C.c_int64), C.POINTER(C.c_double), _P, _P, _P]),
     "zf_mo_prepare_async": (C.c_int, [_P]),
     "zf_mo_set_fused": (C.c_int, [_P, C.c_int32]),
+    "zf_mo_trial_launch": (C.c_int, [_P, C.c_double, _P, C.c_int32, _P, C.c_double, C.c_int64, C.c_double, C.c_int32,
+                                     C.c_int32, _P]),
+    "zf_mo_trial_wait": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "zf_mo_uncommit": (C.c_int, [_P]),
     "zf_mo_get_f_y": (C.c_int, [_P, _P]),
     "zf_mo_solve_stats": (C.c_int, [_P, _P]),
     "zf_mo_recover": (C.c_int, [_P, C.c_double, _P, _P]),

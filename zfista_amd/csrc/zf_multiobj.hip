@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * MO_RED_WAVES) void k_mo_reduce(const double* _
 
 // f(y) from the raw sums, on the device (zf_mo_prepare_async: no host round trip between the sums
 // of f(y), the Jacobian kernel that needs sum(y), and the dual search that needs f(y))
-__host__ __device__ inline void mo_f_from_sums(int kind, double dn, const double* t, double* f_out) {
+__host__ __device__ __attribute__((always_inline)) inline void mo_f_from_sums(int kind, double dn, const double* t, double* f_out) {
     if (kind == ZF_MO_JOS1) {
         const double n0 = sqrt(t[0]), n1 = sqrt(t[1]);
         f_out[0] = n0 * n0 / dn;   // np.linalg.norm(x) ** 2 / n
@@ -289,6 +289,11 @@ struct mo_solve_result {
     double f_sums[4], g_sums[MO_MAX_M + 1];
     int32_t has_F, reserved2;
     double f_y[MO_MAX_M];   // f(y) the search used (computed on the device after zf_mo_prepare_async)
+    // the acceptance test of the trial (:298-303), taken by the kernel on F(x+) formed on the device (the
+    // built-in problems): what lets the NEXT trial be launched before this record is read (gate)
+    double f_x[MO_MAX_M], g_x[MO_MAX_M];
+    int32_t accepted;   // 1: F(x+) - F(x_k) <= model + tol for all objectives (or decay_rate == 1); 0: not / not decidable here
+    int32_t skipped;    // 1: the launch found its gate closed (the trial before it was not accepted) and did nothing
     // the record lives in pinned host memory and is written by the kernel itself; `seq` = the launch
     // number, stored last behind a system-scope fence: the host waits for it instead of a copy + stream sync
     unsigned long long seq;
@@ -324,6 +329,15 @@ struct mo_solve_args {
     double* y_w;          // writable y, J (= y, J above) and f(y) on the device: everything formed here is also
     double* J_w;          //   stored, so every other entry point finds the state zf_mo_prepare_async leaves
     double* f_y_w;
+    // trials launched ahead (zf_mo_trial_launch): the acceptance decision of this trial goes to *accept_out
+    // and F(x+) to F_new_out; a launch with a gate exits at once unless *gate == 1 and takes F(x_k) from
+    // F_old_dev - the outputs of the launch before it, which the host has not read yet
+    const int* gate;
+    const double* F_old_dev;
+    int* accept_out;
+    double* F_new_out;
+    int decay_is_one;
+    double accept_tol;
 };
 
 template <int M>
@@ -502,7 +516,20 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
     __shared__ double s_fun[NB], s_jac[NB][M];
     __shared__ int s_flag;
     __shared__ double s_fy[M];   // f(y): given (host value / zf_mo_prepare_async) or formed by the prologue below
+    __shared__ double s_Fold[M];
     const int tid = threadIdx.x;
+    if (A.gate && *A.gate != 1) {   // launched ahead of a trial that was then not accepted: nothing may be touched
+        if (blockIdx.x == 0 && tid == 0) {
+            if (A.accept_out) *A.accept_out = 0;
+            A.out->skipped = 1;
+            A.out->accepted = 0;
+            A.out->ok = 0;
+            __threadfence_system();
+            __hip_atomic_store(&A.out->seq, (unsigned long long)A.nonce, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    if (tid < M) s_Fold[tid] = A.F_old_dev ? A.F_old_dev[tid] : A.F_old[tid];
     const int64_t n = A.n;
     const int64_t stride = (int64_t)gridDim.x * MO_SOLVE_TPB;
     const int64_t j0 = (int64_t)blockIdx.x * MO_SOLVE_TPB + tid;
@@ -748,7 +775,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             for (int i = 0; i < M; ++i) {
                 double jv = -g_p[i] - t[M + 2 + i];
                 if (!A.deprecated) {
-                    const double dF = A.F_old[i] - s_fy[i];
+                    const double dF = s_Fold[i] - s_fy[i];
                     corr += s_w[tid][i] * dF;
                     jv += dF;
                 }
@@ -874,6 +901,30 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         r.cyc_eval = c_eval;
         r.cyc_combine = c_comb;
         r.cyc_step = c_step;
+        // F(x+) and the acceptance test (:295, :298-303) from the sums of this same kernel
+        int accepted = 0;
+#pragma unroll
+        for (int i = 0; i < MO_MAX_M; ++i) r.f_x[i] = r.g_x[i] = 0.0;
+        if (r.has_F && tail_kind != 0 && r.ok == 1) {
+            double fx[3] = {0.0, 0.0, 0.0};
+            const double t4[4] = {s_tot[1], s_tot[2], s_tot[3], s_tot[4]};   // (not &r.f_sums: that sends r to scratch)
+            mo_f_from_sums(M == 2 ? ZF_MO_JOS1 : ZF_MO_FDS, (double)n, t4, fx);   // (tail_kind != 0: JOS1 has m = 2, FDS m = 3)
+            accepted = 1;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const double gx = (A.G.has_box && s_tot[5 + M] > 0.0) ? INFINITY : (A.G.has_l1 ? A.G.ratio[i] * s_tot[5 + i] : 0.0);
+                r.f_x[i] = fx[i];
+                r.g_x[i] = gx;
+                const double F_new = fx[i] + gx;
+                if (A.F_new_out) A.F_new_out[i] = F_new;
+                const double lhs = A.deprecated ? fx[i] - s_fy[i] : F_new - s_Fold[i];
+                if (!(lhs <= -s_mach.fun + A.accept_tol)) accepted = 0;   // (fun of the trial = - dual value, :207)
+            }
+            if (A.decay_is_one) accepted = 1;
+        }
+        r.accepted = accepted;
+        r.skipped = 0;
+        if (A.accept_out) *A.accept_out = accepted;
         r.seq = 0;
         *A.out = r;
         __threadfence_system();
@@ -909,8 +960,12 @@ struct zf_mo {
     unsigned long long* solve_partials = nullptr;
     unsigned long long* solve_totals = nullptr;
     unsigned solve_nonce = 0;
-    mo_solve_result* solve_out = nullptr;      // device
-    mo_solve_result* h_solve_out = nullptr;    // pinned host mirror
+    mo_solve_result* solve_out = nullptr;      // device view of h_solve_out (two records: launches alternate)
+    mo_solve_result* h_solve_out = nullptr;    // pinned host memory the kernel writes directly
+    int* accept_dev = nullptr;                 // [2] acceptance decision of the launch of either parity
+    double* F_dev = nullptr;                   // [2][MO_MAX_M] F(x+) of the launch of either parity
+    unsigned last_nonce[2] = {0, 0};           // launch number whose record each slot is waiting for / holds
+    int last_slot = 0;                         // slot of the most recent launch (zf_mo_solve_stats)
     int solve_grid = 0;
     size_t solve_lds_set = (size_t)-1;         // dynamic LDS size last registered for k_dual_solve
     double* f_y_dev = nullptr;                 // f(y) of zf_mo_prepare_async (device, MO_MAX_M)
@@ -1074,6 +1129,8 @@ extern "C" int zf_mo_destroy(zf_mo* s) {
     if (s->solve_totals) (void)hipFree(s->solve_totals);
     if (s->f_y_dev) (void)hipFree(s->f_y_dev);
     if (s->h_solve_out) (void)hipHostFree(s->h_solve_out);
+    if (s->accept_dev) (void)hipFree(s->accept_dev);
+    if (s->F_dev) (void)hipFree(s->F_dev);
     (void)hipFree(s->buf);
     (void)hipFree(s->partials);
     (void)hipFree(s->totals);
@@ -1319,21 +1376,25 @@ extern "C" int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const do
 // was not attempted.
 // *ok_out = 0: not attempted (non-finite start, sharded x, unsupported m) - use zf_mo_solve_dual /
 // the reference's calls and zf_mo_recover instead.
-extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
-                                       const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
-                                       int64_t* nit_out, int32_t* ok_out, int64_t* evals_out, double* err_out,
-                                       double* f_x_out, double* g_x_out, double* f_y_out) {
-    ZF_REQUIRE(s && F_old && w_out && fun_out && nit_out && ok_out && err_out, "zf_mo_solve_dual_device: null argument");
-    ZF_REQUIRE(f_y || s->f_y_on_device, "zf_mo_solve_dual_device: f_y is NULL and no zf_mo_prepare_async result exists");
-    ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_solve_dual_device: lr must be > 0 and max_iter >= 1");
-    *ok_out = 0;
-    if (evals_out) *evals_out = 0;
+// ---- launch / wait halves of a device trial ----------------------------------------------------
+namespace {
+struct mo_launch_opts {
+    int gated = 0;          // launched ahead: runs only if the launch before it accepted its trial, F(x_k) from there
+    int decay_is_one = 0;   // decay_rate == 1: every trial is accepted (:299)
+    double accept_tol = 0.0;
+};
+
+// launches one trial; *slot_out = the record slot (0 / 1) to wait on; *launched = 0: not attempted here
+// (sharded x, m > 3: the caller's host loop), nothing was enqueued
+int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated, const double* w0,
+                    double tol, int64_t max_iter, const mo_launch_opts& L, int* slot_out, int* launched) {
+    *launched = 0;
     // fused outer iteration: y (deferred commit), f(y) and J are formed by this launch itself
     const bool fuse = s->fused && s->prep_pending && !f_y && !s->exchange && s->m <= 3 &&
                       (s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS);
     if (!fuse)
         if (int rc = mo_flush(s)) return rc;
-    if (s->exchange) return ZF_OK;   // x sharded over ranks: every evaluation needs an exchange (host loop)
+    if (s->exchange || s->m > 3) return ZF_OK;   // sharded x: every evaluation needs an exchange; m > 3: register budget
     if (!s->solve_partials) {
         int dev = 0, cus = 0;
         ZF_HIP(hipGetDevice(&dev));
@@ -1347,10 +1408,14 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
         ZF_HIP(hipMalloc(&s->solve_totals, 16 * 2 * zf_dual::MAXB * nq));
         ZF_HIP(hipMemsetAsync(s->solve_partials, 0, 16 * 2 * zf_dual::MAXB * nq * s->solve_grid, s->stream));
         ZF_HIP(hipMemsetAsync(s->solve_totals, 0, 16 * 2 * zf_dual::MAXB * nq, s->stream));
-        // the result record: pinned host memory the kernel writes directly (fine-grained, device-visible)
-        ZF_HIP(hipHostMalloc((void**)&s->h_solve_out, sizeof(mo_solve_result), hipHostMallocMapped));
-        memset(s->h_solve_out, 0, sizeof(mo_solve_result));
+        // the result records: pinned host memory the kernel writes directly (fine-grained, device-visible)
+        ZF_HIP(hipHostMalloc((void**)&s->h_solve_out, 2 * sizeof(mo_solve_result), hipHostMallocMapped));
+        memset(s->h_solve_out, 0, 2 * sizeof(mo_solve_result));
         ZF_HIP(hipHostGetDevicePointer((void**)&s->solve_out, s->h_solve_out, 0));
+        ZF_HIP(hipMalloc(&s->accept_dev, 2 * sizeof(int)));
+        ZF_HIP(hipMalloc(&s->F_dev, 2 * MO_MAX_M * sizeof(double)));
+        ZF_HIP(hipMemsetAsync(s->accept_dev, 0, 2 * sizeof(int), s->stream));
+        ZF_HIP(hipMemsetAsync(s->F_dev, 0, 2 * MO_MAX_M * sizeof(double), s->stream));
     }
     mo_solve_args A;
     memset(&A, 0, sizeof(A));
@@ -1362,7 +1427,7 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
     A.lr = lr;
     for (int i = 0; i < s->m; ++i) {
         A.f_y[i] = f_y ? f_y[i] : 0.0;
-        A.F_old[i] = F_old[i];
+        A.F_old[i] = F_old ? F_old[i] : 0.0;
         if (w0) A.w0[i] = w0[i];
     }
     A.f_y_dev = f_y ? nullptr : s->f_y_dev;
@@ -1374,7 +1439,16 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
     A.partials = s->solve_partials;
     A.totals = s->solve_totals;
     A.nonce = ++s->solve_nonce;
-    A.out = s->solve_out;
+    const int slot = (int)(A.nonce & 1u);
+    A.out = s->solve_out + slot;
+    A.accept_out = s->accept_dev + slot;
+    A.F_new_out = s->F_dev + slot * MO_MAX_M;
+    A.decay_is_one = L.decay_is_one;
+    A.accept_tol = L.accept_tol;
+    if (L.gated) {   // the launch before this one has the other parity
+        A.gate = s->accept_dev + (1 - slot);
+        A.F_old_dev = s->F_dev + (1 - slot) * MO_MAX_M;
+    }
     if (fuse) {
         A.prep_kind = s->kind;
         A.make_y = s->y_pending ? 1 : 0;
@@ -1395,44 +1469,55 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
     const size_t lds = (size_t)A.resident_rows * (s->m + 1) * MO_SOLVE_TPB * sizeof(double);
     const bool set_attr = s->solve_lds_set != lds;   // (a driver call of several microseconds: once, not per trial)
     s->solve_lds_set = lds;
-    switch (s->m) {
-        case 2:
-            if (set_attr) ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_dual_solve<2>, grid, block, lds, s->stream, A);
-            break;
-        case 3:
-            if (set_attr) ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_dual_solve<3>, grid, block, lds, s->stream, A);
-            break;
-        default: return ZF_OK;   // larger m: host loop (register budget of the resident elements + machine)
+    if (s->m == 2) {
+        if (set_attr) ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_dual_solve<2>, grid, block, lds, s->stream, A);
+    } else {
+        if (set_attr) ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_dual_solve<3>, grid, block, lds, s->stream, A);
     }
     ZF_HIP(hipGetLastError());
-    // wait for the record (the kernel stores `seq` last): no copy, no stream synchronisation.  Should the
-    // launch die without writing it, the stream goes idle: checked now and then, reported as an error.
-    {
-        volatile unsigned long long* seq = &s->h_solve_out->seq;
-        unsigned spins = 0;
-        while (*seq != (unsigned long long)A.nonce) {
-            if ((++spins & 0xFFFu) == 0) {
-                const hipError_t q = hipStreamQuery(s->stream);
-                if (q == hipSuccess) {
-                    if (*seq == (unsigned long long)A.nonce) break;
-                    return zf_fail(ZF_ERR_STATE, "zf_mo_solve_dual_device: the kernel ended without a result record%s");
-                }
-                if (q != hipErrorNotReady) return zf_fail(ZF_ERR_HIP, "zf_mo_solve_dual_device: %s", hipGetErrorString(q));
+    s->last_nonce[slot] = A.nonce;
+    s->last_slot = slot;
+    *slot_out = slot;
+    *launched = 1;
+    return ZF_OK;
+}
+
+// waits for the record of slot `slot` (the kernel stores `seq` last): no copy, no stream synchronisation.
+// Should the launch die without writing it, the stream goes idle: checked now and then, reported as an error.
+int mo_trial_wait(zf_mo* s, int slot, const mo_solve_result** out) {
+    volatile unsigned long long* seq = &s->h_solve_out[slot].seq;
+    const unsigned long long want = (unsigned long long)s->last_nonce[slot];
+    unsigned spins = 0;
+    while (*seq != want) {
+        if ((++spins & 0xFFFu) == 0) {
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q == hipSuccess) {
+                if (*seq == want) break;
+                return zf_fail(ZF_ERR_STATE, "zf_mo: the trial kernel ended without a result record%s");
             }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
+            if (q != hipErrorNotReady) return zf_fail(ZF_ERR_HIP, "zf_mo: %s", hipGetErrorString(q));
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
     }
-    const mo_solve_result& r = *s->h_solve_out;
-    if (evals_out) *evals_out = r.evals;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *out = &s->h_solve_out[slot];
+    return ZF_OK;
+}
+
+// unpacks a record the way zf_mo_solve_dual_device reports it
+int mo_trial_unpack(zf_mo* s, const mo_solve_result& r, double* w_out, double* fun_out, int64_t* nit_out, int32_t* ok_out,
+                    int64_t* evals_out, double* err_out, double* f_x_out, double* g_x_out, double* f_y_out) {
+    *ok_out = 0;
+    if (evals_out) *evals_out = r.skipped ? 0 : r.evals;
+    if (r.skipped) return ZF_OK;
     if (f_y_out)
         for (int i = 0; i < s->m; ++i) f_y_out[i] = r.f_y[i];
     if (r.ok < 0) return zf_fail(ZF_ERR_STATE, "zf_mo_solve_dual_device: a grid-wide wait timed out (is another kernel "
-                                               "occupying the GPU?)");
+                                               "occupying the GPU?)%s");
     if (r.ok == 0) return ZF_OK;
     for (int i = 0; i < s->m; ++i) w_out[i] = r.w[i];
     *fun_out = r.fun;
@@ -1446,9 +1531,82 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
             else g_x_out[i] = s->G.has_l1 ? s->G.ratio[i] * r.g_sums[i] : 0.0;     // :112-117
         }
     if (f_x_out) {
-        if (A.tail_kind) mo_f_from_sums(s->kind, (double)s->n_global, r.f_sums, f_x_out);
+        if (s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS) mo_f_from_sums(s->kind, (double)s->n_global, r.f_sums, f_x_out);
         else f_x_out[0] = NAN;   // f is a host callback for this kind
     }
+    return ZF_OK;
+}
+}  // namespace
+
+extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
+                                       const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
+                                       int64_t* nit_out, int32_t* ok_out, int64_t* evals_out, double* err_out,
+                                       double* f_x_out, double* g_x_out, double* f_y_out) {
+    ZF_REQUIRE(s && F_old && w_out && fun_out && nit_out && ok_out && err_out, "zf_mo_solve_dual_device: null argument");
+    ZF_REQUIRE(f_y || s->f_y_on_device, "zf_mo_solve_dual_device: f_y is NULL and no zf_mo_prepare_async result exists");
+    ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_solve_dual_device: lr must be > 0 and max_iter >= 1");
+    *ok_out = 0;
+    if (evals_out) *evals_out = 0;
+    int slot = 0, launched = 0;
+    int rc = mo_trial_launch(s, lr, f_y, F_old, deprecated, w0, tol, max_iter, mo_launch_opts(), &slot, &launched);
+    if (rc || !launched) return rc;
+    const mo_solve_result* r = nullptr;
+    if ((rc = mo_trial_wait(s, slot, &r))) return rc;
+    return mo_trial_unpack(s, *r, w_out, fun_out, nit_out, ok_out, evals_out, err_out, f_x_out, g_x_out, f_y_out);
+}
+
+// Trials launched AHEAD of their predecessor's result (the outer loop without the host in its critical
+// path).  zf_mo_trial_launch enqueues one trial and returns a ticket; zf_mo_trial_wait returns its result
+// and the acceptance decision (:298-303) the kernel took on F(x+) = f(x+) + g(x+) formed on the device.
+// A trial launched with gated = 1 - after zf_mo_commit + zf_mo_prepare_async in fused mode, BEFORE the
+// result of the trial before it is known - runs only if that trial was accepted (else it exits at once,
+// *skipped_out = 1, having touched nothing: call zf_mo_uncommit and retry with a smaller step) and takes
+// F(x_k) from that trial's F(x+) on the device (F_old may be NULL).  At most one trial may be in flight
+// ahead of the one being waited for.
+extern "C" int zf_mo_trial_launch(zf_mo* s, double lr, const double* F_old, int32_t deprecated, const double* w0,
+                                  double tol, int64_t max_iter, double accept_tol, int32_t decay_is_one, int32_t gated,
+                                  int32_t* ticket_out) {
+    ZF_REQUIRE(s && ticket_out, "zf_mo_trial_launch: null argument");
+    ZF_REQUIRE(F_old || gated, "zf_mo_trial_launch: F_old may be NULL only for a gated trial");
+    ZF_REQUIRE(s->f_y_on_device, "zf_mo_trial_launch: call zf_mo_prepare_async first");
+    ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_trial_launch: lr must be > 0 and max_iter >= 1");
+    mo_launch_opts L;
+    L.gated = gated != 0;
+    L.decay_is_one = decay_is_one != 0;
+    L.accept_tol = accept_tol;
+    int slot = 0, launched = 0;
+    int rc = mo_trial_launch(s, lr, nullptr, F_old, deprecated, w0, tol, max_iter, L, &slot, &launched);
+    if (rc) return rc;
+    *ticket_out = launched ? slot : -1;   // -1: not a device trial (sharded x, m > 3)
+    return ZF_OK;
+}
+
+extern "C" int zf_mo_trial_wait(zf_mo* s, int32_t ticket, double* w_out, double* fun_out, int64_t* nit_out,
+                                int32_t* ok_out, int64_t* evals_out, double* err_out, double* f_x_out, double* g_x_out,
+                                double* f_y_out, int32_t* accepted_out, int32_t* skipped_out) {
+    ZF_REQUIRE(s && w_out && fun_out && nit_out && ok_out && err_out && accepted_out && skipped_out &&
+                   (ticket == 0 || ticket == 1) && s->h_solve_out,
+               "zf_mo_trial_wait: bad argument");
+    const mo_solve_result* r = nullptr;
+    int rc = mo_trial_wait(s, ticket, &r);
+    if (rc) return rc;
+    *accepted_out = r->accepted;
+    *skipped_out = r->skipped;
+    rc = mo_trial_unpack(s, *r, w_out, fun_out, nit_out, ok_out, evals_out, err_out, nullptr, nullptr, f_y_out);
+    if (rc || !*ok_out) return rc;
+    for (int i = 0; i < s->m; ++i) {   // the values the kernel decided on
+        if (f_x_out) f_x_out[i] = r->f_x[i];
+        if (g_x_out) g_x_out[i] = r->g_x[i];
+    }
+    return ZF_OK;
+}
+
+// undo of a zf_mo_commit (+ zf_mo_prepare_async) whose gated trial was skipped: x_k, x_{k-1}, y, J and
+// f(y) are those of the rejected trial again
+extern "C" int zf_mo_uncommit(zf_mo* s) {
+    ZF_REQUIRE(s, "zf_mo_uncommit: null argument");
+    s->cur = (s->cur + 2) % 3;
+    s->y_pending = s->prep_pending = false;
     return ZF_OK;
 }
 
@@ -1456,7 +1614,7 @@ extern "C" int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, c
 // cycles of workgroup 0: whole kernel, evaluation loops, grid-wide hand-overs, solver steps
 extern "C" int zf_mo_solve_stats(zf_mo* s, int64_t out[6]) {
     ZF_REQUIRE(s && out && s->h_solve_out, "zf_mo_solve_stats: no device solve has run");
-    const mo_solve_result& r = *s->h_solve_out;
+    const mo_solve_result& r = s->h_solve_out[s->last_slot];
     out[0] = r.batches, out[1] = r.evals, out[2] = r.cyc_total, out[3] = r.cyc_eval, out[4] = r.cyc_combine,
     out[5] = r.cyc_step;
     return ZF_OK;

@@ -11,6 +11,7 @@ built-in problems and the momentum update are HIP kernels too
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from warnings import warn
 
@@ -230,6 +231,52 @@ class MoEngine:
             return None
         return (w.copy(), np.float64(fun.value), int(nit.value), np.float64(err.value),
                 None if np.isnan(f_x[0]) else f_x.copy(), g_x.copy(), f_y_used.copy())
+
+    # -- trials launched ahead of their predecessor's result (zf_mo_trial_launch / _wait) -------------
+    def trial_launch(self, lr, F_old, deprecated, w0, tol, max_iter, accept_tol, decay_is_one, gated):
+        """Enqueue one trial (after prepare_async()); returns a ticket, or None when this problem has no
+        device trial (sharded x, m > 3).  ``gated``: the trial runs only if the one launched before it
+        turns out accepted, and takes F(x_k) from that trial's F(x+) on the device (``F_old`` None)."""
+        st = self.__dict__.get("_launch_bufs")
+        if st is None:
+            arrs = [np.zeros(self.m) for _ in range(2)]   # F_old, w0
+            st = self._launch_bufs = (arrs, [C.c_void_p(_lib.ptr(a)) for a in arrs], C.c_int32(0))
+        (b_Fold, b_w0), ptrs, ticket = st
+        if F_old is not None:
+            b_Fold[:] = F_old
+        if w0 is not None:
+            b_w0[:] = w0
+        rc = self.lib.zf_mo_trial_launch(self.h, float(lr), None if F_old is None else ptrs[0], int(bool(deprecated)),
+                                         None if w0 is None else ptrs[1], float(tol), int(max_iter), float(accept_tol),
+                                         int(bool(decay_is_one)), int(bool(gated)), C.byref(ticket))
+        if rc != _lib.ZF_OK:
+            self._check(rc, "zf_mo_trial_launch")
+        return None if ticket.value < 0 else int(ticket.value)
+
+    def trial_wait(self, ticket):
+        """Result of a launched trial: None if it was skipped (its gate was closed), else
+        (weight, fun, nit, err, f_x, g_x, f_y, accepted) - or ("not attempted", f_y) when the search did not
+        run (non-finite start): the caller continues with the host path."""
+        st = self.__dict__.get("_wait_bufs")
+        if st is None:
+            arrs = [np.zeros(self.m) for _ in range(4)]   # w, f_x, g_x, f_y
+            scal = (C.c_double(0.0), C.c_int64(0), C.c_int32(0), C.c_int64(0), C.c_double(0.0), C.c_int32(0), C.c_int32(0))
+            st = self._wait_bufs = (arrs, [C.c_void_p(_lib.ptr(a)) for a in arrs], scal, [C.byref(v) for v in scal])
+        (w, f_x, g_x, f_y), ptrs, (fun, nit, ok, evals, err, accepted, skipped), refs = st
+        rc = self.lib.zf_mo_trial_wait(self.h, int(ticket), ptrs[0], refs[0], refs[1], refs[2], refs[3], refs[4],
+                                       ptrs[1], ptrs[2], ptrs[3], refs[5], refs[6])
+        if rc != _lib.ZF_OK:
+            self._check(rc, "zf_mo_trial_wait")
+        if skipped.value:
+            return None
+        self.n_dual_evals += int(evals.value)
+        if not ok.value:
+            return ("not attempted", f_y.copy())
+        return (w.copy(), np.float64(fun.value), int(nit.value), np.float64(err.value), f_x.copy(), g_x.copy(),
+                f_y.copy(), bool(accepted.value))
+
+    def uncommit(self):
+        _lib.check(self.lib.zf_mo_uncommit(self.h), "zf_mo_uncommit")
 
     def solve_stats(self):
         """Diagnostics of the last solve_dual_device(): batches, evaluations and the shader-clock
@@ -517,6 +564,13 @@ def solve_native(problem, x0, o):
 
     f0, g0 = eval_F(X_K)
     F_old = f0 + g0                     # F(x_k); cached between iterations instead of recomputed (:279)
+    if (lazy_f_y and not o["return_all"] and not o["warm_start"] and o["max_iter"] >= 1
+            and os.environ.get("ZF_MO_LAUNCH_AHEAD", "1") != "0"):
+        out = _solve_native_ahead(eng, o, m, F_old, res, t0)
+        if out is not None:
+            return out
+        eng.set_x0(x0)                  # (no device trial for this problem: the loop below, from the start)
+        eng.set_fused(lazy_f_y)
     w0 = np.ones(m) / m
     lr = o["lr"]
     allvecs = allfuns = allerrs = None
@@ -595,6 +649,98 @@ def solve_native(problem, x0, o):
         res.status, res.message, res.success = 0, _MSG_MAXITER, False
     res.update(x=eng.get(X_K), fun=F_old, nit=nit, allvecs=allvecs, allfuns=allfuns, allerrs=allerrs,
                time=time.time() - t0)
+    return res, status
+
+
+def _solve_native_ahead(eng, o, m, F_old, res, t0):
+    """The outer loop (:474-538) with every trial launched AHEAD of its predecessor's result
+    (dual_solver="device", built-in problems): while the host reads the record of trial k and does its
+    bookkeeping, the kernel of trial k + 1 - enqueued under the assumption that k is accepted, gated on
+    the decision the kernel of k takes itself (:298-303) - is already running.  A rejected trial closes the
+    gate: the trial launched ahead exits without touching anything, the speculative commit is undone and
+    the line search continues with the smaller step.  Returns (result, status), or None when the problem
+    has no device trial / the search cannot run on the device (the caller's loop takes over)."""
+    from .proximal_gradient import (_MSG_BACKTRACK, _MSG_MAXITER, _MSG_OK, _print_row)
+
+    lr = o["lr"]
+    tol_i, max_i, dep = o["tol_internal"], o["max_iter_internal"], o["deprecated"]
+    decay_one = o["decay_rate"] == 1
+    t_state, betas = None, []
+
+    def next_beta():
+        nonlocal t_state, betas
+        if not o["nesterov"]:
+            return 0.0
+        if not betas:
+            b, t_state = momentum_factors(64, o["nesterov_ratio"], t_state)
+            betas = list(b[::-1])
+        return betas.pop()
+
+    eng.prepare_async()
+    ticket = eng.trial_launch(lr, F_old, dep, None, tol_i, max_i, tol_i, decay_one, False)
+    if ticket is None:
+        return None
+    status = _lib.ZF_MAXITER
+    nit = 0
+    F_k = F_old
+    for nit in range(1, o["max_iter"] + 1):
+        trials = 0
+        ahead = None
+        while True:
+            trials += 1
+            if ahead is None and nit < o["max_iter"]:
+                # assume this trial is accepted: its commit and the next trial, before its result is known
+                beta = next_beta()
+                eng.commit(beta, o["nesterov"])
+                eng.prepare_async()
+                ahead = (eng.trial_launch(lr, None, dep, None, tol_i, max_i, tol_i, decay_one, True), beta)
+            out = eng.trial_wait(ticket)
+            if out is None or isinstance(out[0], str):
+                # the search did not run on the device (non-finite dual values, e.g. F(x_0) = inf outside the
+                # box): its record says "not accepted", so a trial launched ahead found its gate closed
+                if ahead is not None:
+                    eng.trial_wait(ahead[0])
+                    eng.uncommit()
+                if out is not None and nit == 1 and trials == 1:
+                    return None                               # from the start: the caller's loop (host search)
+                raise RuntimeError("the device-side trial was not attempted in the middle of a solve")
+            weight, dual_fun, nit_int, err, f_x, g_x, f_y, accepted = out
+            fun = -dual_fun                                   # (:207)
+            F_new = f_x + g_x                                 # (:295) formed and tested on the device
+            if accepted:
+                break
+            # rejected: the trial launched ahead found its gate closed
+            if ahead is not None:
+                skipped = eng.trial_wait(ahead[0])
+                assert skipped is None, "a gated trial ran although its predecessor was rejected"
+                eng.uncommit()
+                if o["nesterov"]:
+                    betas.append(ahead[1])                    # (the factor belongs to the next ACCEPTED iteration)
+                ahead = None
+            if trials >= o["max_backtrack_iter"]:
+                print(f"An error occurred: {_MSG_BACKTRACK}")
+                bad = OptimizeResult()
+                bad.update(success=False, message=f"Error: {_MSG_BACKTRACK}", x=eng.get(X_K), fun=F_k, nit=nit - 1,
+                           time=time.time() - t0, allvecs=None, allfuns=None, allerrs=None)
+                return bad, _lib.ZF_BACKTRACK_FAILED
+            lr *= o["decay_rate"]
+            ticket = eng.trial_launch(lr, F_k, dep, None, tol_i, max_i, tol_i, decay_one, False)
+        if o["verbose"]:
+            _print_row(nit, nit_int, err, fun, lr)
+        F_k = F_new
+        if ahead is None:                                     # the last iteration max_iter allows: commit for x_k
+            eng.commit(next_beta(), o["nesterov"])
+        else:
+            ticket = ahead[0]
+        if err < o["tol"]:   # :525
+            res.status, res.message, res.success = 1, _MSG_OK, True
+            status = _lib.ZF_CONVERGED
+            if ahead is not None:
+                eng.trial_wait(ahead[0])                      # (runs to its end: it only wrote y, J and the x+ slot)
+            break
+    if status == _lib.ZF_MAXITER:
+        res.status, res.message, res.success = 0, _MSG_MAXITER, False
+    res.update(x=eng.get(X_K), fun=F_k, nit=nit, allvecs=None, allfuns=None, allerrs=None, time=time.time() - t0)
     return res, status
 
 
