@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: many random sizes (single- and multi-workgroup finalize, ragged tails, autotuned tiles)
-and option sets; the chained solve (S = 8) must reproduce the one-trial-per-pass solve bit for bit,
+and option sets; the chained solves (S = 8 and S = 16) must reproduce the one-trial-per-pass solve bit for bit,
 and two runs of the same solve must be identical (no timing-dependent reduction anywhere)."""
 import os
 import sys
@@ -39,8 +39,9 @@ for k in range(cases):
              nesterov=bool(rng.integers(0, 2)), nesterov_ratio=(0, 0.25), deprecated=False)
     prob = DiagQuadL1(d, c, 0.1)
     x0 = torch.randn(n, dtype=torch.float64, device="cuda", generator=gen)
-    a, b, a2 = solve(prob, x0, o, 1), solve(prob, x0, o, 8), solve(prob, x0, o, 8)
-    same = all(np.array_equal(u, v) if isinstance(u, np.ndarray) else u == v for u, v in zip(a, b))
+    a, b, a2, c16 = solve(prob, x0, o, 1), solve(prob, x0, o, 8), solve(prob, x0, o, 8), solve(prob, x0, o, 16)
+    same = all(np.array_equal(u, v) if isinstance(u, np.ndarray) else u == v for u, v in zip(a, b)) and \
+        all(np.array_equal(u, v) if isinstance(u, np.ndarray) else u == v for u, v in zip(a, c16))
     rep = all(np.array_equal(u, v) if isinstance(u, np.ndarray) else u == v for u, v in zip(b, a2))
     if not (same and rep):
         bad += 1
