@@ -42,6 +42,51 @@ extern "C" int dual_native_solve(int m, const double* Q, const double* q, const 
     return rc ? rc : (ok ? 0 : 1);
 }
 
+// The same problem through the EXACT-HESSIAN mode of the machine (zf_dual::machine<M, true>): every point
+// comes with the Hessian of its quadratic piece, Q + 2 diag(kink_i [w_i > knot_i]) - no curvature probes.
+namespace {
+template <int M>
+int solve_xh(const problem& p, const double* w0, double tol, long max_iter, double* w, double* fun, long* nit,
+             int* evals, int* batches) {
+    using mach = zf_dual::machine<M, true>;
+    mach S;
+    S.start(w0, tol, max_iter);
+    double funs[mach::NB] = {0}, jacs[mach::NB][M] = {{0}}, hess[mach::NB * M * M] = {0};
+    *evals = *batches = 0;
+    while (!S.done()) {
+        for (int k = 0; k < S.npts; ++k) {
+            double jac[zf_dual::MAXM];
+            eval(const_cast<problem*>(&p), S.pts[k], &funs[k], jac);
+            for (int i = 0; i < M; ++i) {
+                jacs[k][i] = jac[i];
+                for (int j = 0; j < M; ++j)
+                    hess[(k * M + i) * M + j] = p.Q[i * M + j] + ((i == j && S.pts[k][i] > p.knot[i]) ? 2.0 * p.kink[i] : 0.0);
+            }
+            *evals += 1;
+        }
+        *batches += 1;
+        S.advance(funs, jacs, hess);
+    }
+    for (int i = 0; i < M; ++i) w[i] = S.w[i];
+    *fun = S.fun;
+    *nit = S.nit;
+    return S.ok ? 0 : 1;
+}
+}  // namespace
+
+extern "C" int dual_native_solve_exact_hessian(int m, const double* Q, const double* q, const double* kink,
+                                               const double* knot, const double* w0, double tol, long max_iter,
+                                               double* w, double* fun, long* nit, int* evals, int* batches) {
+    problem p = {m, Q, q, kink, knot};
+    switch (m) {
+        case 3: return solve_xh<3>(p, w0, tol, max_iter, w, fun, nit, evals, batches);
+        case 4: return solve_xh<4>(p, w0, tol, max_iter, w, fun, nit, evals, batches);
+        case 5: return solve_xh<5>(p, w0, tol, max_iter, w, fun, nit, evals, batches);
+        case 8: return solve_xh<8>(p, w0, tol, max_iter, w, fun, nit, evals, batches);
+        default: return -1;
+    }
+}
+
 extern "C" double dual_native_min_eig(int m, const double* Q) {
     double A[zf_dual::MAXM][zf_dual::MAXM];
     for (int i = 0; i < m; ++i)

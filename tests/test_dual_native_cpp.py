@@ -79,3 +79,26 @@ def test_min_eigenvalue(lib):
         A = 0.5 * (A + A.T)
         got = lib.dual_native_min_eig(C.c_int(m), np.ascontiguousarray(A).ctypes.data_as(C.c_void_p))
         assert abs(got - np.linalg.eigvalsh(A).min()) < 1e-10
+
+
+@pytest.mark.parametrize("m", [3, 4, 5, 8])
+@pytest.mark.parametrize("seed", range(6))
+def test_exact_hessian_mode_reaches_the_same_optimum_in_fewer_evaluations(lib, m, seed):
+    """zf_dual::machine<M, true> (the mode the device kernel runs, where the Hessian of the dual's quadratic
+    piece comes out of the same pass as the gradient): same optimum as the probing mode, without the m
+    curvature probes per Newton iteration."""
+    Q, q, kink, knot, dual = _problem(m, 100 * m + seed)
+    w_probe, f_probe, _, evals_probe = _solve_cpp(lib, m, Q, q, kink, knot)
+    w = np.zeros(m)
+    fun, nit, evals, batches = C.c_double(), C.c_long(), C.c_int(), C.c_int()
+    p = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p)   # noqa: E731
+    Qc, qc, kc, nc = (np.ascontiguousarray(a, dtype=np.float64) for a in (Q, q, kink, knot))
+    lib.dual_native_solve_exact_hessian.restype = C.c_int
+    rc = lib.dual_native_solve_exact_hessian(C.c_int(m), p(Qc), p(qc), p(kc), p(nc), None, C.c_double(1e-12),
+                                             C.c_long(200), w.ctypes.data_as(C.c_void_p), C.byref(fun), C.byref(nit),
+                                             C.byref(evals), C.byref(batches))
+    assert rc == 0
+    assert abs(w.sum() - 1) < 1e-12 and np.all(w >= 0)
+    np.testing.assert_allclose(w, w_probe, rtol=0, atol=1e-8)
+    assert abs(fun.value - f_probe) <= 1e-12 * max(1.0, abs(f_probe))
+    assert evals.value < evals_probe and batches.value <= evals.value

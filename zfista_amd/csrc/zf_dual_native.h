@@ -67,15 +67,21 @@ struct bracket_state {
 template <>
 struct bracket_state<false> {};
 
-template <int M>
+// EXACT_H (m >= 3): the caller hands in, with the value and the gradient of every point, the generalised
+// HESSIAN of the dual there (the dual of the shifted-l1 + box family is piecewise quadratic: its Hessian on
+// the piece a point sits in comes out of the same pass over the data as the gradient, zf_multiobj.hip).
+// The Newton model then needs no finite-difference probes: a Newton iteration is ONE batch (its line search,
+// whose accepted point brings its own Hessian) instead of two, and m evaluations fewer.
+template <int M, bool EXACT_H = false>
 struct machine {
     static_assert(M >= 2 && M <= MAXM, "2 <= m <= 8");
+    static constexpr bool XH = EXACT_H && M >= 3;
     enum { P_INIT, P_ENDS, P_BRACKET, P_FINAL, P_CURV, P_LS, P_REEVAL, P_DONE };
     static constexpr int N = M + 1;   // KKT systems of the simplex QP
     // largest batch: the start point together with its M curvature probes (m >= 3; the probes do not
     // depend on the values at the start point, and on the device a batch costs one grid-wide hand-over
     // whatever its size)
-    static constexpr int NB = M >= 3 ? M + 1 : LS_BATCH;
+    static constexpr int NB = (M >= 3 && !XH) ? M + 1 : LS_BATCH;
     // problem
     double tol;
     long max_iter;
@@ -377,11 +383,41 @@ struct machine {
     // curvature on the tangent space), the exact simplex QP, and the request for its line search.
     template <int OFF>
     ZF_DHD_INLINE void newton_step(const double (&jacs)[NB][M]) {
-        double HT[M][M], Q[M][M], q[M], w_new[M];
+        double HT[M][M];
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
             for (int r = 0; r < M; ++r) HT[r][i] = (jacs[(OFF + i) % NB][r] - grad[r]) / h;
+        newton_model(HT);
+    }
+    // exact-Hessian mode: H (m x m, flattened) is the generalised Hessian of the dual at w
+    ZF_DHD_INLINE void newton_from_hessian(const double (&H)[M][M]) {
+        double HT[M][M];
+#pragma unroll
+        for (int r = 0; r < M; ++r)
+#pragma unroll
+            for (int i = 0; i < M; ++i) T[r][i] = (r == i ? 1.0 : 0.0) - w[r];   // column i = e_i - w
+#pragma unroll
+        for (int r = 0; r < M; ++r)
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                double t = 0.0;
+#pragma unroll
+                for (int q2 = 0; q2 < M; ++q2) t += H[r][q2] * T[q2][i];
+                HT[r][i] = t;                                                      // H (e_i - w)
+            }
+        newton_model(HT);
+    }
+    // after an accepted Newton step in exact-Hessian mode: stop, or the next Newton model right away
+    ZF_DHD_INLINE void after_step_xh(const double (&H)[M][M]) {
+        if (t_acc * step <= tol) return finish(nit > max_iter ? max_iter : nit);
+        nit += 1;
+        if (nit > max_iter) return finish(max_iter);
+        newton_from_hessian(H);
+    }
+    // HT = H T (columns: the curvature along e_i - w) -> the model on the tangent space, the QP, the line search
+    ZF_DHD_INLINE void newton_model(const double (&HT)[M][M]) {
+        double Q[M][M], q[M], w_new[M];
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
@@ -456,11 +492,12 @@ struct machine {
 #pragma unroll
         for (int i = 0; i < M; ++i) pts[0][i] = w[i];
         phase = P_INIT;
-        if constexpr (M >= 3) request_curvature<1>();   // the start point and its curvature probes together
+        if constexpr (M >= 3 && !XH) request_curvature<1>();   // the start point and its curvature probes together
     }
 
     // funs[k], jacs[k][0..M): the dual and its gradient at pts[k], k < npts
-    ZF_DHD_INLINE void advance(const double (&funs)[NB], const double (&jacs)[NB][M]) {
+    // hess (exact-Hessian mode, else ignored / NULL): [NB][M][M] flattened, the Hessian of the dual at pts[k]
+    ZF_DHD_INLINE void advance(const double (&funs)[NB], const double (&jacs)[NB][M], const double* hess = nullptr) {
         switch (phase) {
         case P_INIT: {
             bool finite = isfinite(funs[0]);
@@ -479,6 +516,14 @@ struct machine {
                 pts[1][0] = 1.0, pts[1][1] = 0.0;
                 phase = P_ENDS;
                 return;
+            } else if constexpr (XH) {
+                nit = 1;
+                double H[M][M];
+#pragma unroll
+                for (int r = 0; r < M; ++r)
+#pragma unroll
+                    for (int q2 = 0; q2 < M; ++q2) H[r][q2] = hess[r * M + q2];
+                return newton_from_hessian(H);
             } else {
                 nit = 1;
                 return newton_step<1>(jacs);   // (m >= 3: the probes came with the start point)
@@ -547,8 +592,15 @@ struct machine {
             double t = t_base;
             bool picked = false;
             double f_pick = 0.0, g_pick[M], p_pick[M];
+            double H_pick[XH ? M : 1][XH ? M : 1];
 #pragma unroll
             for (int i = 0; i < M; ++i) g_pick[i] = p_pick[i] = 0.0;
+            if constexpr (XH) {
+#pragma unroll
+                for (int r = 0; r < M; ++r)
+#pragma unroll
+                    for (int q2 = 0; q2 < M; ++q2) H_pick[r][q2] = 0.0;
+            }
 #pragma unroll
             for (int k = 0; k < LS_BATCH; ++k) {
                 const bool take = !picked && (funs[k] <= fun + 1e-4 * t * slope + 1e-15 * fabs(fun) || t < 1e-10);
@@ -560,6 +612,12 @@ struct machine {
                     for (int i = 0; i < M; ++i) {
                         g_pick[i] = jacs[k][i];
                         p_pick[i] = pts[k][i];
+                    }
+                    if constexpr (XH) {
+#pragma unroll
+                        for (int r = 0; r < M; ++r)
+#pragma unroll
+                            for (int q2 = 0; q2 < M; ++q2) H_pick[r][q2] = hess[(k * M + r) * M + q2];
                     }
                 }
                 if (!picked) t *= 0.5;
@@ -588,13 +646,23 @@ struct machine {
             fun = f_pick;
 #pragma unroll
             for (int i = 0; i < M; ++i) grad[i] = g_pick[i];
-            return after_step();
+            if constexpr (XH) return after_step_xh(H_pick);
+            else return after_step();
         }
         case P_REEVAL: {
             fun = funs[0];
 #pragma unroll
             for (int i = 0; i < M; ++i) grad[i] = jacs[0][i];
-            return after_step();
+            if constexpr (XH) {
+                double H[M][M];
+#pragma unroll
+                for (int r = 0; r < M; ++r)
+#pragma unroll
+                    for (int q2 = 0; q2 < M; ++q2) H[r][q2] = hess[r * M + q2];
+                return after_step_xh(H);
+            } else {
+                return after_step();
+            }
         }
         default:
             return;
