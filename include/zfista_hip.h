@@ -371,6 +371,10 @@ int zf_mo_get_f_y(zf_mo* s, double* f_y_out /* m */);
 int zf_mo_set_jac(zf_mo* s, const double* J_host);              /* generic kind         :142 */
 /* out[0..m) = g_i(p), out[m] = |p-v|^2, out[m+1] = |w@J|^2, out[m+2..2m+2) = J_i.(p-y)   :162-173 */
 int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double* out);
+/* H_out (m x m): the generalised Hessian of the dual (:161-177) at w, d jac_i / d w_k on the quadratic piece w sits
+ * in - from the derivative of prox_wsum_g through its composed soft-thresholds and the clip (problems.py:126-138);
+ * what the device-side search builds its Newton model from instead of finite-difference probes.  m <= 5. */
+int zf_mo_dual_hessian(zf_mo* s, double lr, const double* w_host, double* H_out);
 /* the whole dual search of one trial inside the library (opt-in replacement of the two SciPy
  * calls :179-205): m = 2 bracketing root finder on the monotone derivative, m >= 3 projected
  * Newton on the simplex; every evaluation is one zf_mo_dual_eval.  *ok_out = 0: not attempted

@@ -531,3 +531,49 @@ def test_trials_launched_ahead_match_the_sequential_loop(case, monkeypatch):
             assert a.success and a.nit < 500
         if case == "jos1_short":
             assert a.nit == opts["max_iter"]
+
+
+@pytest.mark.parametrize("variant", ["l1", "l1_box", "box", "plain"])
+def test_dual_hessian_against_differences_of_the_gradient(variant):
+    """zf_mo_dual_hessian (the derivative of prox_wsum_g through its composed soft-thresholds and the clip,
+    accumulated as m x m sums: what the device-side search builds its Newton model from) against central
+    differences of the gradient of the dual (zf_mo_dual_eval), FDS m = 3 with / without l1 terms and box,
+    at random weights.  The dual is piecewise quadratic: inside a piece the two agree to the accuracy of the
+    differences."""
+    from zfista_amd.multiobjective import X_K
+    from zfista_amd.problems import FDS
+
+    n = 400
+    rng = np.random.default_rng(21)
+    kw = {}
+    if "l1" in variant:
+        kw.update(l1_ratios=np.array([0.7, 1.3, 0.4]) / n, l1_shifts=[0.0, 0.8, -0.5])
+    if "box" in variant:
+        kw.update(bounds=(-1.5, 1.5))
+    p = FDS(n, **kw)
+    eng = p._engine()
+    eng.set_x0(rng.uniform(-1.4, 1.4, n))
+    eng.eval_F(X_K)
+    eng.prepare()
+    m, lr = 3, 0.05
+
+    def grad(w):   # the gradient of the dual as :173-177 compose it (without the constant F_old - f_y)
+        g_p, _, _, dots = eng.dual_eval(lr, w)
+        return -g_p - dots
+
+    worst = 0.0
+    for _ in range(12):
+        w = rng.dirichlet(np.ones(m))
+        H = eng.dual_hessian(lr, w)
+        h = 1e-6
+        fd = np.zeros((m, m))
+        for k in range(m):
+            e = np.zeros(m)
+            e[k] = h
+            fd[:, k] = (grad(w + e) - grad(w - e)) / (2 * h)
+        scale = np.abs(fd).max()
+        worst = max(worst, np.abs(H - fd).max() / scale)
+        assert np.abs(H - H.T).max() <= 1e-9 * scale      # symmetric, as a Hessian is
+    # (a kink of some element may fall inside a difference interval: allow the odd piece change)
+    assert worst <= 2e-3
+    eng.close()

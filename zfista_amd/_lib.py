@@ -147,6 +147,7 @@ SIGNATURES = {
     "zf_mo_prepare": (C.c_int, [_P, _P]),
     "zf_mo_set_jac": (C.c_int, [_P, _P]),
     "zf_mo_dual_eval": (C.c_int, [_P, C.c_double, _P, _P]),
+    "zf_mo_dual_hessian": (C.c_int, [_P, C.c_double, _P, _P]),
     "zf_mo_solve_dual": (C.c_int, [_P, C.c_double, _P, _P, C.c_int32, _P, C.c_double, C.c_int64, _P,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int64)]),

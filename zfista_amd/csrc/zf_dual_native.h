@@ -408,13 +408,6 @@ struct machine {
             }
         newton_model(HT);
     }
-    // after an accepted Newton step in exact-Hessian mode: stop, or the next Newton model right away
-    ZF_DHD_INLINE void after_step_xh(const double (&H)[M][M]) {
-        if (t_acc * step <= tol) return finish(nit > max_iter ? max_iter : nit);
-        nit += 1;
-        if (nit > max_iter) return finish(max_iter);
-        newton_from_hessian(H);
-    }
     // HT = H T (columns: the curvature along e_i - w) -> the model on the tangent space, the QP, the line search
     ZF_DHD_INLINE void newton_model(const double (&HT)[M][M]) {
         double Q[M][M], q[M], w_new[M];
@@ -495,9 +488,108 @@ struct machine {
         if constexpr (M >= 3 && !XH) request_curvature<1>();   // the start point and its curvature probes together
     }
 
+    // exact-Hessian mode, first half of advance(): consumes the values of the batch; returns 1 / 2 with the
+    // Hessian at the (new) w in Hn when a Newton model is due, 0 when a request was issued or the search ended
+    ZF_DHD_INLINE int advance_pick(const double (&funs)[NB], const double (&jacs)[NB][M], const double* hess,
+                                   double (&Hn)[M][M]) {
+#pragma unroll
+        for (int r = 0; r < M; ++r)
+#pragma unroll
+            for (int q2 = 0; q2 < M; ++q2) Hn[r][q2] = 0.0;
+        if (phase == P_INIT || phase == P_REEVAL) {
+            if (phase == P_INIT) {
+                bool finite = isfinite(funs[0]);
+#pragma unroll
+                for (int i = 0; i < M; ++i) finite = finite && isfinite(jacs[0][i]);
+                if (!finite) {   // e.g. F(x_k) = inf outside the box: not attempted
+                    ok = 0;
+                    finish(0);
+                    return 0;
+                }
+                nit = 1;
+            }
+            const int todo = phase == P_INIT ? 1 : 2;
+            fun = funs[0];
+#pragma unroll
+            for (int i = 0; i < M; ++i) grad[i] = jacs[0][i];
+#pragma unroll
+            for (int r = 0; r < M; ++r)
+#pragma unroll
+                for (int q2 = 0; q2 < M; ++q2) Hn[r][q2] = hess[r * M + q2];
+            return todo;
+        }
+        if (phase != P_LS) return 0;
+        double t = t_base;
+        bool picked = false;
+        double f_pick = 0.0, g_pick[M], p_pick[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) g_pick[i] = p_pick[i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < LS_BATCH; ++k) {
+            const bool take = !picked && (funs[k] <= fun + 1e-4 * t * slope + 1e-15 * fabs(fun) || t < 1e-10);
+            if (take) {
+                picked = true;
+                t_acc = t;
+                f_pick = funs[k];
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    g_pick[i] = jacs[k][i];
+                    p_pick[i] = pts[k][i];
+                }
+#pragma unroll
+                for (int r = 0; r < M; ++r)
+#pragma unroll
+                    for (int q2 = 0; q2 < M; ++q2) Hn[r][q2] = hess[(k * M + r) * M + q2];
+            }
+            if (!picked) t *= 0.5;
+        }
+        if (!picked) {
+            request_line_search(t);   // (t is already halved past the batch)
+            return 0;
+        }
+        bool moved = false;
+        double wq[M], sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            wq[i] = p_pick[i] > 0.0 ? p_pick[i] : 0.0;
+            sum += wq[i];
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            wq[i] /= sum;
+            if (wq[i] != p_pick[i]) moved = true;
+            w[i] = wq[i];
+        }
+        if (t_acc < 1.0 || moved) {
+            npts = 1;
+#pragma unroll
+            for (int i = 0; i < M; ++i) pts[0][i] = w[i];
+            phase = P_REEVAL;
+            return 0;
+        }
+        fun = f_pick;
+#pragma unroll
+        for (int i = 0; i < M; ++i) grad[i] = g_pick[i];
+        return 2;
+    }
+
     // funs[k], jacs[k][0..M): the dual and its gradient at pts[k], k < npts
     // hess (exact-Hessian mode, else ignored / NULL): [NB][M][M] flattened, the Hessian of the dual at pts[k]
     ZF_DHD_INLINE void advance(const double (&funs)[NB], const double (&jacs)[NB][M], const double* hess = nullptr) {
+        if constexpr (XH) {
+            // exact-Hessian mode: the cases below only pick the point and its Hessian; the Newton model is
+            // built at ONE place (three inlined copies of the QP and the eigenvalue sweep cost the device
+            // kernel its register budget)
+            double Hn[M][M];
+            const int todo = advance_pick(funs, jacs, hess, Hn);   // 0: request issued / done, 1: first model, 2: after a step
+            if (todo == 2) {
+                if (t_acc * step <= tol) return finish(nit > max_iter ? max_iter : nit);
+                nit += 1;
+                if (nit > max_iter) return finish(max_iter);
+            }
+            if (todo) newton_from_hessian(Hn);
+            return;
+        }
         switch (phase) {
         case P_INIT: {
             bool finite = isfinite(funs[0]);
@@ -516,14 +608,6 @@ struct machine {
                 pts[1][0] = 1.0, pts[1][1] = 0.0;
                 phase = P_ENDS;
                 return;
-            } else if constexpr (XH) {
-                nit = 1;
-                double H[M][M];
-#pragma unroll
-                for (int r = 0; r < M; ++r)
-#pragma unroll
-                    for (int q2 = 0; q2 < M; ++q2) H[r][q2] = hess[r * M + q2];
-                return newton_from_hessian(H);
             } else {
                 nit = 1;
                 return newton_step<1>(jacs);   // (m >= 3: the probes came with the start point)
@@ -592,15 +676,8 @@ struct machine {
             double t = t_base;
             bool picked = false;
             double f_pick = 0.0, g_pick[M], p_pick[M];
-            double H_pick[XH ? M : 1][XH ? M : 1];
 #pragma unroll
             for (int i = 0; i < M; ++i) g_pick[i] = p_pick[i] = 0.0;
-            if constexpr (XH) {
-#pragma unroll
-                for (int r = 0; r < M; ++r)
-#pragma unroll
-                    for (int q2 = 0; q2 < M; ++q2) H_pick[r][q2] = 0.0;
-            }
 #pragma unroll
             for (int k = 0; k < LS_BATCH; ++k) {
                 const bool take = !picked && (funs[k] <= fun + 1e-4 * t * slope + 1e-15 * fabs(fun) || t < 1e-10);
@@ -612,12 +689,6 @@ struct machine {
                     for (int i = 0; i < M; ++i) {
                         g_pick[i] = jacs[k][i];
                         p_pick[i] = pts[k][i];
-                    }
-                    if constexpr (XH) {
-#pragma unroll
-                        for (int r = 0; r < M; ++r)
-#pragma unroll
-                            for (int q2 = 0; q2 < M; ++q2) H_pick[r][q2] = hess[(k * M + r) * M + q2];
                     }
                 }
                 if (!picked) t *= 0.5;
@@ -646,23 +717,13 @@ struct machine {
             fun = f_pick;
 #pragma unroll
             for (int i = 0; i < M; ++i) grad[i] = g_pick[i];
-            if constexpr (XH) return after_step_xh(H_pick);
-            else return after_step();
+            return after_step();
         }
         case P_REEVAL: {
             fun = funs[0];
 #pragma unroll
             for (int i = 0; i < M; ++i) grad[i] = jacs[0][i];
-            if constexpr (XH) {
-                double H[M][M];
-#pragma unroll
-                for (int r = 0; r < M; ++r)
-#pragma unroll
-                    for (int q2 = 0; q2 < M; ++q2) H[r][q2] = hess[r * M + q2];
-                return after_step_xh(H);
-            } else {
-                return after_step();
-            }
+            return after_step();
         }
         default:
             return;

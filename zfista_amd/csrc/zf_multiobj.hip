@@ -371,6 +371,118 @@ __device__ __forceinline__ void mo_dual_terms(const mo_g& G, const double (&w)[M
     for (int i = 0; i < M; ++i) acc[M + 2 + i] += Jc[i] * dy;
 }
 
+// prox_wsum_g with its derivatives (forward mode through the composed soft-thresholds and the clip,
+// problems.py:126-138): dv = d prox / d x, dc[k] = d prox / d coef_k.  The prox is piecewise linear in
+// (x, coef): on the piece the point sits in these are exact (0 / +-1 patterns).
+template <int M>
+__device__ __forceinline__ double mo_prox_ad(const mo_g& G, const double (&coef)[M], double tail_sum, double x, int64_t j,
+                                             double& dv, double (&dc)[M]) {
+    dv = 1.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) dc[k] = 0.0;
+    if (G.has_l1) {
+        {   // stage 0: soft-threshold of x + sum(coef[1:]) at coef[0]
+            const double u = x + tail_sum - G.shift[0] + G.shift[0];
+            const double act = fabs(u) > coef[0] ? 1.0 : 0.0;
+            const double sg = u < 0.0 ? -1.0 : 1.0;
+            x = zf_soft_threshold(u, coef[0]);
+            dv = act;
+            dc[0] = -sg * act;
+#pragma unroll
+            for (int k = 1; k < M; ++k) dc[k] = act;
+        }
+#pragma unroll
+        for (int i = 1; i < M; ++i) {   // stage i: soft-threshold of x - coef[i] - shift[i] at coef[i], shifted back
+            const double u = x - coef[i] - G.shift[i];
+            const double act = fabs(u) > coef[i] ? 1.0 : 0.0;
+            const double sg = u < 0.0 ? -1.0 : 1.0;
+            x = zf_soft_threshold(u, coef[i]) + G.shift[i];
+            dv *= act;
+#pragma unroll
+            for (int k = 0; k < M; ++k) dc[k] = act * (dc[k] - (k == i ? 1.0 : 0.0));
+            dc[i] -= sg * act;
+        }
+    }
+    if (G.has_box) {
+        const double lo = G.lo_v ? G.lo_v[j] : G.lo, hi = G.hi_v ? G.hi_v[j] : G.hi;
+        const double inside = (x >= lo && x <= hi) ? 1.0 : 0.0;
+        x = zf_clip(x, lo, hi);
+        dv *= inside;
+#pragma unroll
+        for (int k = 0; k < M; ++k) dc[k] *= inside;
+    }
+    return x;
+}
+
+// mo_dual_terms plus the M x M sums of the generalised HESSIAN of the dual (acc[2M + 2 + i M + k]):
+//   jac_i = - ratio_i sum_j |p_j - s_i| - sum_j J_ij (p_j - y_j) + const            (:173-177)
+//   d p_j / d w_k = lr (- P_j J_kj + ratio_k c_kj)      (v = y - lr w@J, coef_k = lr w_k ratio_k)
+//   H_ik = d jac_i / d w_k = lr sum_j (ratio_i sign(p_j - s_i) + J_ij) (P_j J_kj - ratio_k c_kj)
+// (the factor lr is applied to the totals)
+template <int M, int NQP>
+__device__ __forceinline__ void mo_dual_terms_h(const mo_g& G, const double (&w)[M], const double (&coef)[M],
+                                                double tail_sum, double lr, const double (&Jc)[M], double yj, int64_t j,
+                                                double (&acc)[NQP]) {
+    double wJ = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) wJ += w[i] * Jc[i];
+    const double v = yj - lr * wJ;
+    double P, c[M];
+    const double p = mo_prox_ad<M>(G, coef, tail_sum, v, j, P, c);
+    double a[M], b[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const double e = p - G.shift[i];
+        acc[i] += fabs(e);
+        const double sg = e > 0.0 ? 1.0 : (e < 0.0 ? -1.0 : 0.0);
+        // (the Hessian only steers the Newton model: its sums take fused multiply-adds; the 2m + 2 sums of the
+        //  reference's formulas below keep their NumPy rounding)
+        a[i] = G.has_l1 ? __builtin_fma(G.ratio[i], sg, Jc[i]) : Jc[i];
+        b[i] = G.has_l1 ? __builtin_fma(-G.ratio[i], c[i], P * Jc[i]) : P * Jc[i];
+    }
+    const double dv = p - v;
+    acc[M] += dv * dv;
+    acc[M + 1] += wJ * wJ;
+    const double dy = p - yj;
+#pragma unroll
+    for (int i = 0; i < M; ++i) acc[M + 2 + i] += Jc[i] * dy;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int k = 0; k < M; ++k) acc[2 * M + 2 + i * M + k] = __builtin_fma(a[i], b[k], acc[2 * M + 2 + i * M + k]);
+}
+
+// the Hessian sums alone, over J and y in global memory (zf_mo_dual_hessian: the check of the formulas
+// above against differences of the gradient; the search itself takes them inside k_dual_solve)
+template <int M>
+__global__ __launch_bounds__(ZF_BLOCK) void k_dual_hessian(const double* __restrict__ J, const double* __restrict__ y,
+                                                           mo_g G, mo_w W, int64_t n, double* partials) {
+    constexpr int NQP = 2 * M + 2 + M * M;
+    __shared__ double lds[ZF_WAVES * M * M];
+    double acc[NQP], w[M], coef[M];
+#pragma unroll
+    for (int k = 0; k < NQP; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        w[i] = W.w[i];
+        coef[i] = W.coef[i];
+    }
+    const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {
+        double Jc[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) Jc[i] = J[(int64_t)i * n + j];
+        mo_dual_terms_h<M, NQP>(G, w, coef, W.tail_sum, W.lr, Jc, y[j], j, acc);
+    }
+    double hs[M * M];
+#pragma unroll
+    for (int q = 0; q < M * M; ++q) hs[q] = acc[2 * M + 2 + q];
+    const double maxs[1] = {0.0};
+    double out = 0.0;
+    zf_block_reduce<M * M, 0, ZF_WAVES>(hs, maxs, lds, out);
+    if (threadIdx.x < M * M) partials[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = out;
+}
+
 // Grid-wide hand-over of `count` doubles per workgroup WITHOUT atomics, flags or fences: every value
 // travels as a self-validating 16-byte record {bits(v), bits(v) ^ key}, key unique per launch and
 // batch.  Workgroup 0 polls the records of all workgroups (a torn or stale record fails the check and
@@ -490,13 +602,13 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
 // (A first version kept the resident elements in 64 registers per thread: together with this step
 // the kernel needed > 256 VGPRs and spilled; the elements now live in LDS.)
 template <int M>
-__device__ __forceinline__ void mo_machine_step(zf_dual::machine<M>* s_mach, const double* s_fun,
-                                                          const double (*s_jac)[M]) {
-    constexpr int NB = zf_dual::machine<M>::NB;
-    zf_dual::machine<M> mach = *s_mach;
+__device__ __forceinline__ void mo_machine_step(zf_dual::machine<M, true>* s_mach, const double* s_fun,
+                                                const double (*s_jac)[M], const double* s_hess) {
+    constexpr int NB = zf_dual::machine<M, true>::NB;
+    zf_dual::machine<M, true> mach = *s_mach;
     // (the values of the batch are read where they are used, at constant indices, straight from LDS:
     //  a register copy of all NB x (M + 1) of them beside the machine spilled)
-    mach.advance(*reinterpret_cast<const double(*)[NB]>(s_fun), *reinterpret_cast<const double(*)[NB][M]>(s_jac));
+    mach.advance(*reinterpret_cast<const double(*)[NB]>(s_fun), *reinterpret_cast<const double(*)[NB][M]>(s_jac), s_hess);
     *s_mach = mach;
 }
 
@@ -508,11 +620,20 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
     // copy (constant indices throughout: no scratch, no dependent LDS round trips inside the
     // dense helpers) - its ~100 registers are then live only inside that step, not across the
     // evaluation loops that hold the resident elements.
-    constexpr int NB = zf_dual::machine<M>::NB;
-    __shared__ zf_dual::machine<M> s_mach;
+    // the machine in its exact-Hessian mode (m >= 3): every point comes with the Hessian of the dual there,
+    // accumulated in the same pass as the gradient (mo_dual_terms_h) - no curvature probes, a Newton
+    // iteration is ONE batch.  NQP sums per point: the 2m + 2 of the reference's formulas + m x m (+ padding)
+    using mach_t = zf_dual::machine<M, true>;
+    constexpr int NB = mach_t::NB;
+    constexpr bool XH = mach_t::XH;
+    constexpr int NQP = (NQ + (XH ? M * M : 0) + 1) & ~1;
+    constexpr int REC_CAP = zf_dual::MAXB * (2 * MO_MAX_M + 2);   // records per parity (the host allocates 2 x this)
+    static_assert(NB * NQP <= REC_CAP, "hand-over buffers too small");
+    __shared__ mach_t s_mach;
+    __shared__ double s_hess[NB * M * M];
     __shared__ double s_w[NB][M], s_coef[NB][M], s_tail[NB];
-    __shared__ double s_red[MO_SOLVE_WAVES * NB * NQ];
-    __shared__ double s_mine[NB * NQ], s_tot[NB * NQ];
+    __shared__ double s_red[MO_SOLVE_WAVES * NB * NQP];
+    __shared__ double s_mine[NB * NQP], s_tot[NB * NQP];
     __shared__ double s_fun[NB], s_jac[NB][M];
     __shared__ int s_flag;
     __shared__ double s_fy[M];   // f(y): given (host value / zf_mo_prepare_async) or formed by the prologue below
@@ -649,7 +770,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         }
     }
     if (tid == 0) {
-        zf_dual::machine<M> mach;
+        mach_t mach;
         mach.start(A.has_w0 ? A.w0 : nullptr, A.tol, (long)A.max_iter);
         s_mach = mach;
     }
@@ -679,9 +800,9 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             // at once held 120 VGPRs of sums and weights, more than the kernel can spare), the sums of a
             // group with ONE transposing butterfly per wave (zf_wave_reduce_multi: the pairing of a
             // shuffle tree per quantity), then the wave totals in wave order
-            constexpr int GP = 2;
-            constexpr int NV = NB * NQ;
-            constexpr int GV = GP * NQ;
+            constexpr int GP = XH ? 1 : 2;   // (with the m x m Hessian sums a point is 18 sums: one point per pass)
+            constexpr int NV = NB * NQP;
+            constexpr int GV = GP * NQP;
             constexpr int H = (GV % 8 == 0) ? 3 : (GV % 4 == 0) ? 2 : (GV % 2 == 0) ? 1 : 0;
             const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -704,12 +825,24 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
 #pragma unroll
                         for (int k = 0; k < GP; ++k) {
                             if (kb + k < npts) {
-                                double a8[NQ];
+                                double a8[NQP];
 #pragma unroll
-                                for (int q = 0; q < NQ; ++q) a8[q] = acc[k * NQ + q];
-                                mo_dual_terms<M>(A.G, w[k], coef[k], tail[k], A.lr, Jc, yj, j, a8);
+                                for (int q = 0; q < NQP; ++q) a8[q] = acc[k * NQP + q];
+                                // the Hessian sums only for point 0 of a batch: the machine uses the Hessian of a
+                                // line-search point only if the FIRST step length is accepted (a shorter step is
+                                // re-evaluated, zf_dual::machine::advance_pick), and they cost 1.4 x the rest
+                                if (XH && kb + k == 0) {
+                                    mo_dual_terms_h<M, NQP>(A.G, w[k], coef[k], tail[k], A.lr, Jc, yj, j, a8);
+                                } else {
+                                    double a0[NQ];
 #pragma unroll
-                                for (int q = 0; q < NQ; ++q) acc[k * NQ + q] = a8[q];
+                                    for (int q = 0; q < NQ; ++q) a0[q] = a8[q];
+                                    mo_dual_terms<M>(A.G, w[k], coef[k], tail[k], A.lr, Jc, yj, j, a0);
+#pragma unroll
+                                    for (int q = 0; q < NQ; ++q) a8[q] = a0[q];
+                                }
+#pragma unroll
+                                for (int q = 0; q < NQP; ++q) acc[k * NQP + q] = a8[q];
                             }
                         }
                     };
@@ -731,7 +864,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
                     if ((lane & ((64 >> H) - 1)) == 0) {
 #pragma unroll
                         for (int q = 0; q < (GV >> H); ++q) {
-                            const int idx = kb * NQ + zf_wave_reduce_multi_index<GV, H>(q, lane);
+                            const int idx = kb * NQP + zf_wave_reduce_multi_index<GV, H>(q, lane);
                             if (idx < NV) s_red[wave * NV + idx] = acc[q];
                         }
                     }
@@ -747,11 +880,11 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             __syncthreads();
         }
         const int parity = (int)(epoch & 1u);
-        const int cnt = npts * NQ;
+        const int cnt = npts * NQP;
         const int64_t c1 = clock64();
         c_eval += c1 - c0;
-        if (!mo_grid_combine<(NB * NQ + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, cnt, -1, A.partials + 2 * ((int64_t)parity * zf_dual::MAXB * NQ * gridDim.x),
-                             A.totals + 2 * (parity * zf_dual::MAXB * NQ), A.nonce, epoch, s_tot, &s_flag)) {
+        if (!mo_grid_combine<(NB * NQP + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, cnt, -1, A.partials + 2 * ((int64_t)parity * REC_CAP * gridDim.x),
+                             A.totals + 2 * (parity * REC_CAP), A.nonce, epoch, s_tot, &s_flag)) {
             timed_out = 1;
             break;
         }
@@ -761,7 +894,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         const int64_t c2 = clock64();
         c_comb += c2 - c1;
         if (tid < npts) {   // D(w), grad D(w) of point `tid` from the grid totals (:165-177)
-            const double* t = s_tot + tid * NQ;
+            const double* t = s_tot + tid * NQP;
             double g_p[M], inner = 0.0;
 #pragma unroll
             for (int i = 0; i < M; ++i) {
@@ -783,11 +916,15 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             }
             if (!A.deprecated) f += corr;
             s_fun[tid] = f;
+            if constexpr (XH) {   // the Hessian of the dual at point `tid` (symmetrised by the machine)
+#pragma unroll
+                for (int q = 0; q < M * M; ++q) s_hess[tid * M * M + q] = A.lr * t[NQ + q];
+            }
         }
         __syncthreads();
         // wave 0, all 64 lanes on identical copies of the state (same LDS words in, same words out):
         // the support enumeration of the simplex QP runs lane-parallel (zf_dual::machine::simplex_qp)
-        if (tid < 64) mo_machine_step<M>(&s_mach, s_fun, s_jac);   // (inlined: see above)
+        if (tid < 64) mo_machine_step<M>(&s_mach, s_fun, s_jac, s_hess);   // (inlined: see above)
         __syncthreads();
         c_step += clock64() - c2;
     }
@@ -874,8 +1011,8 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         }
         __syncthreads();
         const int parity = (int)(epoch & 1u);
-        if (!mo_grid_combine<(NT + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, NT, 0, A.partials + 2 * ((int64_t)parity * zf_dual::MAXB * NQ * gridDim.x),
-                             A.totals + 2 * (parity * zf_dual::MAXB * NQ), A.nonce, epoch, s_tot, &s_flag))
+        if (!mo_grid_combine<(NT + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, NT, 0, A.partials + 2 * ((int64_t)parity * REC_CAP * gridDim.x),
+                             A.totals + 2 * (parity * REC_CAP), A.nonce, epoch, s_tot, &s_flag))
             timed_out = 1;
     }
     if (blockIdx.x == 0 && tid == 0) {
@@ -1301,6 +1438,28 @@ extern "C" int zf_mo_dual_eval(zf_mo* s, double lr, const double* w_host, double
     int rc = mo_reduce_to_host(s, 2 * m + 2, -1, out);
     if (rc) return rc;
     for (int i = 0; i < m; ++i) out[i] = s->G.has_l1 ? s->G.ratio[i] * out[i] : 0.0;
+    return ZF_OK;
+}
+
+// H_out (m x m, row-major): the generalised Hessian of the dual at w - d jac_i / d w_k on the quadratic piece w
+// sits in (what the device-side search feeds its Newton model with; m <= 5: the reduction carries m x m sums)
+extern "C" int zf_mo_dual_hessian(zf_mo* s, double lr, const double* w_host, double* H_out) {
+    ZF_REQUIRE(s && w_host && H_out, "zf_mo_dual_hessian: null argument");
+    ZF_REQUIRE(s->m <= 5, "zf_mo_dual_hessian: m <= 5");
+    if (int rc = mo_flush(s)) return rc;
+    mo_w W;
+    mo_fill_w(s, lr, w_host, &W);
+    const int m = s->m;
+    switch (m) {
+        case 2: hipLaunchKernelGGL(k_dual_hessian<2>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials); break;
+        case 3: hipLaunchKernelGGL(k_dual_hessian<3>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials); break;
+        case 4: hipLaunchKernelGGL(k_dual_hessian<4>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials); break;
+        default: hipLaunchKernelGGL(k_dual_hessian<5>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n, s->partials); break;
+    }
+    ZF_HIP(hipGetLastError());
+    int rc = mo_reduce_to_host(s, m * m, -1, H_out);
+    if (rc) return rc;
+    for (int q = 0; q < m * m; ++q) H_out[q] *= lr;
     return ZF_OK;
 }
 

@@ -183,6 +183,14 @@ class MoEngine:
         out = ob.copy()
         return out[:m], out[m], out[m + 1], out[m + 2:]
 
+    def dual_hessian(self, lr, w):
+        """The generalised Hessian of the dual at w (m x m), as the device-side search uses it."""
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        H = np.zeros((self.m, self.m))
+        self._check(self.lib.zf_mo_dual_hessian(self.h, float(lr), C.c_void_p(_lib.ptr(w)), C.c_void_p(_lib.ptr(H))),
+                    "zf_mo_dual_hessian")
+        return H
+
     def solve_dual(self, lr, f_y, F_old, deprecated, w0, tol, max_iter):
         """The whole dual search of a trial inside the library (zf_mo_solve_dual; opt-in,
         ZF_DUAL_SOLVER=native).  Returns (weight, fun, nit) or None when it was not attempted
