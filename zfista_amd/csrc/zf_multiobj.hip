@@ -534,17 +534,27 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
             }
         unsigned spins = 0;
         while (pending) {
+            // all records of this lane in flight at once, then the checks: loading one record, checking it
+            // and only then loading the next made a poll QW x GL dependent round trips to memory
+            mo_u64 rlo[QW][GL], rhi[QW][GL];
+#pragma unroll
+            for (int a = 0; a < QW; ++a)
+#pragma unroll
+                for (int c = 0; c < GL; ++c) {
+                    int q = wave + a * MO_SOLVE_WAVES, g = lane + 64 * c;
+                    q = q < count ? q : 0;   // (out-of-range slots re-read a valid record; their pending bit is clear)
+                    g = g < G ? g : 0;
+                    const mo_u64* r = partials + 2 * ((int64_t)q * G + g);
+                    rlo[a][c] = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    rhi[a][c] = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
 #pragma unroll
             for (int a = 0; a < QW; ++a)
 #pragma unroll
                 for (int c = 0; c < GL; ++c)
-                    if (pending & (1u << (a * GL + c))) {
-                        const int q = wave + a * MO_SOLVE_WAVES, g = lane + 64 * c;
-                        double v;
-                        if (mo_get(partials + 2 * ((int64_t)q * G + g), key, &v)) {
-                            pv[a][c] = v;
-                            pending &= ~(1u << (a * GL + c));
-                        }
+                    if ((pending & (1u << (a * GL + c))) && (rlo[a][c] ^ rhi[a][c]) == key) {
+                        pv[a][c] = __longlong_as_double((long long)rlo[a][c]);
+                        pending &= ~(1u << (a * GL + c));
                     }
             if (pending) {
                 __builtin_amdgcn_s_sleep(2);   // (do not hammer the memory system while the others still compute)
