@@ -643,11 +643,13 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
     __shared__ double s_hess[NB * M * M];
     __shared__ double s_w[NB][M], s_coef[NB][M], s_tail[NB];
     __shared__ double s_red[MO_SOLVE_WAVES * NB * NQP];
-    __shared__ double s_mine[NB * NQP], s_tot[NB * NQP];
+    __shared__ double s_mine[NB * NQP + 2], s_tot[NB * NQP + 2];
     __shared__ double s_fun[NB], s_jac[NB][M];
     __shared__ int s_flag;
     __shared__ double s_fy[M];   // f(y): given (host value / zf_mo_prepare_async) or formed by the prologue below
     __shared__ double s_Fold[M];
+    __shared__ double s_prep[4];   // m = 2: the sums of f(y) waiting for the first hand-over of the search
+    int prep_merge = 0;
     const int tid = threadIdx.x;
     if (A.gate && *A.gate != 1) {   // launched ahead of a trial that was then not accepted: nothing may be touched
         if (blockIdx.x == 0 && tid == 0) {
@@ -735,9 +737,16 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             }
             __syncthreads();
         }
-        if (!mo_grid_combine<1>(s_mine, NP, -1, A.partials, A.totals, A.nonce, epoch, s_tot, &s_flag)) timed_out = 1;
-        epoch += 1;
-        if (tid == 0) {
+        if constexpr (M == 2) {
+            // JOS1: the rows of J need none of the sums (2 y / n, 2 (y - 2) / n) - the two sums of f(y) ride
+            // along with the first batch of the search instead of a hand-over of their own
+            if (tid < NP) s_prep[tid] = s_mine[tid];
+            prep_merge = 1;
+        } else {
+            if (!mo_grid_combine<1>(s_mine, NP, -1, A.partials, A.totals, A.nonce, epoch, s_tot, &s_flag)) timed_out = 1;
+            epoch += 1;
+        }
+        if (M != 2 && tid == 0) {
             double t4[4] = {0.0, 0.0, 0.0, 0.0}, fy[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < NP; ++q) t4[q] = s_tot[q];
@@ -890,15 +899,33 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             __syncthreads();
         }
         const int parity = (int)(epoch & 1u);
-        const int cnt = npts * NQP;
+        const int extra = (prep_merge && batches == 0) ? 2 : 0;
+        const int cnt = npts * NQP + extra;
+        if (extra) {
+            if (tid < 2) s_mine[npts * NQP + tid] = s_prep[tid];
+            __syncthreads();
+        }
         const int64_t c1 = clock64();
         c_eval += c1 - c0;
-        if (!mo_grid_combine<(NB * NQP + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, cnt, -1, A.partials + 2 * ((int64_t)parity * REC_CAP * gridDim.x),
+        if (!mo_grid_combine<(NB * NQP + 2 + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, cnt, -1, A.partials + 2 * ((int64_t)parity * REC_CAP * gridDim.x),
                              A.totals + 2 * (parity * REC_CAP), A.nonce, epoch, s_tot, &s_flag)) {
             timed_out = 1;
             break;
         }
         epoch += 1;
+        if (extra) {   // f(y) of JOS1 from the two sums that came with this hand-over (problems.py:193-197)
+            if (tid == 0) {
+                const double t4[4] = {s_tot[npts * NQP], s_tot[npts * NQP + 1], 0.0, 0.0};
+                double fy[3] = {0.0, 0.0, 0.0};
+                mo_f_from_sums(ZF_MO_JOS1, (double)n, t4, fy);
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    s_fy[i] = fy[i < 3 ? i : 0];
+                    if (blockIdx.x == 0) A.f_y_w[i] = fy[i < 3 ? i : 0];
+                }
+            }
+            __syncthreads();
+        }
         batches += 1;
         evals += npts;
         const int64_t c2 = clock64();
