@@ -404,6 +404,9 @@ static void zf_launch_finalize(zf_solver* s, bool decide) {
     F.trace = s->trace;
     F.beta_ring = s->beta_ring;
     int wgs = (s->grid + ZF_FIN_THREADS - 1) / ZF_FIN_THREADS;   // no more workgroups than slices of work
+    // up to 1024 rows of partials one workgroup (four rows per thread) does it alone: publishing slice sums,
+    // the ticket and the last arriver's gather are three dependent round trips to memory (~7 us of a ~20 us kernel)
+    if (s->grid <= 1024) wgs = 1;
     if (wgs > ZF_FIN_WGS) wgs = ZF_FIN_WGS;
     if (wgs < 1) wgs = 1;
     if (s->sub == 16) hipLaunchKernelGGL(zf_finalize_kernel<16>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
