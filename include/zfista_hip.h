@@ -15,6 +15,12 @@
  * hipStream_t passed as void* (NULL = the default stream).  One solver object
  * per host thread/process and GPU; stream-ordered; thread-compatible, not
  * thread-safe.
+ *
+ * Caller-owned output memory is SIZED (ABI 4): every entry point that writes a struct or a
+ * library-defined amount of data into caller memory takes the capacity of that buffer and
+ * returns ZF_ERR_ARG - writing nothing - when it is too small (a host compiled against an
+ * older, smaller zf_control is refused instead of overrun).  Arrays whose length is an
+ * argument of the same call (n, m) are the caller's to size.
  */
 #ifndef ZFISTA_HIP_H
 #define ZFISTA_HIP_H
@@ -25,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZF_ABI_VERSION 3
+#define ZF_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------ */
 #define ZF_OK 0
@@ -175,7 +181,8 @@ int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int
  * the control logic of proximal_gradient.py:279-307,510,525-543 can be tested
  * on a machine without a GPU.  `packs` holds `world` packs of ZF_PACK_LEN
  * doubles; `trace` is a ZF_RING x ZF_TRACE_COLS ring. */
-int zf_decide_host(zf_control* ctl, const double* packs, double* trace);
+int zf_decide_host(zf_control* ctl, int64_t ctl_bytes /* == zf_sizeof_control() */, const double* packs,
+                   double* trace);
 
 /* ---- device-resident single-objective solver -----------------------------
  * Replaces the body of the outer loop, proximal_gradient.py:474-538, for the
@@ -248,26 +255,29 @@ int zf_solver_svec_ptrs(zf_solver* s, double** s_part_dev, double** s_all_dev);
 int zf_solver_set_svec_buffers(zf_solver* s, double* s_part_dev, double* s_all_dev);
 int zf_solver_enqueue_trial_finish(zf_solver* s);
 int zf_solver_enqueue_init_finish(zf_solver* s);
-/* synchronise the stream, copy out the control block and the trace ring */
-int zf_solver_poll(zf_solver* s, zf_control* ctl_host, double* trace_host /* ZF_RING*ZF_TRACE_COLS */);
+/* synchronise the stream, copy out the control block and (trace_host != NULL) the trace ring.
+ * ctl_bytes / trace_bytes: capacity of the two host buffers; ZF_ERR_ARG, nothing written, unless
+ * ctl_bytes >= zf_sizeof_control() and trace_bytes >= ZF_RING * ZF_TRACE_COLS * 8 */
+int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_bytes, double* trace_host, int64_t trace_bytes);
 /* device address / host copy of the latest accepted iterate x_k (local shard) */
 int zf_solver_x_dev(zf_solver* s, const double** x_dev);
-int zf_solver_get_x(zf_solver* s, double* x_host);
+int zf_solver_get_x(zf_solver* s, double* x_host, int64_t count /* capacity in doubles, >= n */);
 /* average duration (ms) of the trial kernel over the launches since the last
  * call, measured with HIP events on the solver's stream; resets the window */
 /* checkpoint / resume: zf_solver_poll + zf_solver_get_x + zf_solver_get_x_prev are the state of a
  * solve (x_k, x_{k-1}, control block); zf_solver_restore puts it into a freshly created solver
  * instead of zf_solver_enqueue_init(+_commit), after which the host re-uploads the momentum
  * factors from accepted count `nit` on.  The resumed solve continues bit for bit. */
-int zf_solver_get_x_prev(zf_solver* s, double* x_host);
-int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev, const zf_control* saved);
+int zf_solver_get_x_prev(zf_solver* s, double* x_host, int64_t count /* >= n */);
+int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev, const zf_control* saved,
+                      int64_t saved_bytes /* == zf_sizeof_control(): a block of another layout is refused */);
 int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches);
 /* the same window split by the shape of the pass, which the kernel logs itself: out[0], out[1] = mean
  * ms and count of full chains (sub_iters fresh trials, nothing replayed); out[2], out[3] = every other
  * pass (shorter chains, replays, materialise-only).  Resets the window. */
-int zf_solver_pass_stats(zf_solver* s, double out4[4]);
+int zf_solver_pass_stats(zf_solver* s, double* out, int64_t count /* >= 4 */);
 /* the same window plus out[4] = fresh trials and out[5] = replayed iterations the other passes carried */
-int zf_solver_pass_stats_ex(zf_solver* s, double out[6]);
+int zf_solver_pass_stats_ex(zf_solver* s, double* out, int64_t count /* >= 6 */);
 int zf_solver_set_timing(zf_solver* s, int32_t enabled);
 
 /* ---- vector kernels for opaque (Python) callbacks ------------------------
@@ -367,6 +377,15 @@ int zf_mo_trial_wait(zf_mo* s, int32_t ticket, double* w_out, double* fun_out, i
                      int64_t* evals_out, double* err_out, double* f_x_out, double* g_x_out, double* f_y_out,
                      int32_t* accepted_out, int32_t* skipped_out);
 int zf_mo_uncommit(zf_mo* s);   /* undo of zf_mo_commit (+ zf_mo_prepare_async) after a skipped gated trial */
+/* The device trial keeps its whole grid spinning on grid-wide hand-overs, so every workgroup must be resident at
+ * once.  What the device can hold of the kernel is checked at launch (hipOccupancyMaxActiveBlocksPerMultiprocessor;
+ * if it cannot: *ticket_out = -1 / *ok_out = 0, nothing launched).  If other work occupies CUs at run time a wait
+ * gives up after ZF_MO_SPIN_LIMIT polls (default 2^24, seconds): the reducer publishes no totals, every workgroup
+ * leaves, *ok_out = -1.  Then: zf_mo_trial_wait the trial launched ahead (it was skipped), zf_mo_uncommit,
+ * zf_mo_invalidate_prepare (y, f(y), J of that trial are due again) and continue with zf_mo_solve_dual +
+ * zf_mo_recover. */
+int zf_mo_invalidate_prepare(zf_mo* s, int32_t ticket /* of the trial that gave up; -1: the most recent launch */);
+int zf_mo_debug_force_timeout(zf_mo* s, int32_t launches);   /* test hook: the next `launches` device trials give up */
 int zf_mo_get_f_y(zf_mo* s, double* f_y_out /* m */);
 int zf_mo_set_jac(zf_mo* s, const double* J_host);              /* generic kind         :142 */
 /* out[0..m) = g_i(p), out[m] = |p-v|^2, out[m+1] = |w@J|^2, out[m+2..2m+2) = J_i.(p-y)   :162-173 */
@@ -386,8 +405,9 @@ int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const double* F_old
  * evaluations run on register-resident (J, y), their sums are combined by a last-arriver reduction,
  * the solver's state machine advances on the device; f(x+), g(x+) (:295) come out of the same pass
  * (f_x_out[0] = NaN when f is a host callback); one launch and one read-back per trial.
- * *ok_out = 0: not attempted (non-finite start, x sharded over ranks, m > 3) - fall back to
- * zf_mo_solve_dual / the reference's calls + zf_mo_recover. */
+ * *ok_out = 0: not attempted (non-finite start, x sharded over ranks, m > 3, grid not co-resident) - fall back to
+ * zf_mo_solve_dual / the reference's calls + zf_mo_recover.  *ok_out = -1: a grid-wide wait gave up (see
+ * zf_mo_invalidate_prepare); same fall-back. */
 int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
                             const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
                             int64_t* nit_out, int32_t* ok_out, int64_t* evals_out, double* err_out,
@@ -395,12 +415,12 @@ int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, const double
                             double* f_y_out /* m or NULL: the f(y) used; f_y may be NULL after zf_mo_prepare_async */);
 /* diagnostics of the last device solve: [0] batches (grid-wide hand-overs), [1] dual evaluations,
  * [2..5] shader-clock cycles of workgroup 0: whole kernel / evaluation loops / hand-overs / solver steps */
-int zf_mo_solve_stats(zf_mo* s, int64_t out6[6]);
+int zf_mo_solve_stats(zf_mo* s, int64_t* out, int64_t count /* >= 6 */);
 int zf_mo_recover(zf_mo* s, double lr, const double* w_host, double* err_out);   /* :206, :510 */
 int zf_mo_commit(zf_mo* s, double beta, int32_t nesterov);      /* :530-538 */
-int zf_mo_get(zf_mo* s, int32_t which, double* host);
+int zf_mo_get(zf_mo* s, int32_t which, double* host, int64_t count /* >= n */);
 int zf_mo_put(zf_mo* s, int32_t which, const double* host);
-int zf_mo_get_jac(zf_mo* s, double* J_host);
+int zf_mo_get_jac(zf_mo* s, double* J_host, int64_t count /* >= m * n */);
 int zf_mo_prox_host(zf_mo* s, const double* weight_host, const double* x_host, double* out_host); /* problems.py:119-138 */
 /* generic kind, after the user's prox callback produced p (host):
  * out[0..m) = J_i.(p - y), out[m] = |p - (y - lr w@J)|^2          proximal_gradient.py:168,173 */

@@ -312,3 +312,31 @@ def make_plasso(m_rows, n, seed=0, n_informative=20, noise=0.01, lam_frac=0.1):
     b = A @ x_true + noise * rng.standard_normal(m_rows)
     lam = lam_frac * np.max(np.abs(A.T @ b))
     return A, b, lam
+
+
+class DiagQuadMORef(ProblemRef):
+    """m separable quadratics f_i(x) = 1/2 sum_j D_ij (x_j - C_ij)^2 with the shifted-l1 / box g of
+    ``ProblemRef`` - a well-conditioned multi-objective family for fixtures at sizes where the
+    reference's own large-n problem (FDS: f_1 ~ n^4 / 6) is dominated by rounding.
+    No class of the reference: the NumPy expressions are *defined* here (like ``DiagQuadL1Ref``)
+    and handed to the reference's solver as plain callbacks."""
+
+    def __init__(self, D, C, l1_ratios=None, l1_shifts=None, bounds=None):
+        D, C = np.asarray(D, float), np.asarray(C, float)
+        super().__init__(D.shape[1], D.shape[0], l1_ratios, l1_shifts, bounds)
+        self.D, self.C = D, C
+
+    def f(self, x):
+        r = x - self.C
+        return 0.5 * np.sum(self.D * (r * r), axis=1)
+
+    def jac_f(self, x):
+        return self.D * (x - self.C)
+
+
+def make_quad_mo(n, m=3, seed=5):
+    """Seeded inputs of ``DiagQuadMORef``: D ~ U[0.5, 2] (L = 2), C_i ~ N(i - 1, 1)."""
+    rng = np.random.default_rng(seed)
+    D = rng.uniform(0.5, 2.0, (m, n))
+    C = rng.standard_normal((m, n)) + np.arange(m)[:, None]
+    return D, C

@@ -142,7 +142,7 @@ class FakeSolver:
             packs = np.ascontiguousarray(self._exchange(pack, self.sub_iters))
             if running:
                 self.passes += 1
-                _lib.check(self.lib.zf_decide_host(C.byref(self.ctl), C.c_void_p(_lib.ptr(packs)),
+                _lib.check(self.lib.zf_decide_host(C.byref(self.ctl), C.sizeof(self.ctl), C.c_void_p(_lib.ptr(packs)),
                                                    C.c_void_p(_lib.ptr(self.trace))))
 
     def poll(self):

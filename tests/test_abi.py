@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in zfista_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.zf_abi_version() == 3
+    assert lib.zf_abi_version() == 4
 
 
 def test_struct_mirrors():
@@ -37,10 +37,54 @@ def test_struct_mirrors():
 
 def test_error_reporting_is_c_style():
     lib = _lib.load()
-    rc = lib.zf_decide_host(None, None, None)
+    rc = lib.zf_decide_host(None, 0, None, None)
     assert rc == -2 and b"zf_decide_host" in lib.zf_last_error()
     with pytest.raises(_lib.ZfError):
         _lib.check(rc, "zf_decide_host")
+
+
+def test_short_output_buffers_are_refused():
+    """ABI 4: entry points that write a struct (or a library-defined amount of data) into caller
+    memory take the capacity of the buffer and refuse - ZF_ERR_ARG, nothing written - a buffer that
+    is too small.  Round 2's documented ctypes stub allocated 176 bytes for a zf_control that had grown
+    to 416: zf_solver_poll overran it and the heap blew up tests later.  No GPU needed: the size checks
+    come before anything dereferences the solver handle or touches a device."""
+    lib = _lib.load()
+    assert lib.zf_sizeof_control() > 176
+    small = (C.c_byte * 176)()
+    packs = np.zeros(_lib.ZF_PACK_LEN)
+    trace = np.zeros((_lib.ZF_RING, _lib.ZF_TRACE_COLS))
+
+    def raw(fn, argtypes, *args):
+        saved = fn.argtypes
+        fn.argtypes = argtypes
+        try:
+            return fn(*args)
+        finally:
+            fn.argtypes = saved
+
+    P, I = C.c_void_p, C.c_int64
+    # zf_decide_host with a 176-byte control block: refused before it is read or written
+    rc = raw(lib.zf_decide_host, [P, I, P, P], C.addressof(small), 176, _lib.ptr(packs), _lib.ptr(trace))
+    assert rc == -2 and b"zf_sizeof_control" in lib.zf_last_error()
+    assert bytes(small) == bytes(176) and not trace.any()
+    # zf_solver_poll: 176 "caller" bytes at the head of a guard region that must stay untouched
+    guard = (C.c_byte * 1024)()
+    dummy = (C.c_byte * 64)()          # a non-null handle; never dereferenced: the checks come first
+    rc = raw(lib.zf_solver_poll, [P, P, I, P, I], C.addressof(dummy), C.addressof(guard), 176, None, 0)
+    assert rc == -2 and b"ctl_bytes" in lib.zf_last_error()
+    ctl = _lib.Control()
+    rc = raw(lib.zf_solver_poll, [P, P, I, P, I], C.addressof(dummy), C.addressof(ctl), C.sizeof(ctl),
+             _lib.ptr(trace), 8 * 100)
+    assert rc == -2 and b"trace_bytes" in lib.zf_last_error()
+    assert bytes(guard) == bytes(1024) and not trace.any()
+    # a saved control block of another size is refused by the restore path as well
+    rc = raw(lib.zf_solver_restore, [P, P, P, P, I], C.addressof(dummy), C.addressof(dummy), C.addressof(dummy),
+             C.addressof(small), 176)
+    assert rc == -2 and b"saved_bytes" in lib.zf_last_error()
+    out = np.zeros(6)
+    rc = raw(lib.zf_solver_pass_stats_ex, [P, P, I], C.addressof(dummy), _lib.ptr(out), 4)
+    assert rc == -2 and not out.any()
 
 
 def test_product_fails_loudly_without_gpu():

@@ -577,3 +577,50 @@ def test_dual_hessian_against_differences_of_the_gradient(variant):
     # (a kink of some element may fall inside a difference interval: allow the odd piece change)
     assert worst <= 2e-3
     eng.close()
+
+
+@pytest.mark.parametrize("ahead", ["1", "0"])
+@pytest.mark.parametrize("kind", ["jos1", "fds"])
+def test_device_trial_that_gives_up_falls_back_to_the_host_search(kind, ahead, monkeypatch):
+    """k_dual_solve keeps its whole grid spinning on grid-wide hand-overs; when its workgroups are not all
+    resident (another kernel / process / a CU mask holds CUs) a wait gives up, the record says ok = -1 and the
+    solve must go on with the host-driven search - a UserWarning, not a failed solve.  The give-up is forced
+    here (zf_mo_debug_force_timeout) at the 4th device launch, with trials launched ahead and without: the
+    result equals the dual_solver="native" solve (the same search, host loop) to the accuracy the two agree
+    at anyway, with the same iteration count."""
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.multiobjective import MoEngine
+    from zfista_amd.problems import FDS, JOS1
+
+    monkeypatch.setenv("ZF_MO_LAUNCH_AHEAD", ahead)
+    rng = np.random.default_rng(12)
+    if kind == "jos1":
+        n = 20011
+        make = lambda: JOS1(n, l1_ratios=np.array([1.0, 2.0]) / n, l1_shifts=[0.0, 1.0])   # noqa: E731
+        x0, kw = rng.uniform(-2, 4, n), dict(lr=64.0 * n, max_iter=12)     # backtracking line searches at the start
+    else:
+        n = 3001
+        make = lambda: FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0.0, 1.0, 2.0])   # noqa: E731
+        x0, kw = rng.uniform(-2, 2, n), dict(lr=1.0, max_iter=8)
+    kw.update(nesterov=True, tol=0.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = minimize_proximal_gradient(*make().callbacks(), x0, dual_solver="native", **kw)
+        clean = minimize_proximal_gradient(*make().callbacks(), x0, dual_solver="device", **kw)
+    launches = {"n": 0}
+    for name in ("trial_launch", "solve_dual_device"):
+        orig = getattr(MoEngine, name)
+
+        def counted(self, *a, _orig=orig, **k):
+            launches["n"] += 1
+            if launches["n"] == 4:
+                self.debug_force_timeout(1)
+            return _orig(self, *a, **k)
+
+        monkeypatch.setattr(MoEngine, name, counted)
+    with pytest.warns(UserWarning, match="gave up waiting for its grid"):
+        got = minimize_proximal_gradient(*make().callbacks(), x0, dual_solver="device", **kw)
+    assert launches["n"] >= 4
+    assert (got.nit, got.status, got.success, got.message) == (want.nit, want.status, want.success, want.message)
+    assert rel_err(got.x, want.x) <= 1e-9 and rel_err(got.x, clean.x) <= 1e-9
+    np.testing.assert_allclose(got.fun, want.fun, rtol=1e-9)

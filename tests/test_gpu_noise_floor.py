@@ -1,0 +1,82 @@
+"""GPU: the resolution limit of the acceptance test (zfista/proximal_gradient.py:298-305) on record.
+
+Fixture G12 (tests/golden/make_golden_r3.py): the imported reference on P-diag n = 1e7 (BASELINE cfg2),
+lr = 0.45, 110 FISTA iterations.  `F(x+) - F(x_k) <= model + 1e-12` subtracts two sums of ~1e6 (ulp 2e-10);
+once |x+ - y|^2 / (2 lr) falls below that, the outcome is the rounding of the sums: the reference rejects
+trials at iterations 90, 94, 95, 97, 102 (lr 0.45 -> 0.014).  Whatever sums in another order - the
+reference itself with permuted features, the oracle with another BLAS, this engine - takes other, equally
+arbitrary branches there.  What is pinned:
+  * BEFORE the reference's first rejection: identical lr / trial sequence, iterates bit-comparable
+    (1e-10), traces to 1e-10;
+  * AFTER it: the engine rejects too - a rejection count within a factor 2 of the reference's over the same
+    110 iterations - and every accepted iteration still satisfies the test it was accepted on."""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(prob, n, K, **kw):
+    from zfista_amd import _lib
+    from zfista_amd.proximal_gradient import NativeRun
+
+    run = NativeRun(prob, np.zeros(n), dict(lr=0.45, tol=0.0, tol_internal=1e-12, decay_rate=0.5, max_iter=K,
+                                            max_backtrack_iter=100, nesterov=True, nesterov_ratio=(0, 0.25),
+                                            deprecated=False, **kw))
+    rows = []
+    while run.status == _lib.ZF_RUNNING:
+        rows.append(run.advance(8))
+    rows = np.concatenate(rows)
+    x = run.solver.get_x()
+    ctl = run.solver.ctl
+    out = dict(rows=rows, x=x, nit=int(ctl.nit), trials=int(ctl.total_trials), lr=float(ctl.lr), status=run.status)
+    run.solver.close()
+    return out
+
+
+def test_noise_floor_of_the_acceptance_test_n1e7(golden):
+    from oracle import problems_ref as P
+    from zfista_amd import _lib
+    from zfista_amd.problems import DiagQuadL1
+
+    G = golden("g12_noise_floor_diag_n1e7.npz")
+    n, K = int(G("n")), int(G("K"))
+    first = int(G("first_rejection"))            # 1-based iteration of the reference's first rejected trial
+    assert first == 90 and int(G("rejections")) == 5
+    d, c, lam = P.make_pdiag(n, seed=1)
+    prob = DiagQuadL1(d, c, lam)
+    clean = first - 1
+    # --- the clean regime: iterations 1 .. first - 1 exactly as the reference
+    a = _run(prob, n, clean)
+    assert a["status"] == _lib.ZF_MAXITER and a["nit"] == clean
+    rows = a["rows"]
+    assert np.array_equal(rows[:, _lib.TR_TRIALS], np.ones(clean)), "a trial was rejected before the reference's first"
+    assert np.array_equal(rows[:, _lib.TR_LR], G("alllrs")[:clean])
+    np.testing.assert_allclose(rows[:, _lib.TR_F], G("allfuns")[1:clean + 1], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(rows[:, _lib.TR_ERR], G("allerrs")[:clean], rtol=1e-10, atol=0)
+    at = list(G("samples_at"))
+    assert at[2] == clean
+    assert rel_err(a["x"][::100003], G("x_samples")[2]) <= 1e-10
+    for k, want in ((at[0], G("x_samples")[0]), (at[1], G("x_samples")[1])):
+        b = _run(prob, n, int(k))
+        assert rel_err(b["x"][::100003], want) <= 1e-10
+    # --- across the floor: the same 110 iterations
+    full = _run(prob, n, K)
+    assert full["status"] == _lib.ZF_MAXITER and full["nit"] == K
+    rej, rej_ref = full["trials"] - K, int(G("rejections"))
+    assert np.array_equal(full["rows"][:clean, _lib.TR_TRIALS], np.ones(clean))
+    assert rej_ref / 2 <= rej <= 2 * rej_ref, (rej, rej_ref)
+    lrs = full["rows"][:, _lib.TR_LR]
+    assert np.all(np.diff(lrs) <= 0) and lrs[-1] == 0.45 * 0.5 ** rej      # lr only ever halves (:305)
+    # every accepted iteration passed the reference's test on the sums it was accepted with (:303)
+    r = full["rows"]
+    F_prev = np.concatenate([[float(G("allfuns")[0])], r[:-1, _lib.TR_F]])
+    assert np.all(r[:, _lib.TR_F] - F_prev <= r[:, _lib.TR_FUN] + 1e-12)
+    # chains of 1 take the same decisions as chains of 16 on this problem too (S-invariance across the floor)
+    one = _run(prob, n, K, sub_iters=1)
+    assert one["trials"] == full["trials"] and np.array_equal(one["x"], full["x"])
+    assert np.array_equal(one["rows"][:, :5], full["rows"][:, :5])

@@ -37,7 +37,7 @@ def _decide(c, pack, world=1):
     lib = _lib.load()
     trace = np.zeros((_lib.ZF_RING, _lib.ZF_TRACE_COLS))
     p = np.ascontiguousarray(np.asarray(pack, float))
-    _lib.check(lib.zf_decide_host(C.byref(c), C.c_void_p(_lib.ptr(p)), C.c_void_p(_lib.ptr(trace))))
+    _lib.check(lib.zf_decide_host(C.byref(c), C.sizeof(c), C.c_void_p(_lib.ptr(p)), C.c_void_p(_lib.ptr(trace))))
     return trace
 
 

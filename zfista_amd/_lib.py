@@ -96,7 +96,7 @@ SIGNATURES = {
     "zf_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "zf_solver_set_comm": (C.c_int, [_P, _P]),
     "zf_solver_enqueue_init_all": (C.c_int, [_P, _P]),
-    "zf_decide_host": (C.c_int, [C.POINTER(Control), _P, _P]),
+    "zf_decide_host": (C.c_int, [C.POINTER(Control), C.c_int64, _P, _P]),
     "zf_solver_create": (C.c_int, [C.POINTER(_P), C.POINTER(ProblemDesc), C.POINTER(Options), _P]),
     "zf_solver_destroy": (C.c_int, [_P]),
     "zf_solver_enqueue_init": (C.c_int, [_P, _P]),
@@ -116,15 +116,15 @@ SIGNATURES = {
     "zf_solver_set_svec_buffers": (C.c_int, [_P, _P, _P]),
     "zf_solver_enqueue_trial_finish": (C.c_int, [_P]),
     "zf_solver_enqueue_init_finish": (C.c_int, [_P]),
-    "zf_solver_poll": (C.c_int, [_P, C.POINTER(Control), _P]),
+    "zf_solver_poll": (C.c_int, [_P, C.POINTER(Control), C.c_int64, _P, C.c_int64]),
     "zf_solver_x_dev": (C.c_int, [_P, C.POINTER(_P)]),
-    "zf_solver_get_x": (C.c_int, [_P, _P]),
-    "zf_solver_get_x_prev": (C.c_int, [_P, _P]),
-    "zf_solver_restore": (C.c_int, [_P, _P, _P, C.POINTER(Control)]),
+    "zf_solver_get_x": (C.c_int, [_P, _P, C.c_int64]),
+    "zf_solver_get_x_prev": (C.c_int, [_P, _P, C.c_int64]),
+    "zf_solver_restore": (C.c_int, [_P, _P, _P, C.POINTER(Control), C.c_int64]),
     "zf_solver_trial_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "zf_solver_set_timing": (C.c_int, [_P, C.c_int32]),
-    "zf_solver_pass_stats": (C.c_int, [_P, _P]),
-    "zf_solver_pass_stats_ex": (C.c_int, [_P, _P]),
+    "zf_solver_pass_stats": (C.c_int, [_P, _P, C.c_int64]),
+    "zf_solver_pass_stats_ex": (C.c_int, [_P, _P, C.c_int64]),
     "zf_host_grad_step": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64]),
     "zf_host_model_terms": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "zf_host_momentum": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64]),
@@ -160,13 +160,15 @@ SIGNATURES = {
                                      C.c_int32, _P]),
     "zf_mo_trial_wait": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "zf_mo_uncommit": (C.c_int, [_P]),
+    "zf_mo_invalidate_prepare": (C.c_int, [_P, C.c_int32]),
+    "zf_mo_debug_force_timeout": (C.c_int, [_P, C.c_int32]),
     "zf_mo_get_f_y": (C.c_int, [_P, _P]),
-    "zf_mo_solve_stats": (C.c_int, [_P, _P]),
+    "zf_mo_solve_stats": (C.c_int, [_P, _P, C.c_int64]),
     "zf_mo_recover": (C.c_int, [_P, C.c_double, _P, _P]),
     "zf_mo_commit": (C.c_int, [_P, C.c_double, C.c_int32]),
-    "zf_mo_get": (C.c_int, [_P, C.c_int32, _P]),
+    "zf_mo_get": (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
     "zf_mo_put": (C.c_int, [_P, C.c_int32, _P]),
-    "zf_mo_get_jac": (C.c_int, [_P, _P]),
+    "zf_mo_get_jac": (C.c_int, [_P, _P, C.c_int64]),
     "zf_mo_prox_host": (C.c_int, [_P, _P, _P, _P]),
     "zf_mo_post_terms": (C.c_int, [_P, C.c_double, _P, _P, _P]),
     "zf_ls_eval": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_double, _P, C.POINTER(C.c_double), _P]),

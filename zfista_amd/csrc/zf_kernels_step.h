@@ -14,6 +14,8 @@
 // -ffp-contract=off, so every x+ is bit-identical to the NumPy expression; only
 // the summation order of the reductions differs.
 #pragma once
+#include <type_traits>
+
 #include "zf_common.h"
 #include "zf_decide.h"
 
@@ -157,11 +159,22 @@ typedef __attribute__((address_space(3))) void* zf_lds_ptr;
 #ifndef ZF_S16_GLDS
 #define ZF_S16_GLDS 1
 #endif
-template <int S, int MODE, bool HIST, bool GRAD_INLINE> constexpr bool zf_uses_glds() {
-    return ZF_S16_GLDS != 0 && S >= 16 && (MODE == 0 || MODE == 2) && !HIST && GRAD_INLINE;
+#ifndef ZF_S8_GLDS
+#define ZF_S8_GLDS 1   // the 8-trial bodies that serve the short passes of a 16-chain solver (PART 1) load by DMA too
+#endif
+#ifndef ZF_GLDS_STAGES
+#define ZF_GLDS_STAGES 3   // LDS stages of the DMA pipeline: units in flight ahead of the one being computed + 1
+#endif
+// SP = packs per pass of the solver (S <= SP): the 8-trial bodies use the DMA path only inside a 16-chain solver
+template <int S, int MODE, bool HIST, bool GRAD_INLINE, int SP = S> constexpr bool zf_uses_glds() {
+    if (HIST || !GRAD_INLINE || ZF_S16_GLDS == 0) return false;
+    if (S >= 16) return true;
+    return ZF_S8_GLDS != 0 && S == 8 && SP >= 16;
 }
 constexpr int ZF_GLDS_STREAMS = 4;                                   // x_k, x_{k-1}, d, c
 constexpr int ZF_GLDS_STAGE_UNITS = ZF_GLDS_STREAMS * ZF_BLOCK;      // 16-byte units per stage (16 KiB)
+constexpr int ZF_GLDS_NST = ZF_GLDS_STAGES;
+static_assert(ZF_GLDS_NST == 2 || ZF_GLDS_NST == 3, "2 or 3 stages");
 
 constexpr int ZF_MAX_SUB = ZF_MAX_SUB_ITERS;   // trials chained per pass (temporal blocking), upper bound
 // levels of the transposing wave butterfly for a chain of S = 2^h trials: slot q < 5 of lane j * (64 >> h)
@@ -463,12 +476,15 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
 #pragma unroll
         for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], first_unit + u * ZF_BLOCK);
     };
-    if constexpr (zf_uses_glds<S, MODE, HIST, GRAD_INLINE>()) {
-        // LDS-DMA pipeline over this workgroup's units (tile-major, ZF_TILE_U units per tile): stage k & 1
-        // holds unit k.  Per unit: read the stage into registers, start the DMA of unit k + 1 into the
-        // other stage, run the chain, store the two iterates, and only then wait for the DMA - which by
-        // then has had a whole chain (~1.4 us) to land; the two stores issued after it may stay in flight
-        // (vector-memory operations retire in issue order: vmcnt(2)).
+    if constexpr (zf_uses_glds<S, MODE, HIST, GRAD_INLINE, SP>()) {
+        // LDS-DMA pipeline over this workgroup's units (tile-major, ZF_TILE_U units per tile): stage k % NST holds
+        // unit k and NST - 1 units are in flight ahead of the one being computed (bytes in flight per CU = waves x
+        // 4 KiB x (NST - 1): one unit ahead left the pipe latency-bound at n = 1e7, where a chain takes ~1 us).
+        // Per unit: read the stage into registers, start the DMA of unit k + NST - 1 into the stage read one unit
+        // ago, run the chain, store the iterate(s), then wait until the DMA of unit k + 1 has landed - everything
+        // issued after it may stay in flight (vector-memory operations retire in issue order: a counted vmcnt).
+        constexpr int NST = ZF_GLDS_NST;
+        constexpr int NL = NESTEROV ? 4 : 3;   // DMA instructions per unit
         int my_tiles = 0;
         for (int t = 0; t < A.tiles_per_wg; ++t)
             if ((int64_t)t * G + blockIdx.x < full_tiles) my_tiles = t + 1;
@@ -480,36 +496,69 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
         };
         auto issue = [&](int k) {
             const int64_t i = unit_of(k);
-            const unsigned base = lds0 + (unsigned)(k & 1) * (ZF_GLDS_STAGE_UNITS * 16u);
+            const unsigned base = lds0 + (unsigned)(k % NST) * (ZF_GLDS_STAGE_UNITS * 16u);
             zf_glds16<NT && (ZF_X_NT != 0)>(xk2 + i, base);
             if (NESTEROV) zf_glds16<NT && (ZF_X_NT != 0)>(xo2 + i, base + ZF_BLOCK * 16u);
             zf_glds16<NT>(p02 + i, base + 2 * ZF_BLOCK * 16u);
             zf_glds16<NT>(p12 + i, base + 3 * ZF_BLOCK * 16u);
         };
         if (total > 0) {
-            issue(0);
+            // NST - 1 units in flight before the first chain; ALL of them are waited for (one more latency per
+            // workgroup, ~1 % of its time) so that the counted wait below is the same constant in every trip:
+            // a wait whose count varied per trip (a switch over immediates) made the compiler restructure the
+            // loop and spill the full chain's 192 running sums
+#pragma unroll
+            for (int k = 0; k < NST - 1; ++k)
+                if (k < total) issue(k);
             zf_wait_vm<0>();
-#pragma unroll 1
-            for (int k = 0; k < total; ++k) {
-                const zf_d2* sp = stage + (k & 1) * ZF_GLDS_STAGE_UNITS + threadIdx.x;
+            int st = 0;
+            // One trip = one unit.  The DMA of unit k + 1 must have landed before the next trip reads its stage.
+            // Younger than it (vector-memory operations retire in issue order): the stores of the NST - 1 units
+            // computed since it was issued and the DMAs of the NST - 2 units behind it - or, in the last NST - 1
+            // trips, which have nothing left to issue, the stores alone.  (The first NST - 2 trips have fewer
+            // stores behind them: their unit k + 1 landed with the prologue's wait.)  Each of the two loops has
+            // ONE wait with ONE immediate; a branch between two waits inside one loop cost the full chain its
+            // register allocation just like the switch.  Bodies that may store one iterate per unit instead of
+            // two count one store per unit (a smaller count only waits for more).
+            static_assert(NST == 2 || NST == 3, "the counted waits below are written for 2 or 3 stages");
+            constexpr int NSTORE = FULL ? 2 : 1;
+            auto trip = [&](int k, auto more_c) {
+                constexpr bool MORE = decltype(more_c)::value;
+                const zf_d2* sp = stage + st * ZF_GLDS_STAGE_UNITS + threadIdx.x;
+                st = (st + 1 == NST) ? 0 : st + 1;
                 const zf_d2 a = sp[0];
                 const zf_d2 o = NESTEROV ? sp[ZF_BLOCK] : a;
                 const zf_d2 q = sp[2 * ZF_BLOCK];
                 const zf_d2 cc = sp[3 * ZF_BLOCK];
                 __builtin_amdgcn_sched_barrier(0);
-                if (k + 1 < total) issue(k + 1);
+                if constexpr (MORE) issue(k + NST - 1);
                 if constexpr (FULL) {
                     advance(a, o, q, cc, unit_of(k));   // the chain + the two iterate stores
-                    zf_wait_vm<2>();
                 } else {
-                    // the general shape: replay of the lagging iterations, then the fresh trials; one or two
-                    // iterates are stored behind the DMA
-                    zf_d2 a1[UB] = {a}, o1[UB] = {o}, q1[UB] = {q}, c1[UB] = {cc};
-                    compute_batch(unit_of(k), a1, o1, q1, c1);
-                    if (ntr >= 2) zf_wait_vm<2>();
-                    else zf_wait_vm<1>();
+                    // the general shape: replay of the lagging iterations (parameters are wave-uniform scalar
+                    // loads), then the fresh trials; one or two iterates are stored behind the DMA
+                    zf_d2 a1 = a, o1 = o;
+                    for (int i = 0; i < lag; ++i) {
+                        const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
+                        const double lr_i = A.ctl->lag_lr[i];
+                        const double tau_i = A.lam * lr_i;
+                        zf_d2 r;
+                        r.x = zf_elem_diag_replay<NESTEROV, BOX>(a1.x, o1.x, q.x, cc.x, b_i, lr_i, tau_i, A.lo, A.hi);
+                        r.y = zf_elem_diag_replay<NESTEROV, BOX>(a1.y, o1.y, q.y, cc.y, b_i, lr_i, tau_i, A.lo, A.hi);
+                        o1 = a1;
+                        a1 = r;
+                    }
+                    advance(a1, o1, q, cc, unit_of(k));
                 }
-            }
+                if constexpr (MORE) zf_wait_vm<NL * (NST - 2) + NSTORE * (NST - 1)>();
+                else zf_wait_vm<NSTORE * (NST - 1)>();
+            };
+            const int steady = total - (NST - 1);   // trips that still have a unit to issue
+            int k = 0;
+#pragma unroll 1
+            for (; k < steady; ++k) trip(k, std::true_type{});
+#pragma unroll 1
+            for (; k < total; ++k) trip(k, std::false_type{});
         }
     } else if constexpr (UB == ZF_TILE_U || MODE == 1 || HIST || S >= 16) {
         // short chains (<= 148 VGPRs, three or more waves per SIMD): the other waves of the SIMD
@@ -642,8 +691,9 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
     static_assert(PART <= 1 || S >= 16, "the third kernel exists for chains of 16 only");
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
-    constexpr bool GLDS = PART != 1 && zf_uses_glds<S, PART == 0 ? 0 : 2, HIST, GRAD_INLINE>();
-    __shared__ zf_d2 stage[GLDS ? 2 * ZF_GLDS_STAGE_UNITS : 1];   // two stages of the LDS-DMA pipeline (32 KiB)
+    constexpr bool GLDS = PART != 1 ? zf_uses_glds<S, PART == 0 ? 0 : 2, HIST, GRAD_INLINE>()
+                                    : (S >= 16 && zf_uses_glds<S / 2, 1, HIST, GRAD_INLINE, S>());
+    __shared__ zf_d2 stage[GLDS ? ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS : 1];   // the stages of the LDS-DMA pipeline (16 KiB each)
     // wave-uniform control reads (scalar loads); written by the previous step's decide
     if (A.ctl->status != ZF_RUNNING) return;
     if constexpr (S == 1) {
@@ -666,9 +716,9 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
             zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, lag, nf_opaque, stage);
         } else if constexpr (S >= 16) {
             constexpr int SS = S / 2;
-            if (lag == 0 && nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 0, HIST, S>(A, lds, 0, SS);
-            else if (nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 1, HIST, S>(A, lds, lag, SS);
-            else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 2, HIST, S>(A, lds, lag, nf);
+            if (lag == 0 && nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 0, HIST, S>(A, lds, 0, SS, stage);
+            else if (nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 1, HIST, S>(A, lds, lag, SS, stage);
+            else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 2, HIST, S>(A, lds, lag, nf, stage);
         } else {
             if (nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1, HIST>(A, lds, lag, S);
             else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, lag, nf);

@@ -275,7 +275,8 @@ typedef unsigned long long mo_u64;
 constexpr int MO_SOLVE_TPB = 512;
 constexpr int MO_SOLVE_LDS_BYTES = 156 * 1024;   // dynamic LDS for the resident elements (static LDS: ~3 KB)
 constexpr int MO_SOLVE_WAVES = MO_SOLVE_TPB / 64;
-constexpr unsigned MO_SPIN_LIMIT = 1u << 24;   // polls (each >= ~100 ns): a stuck grid gives up after seconds
+constexpr unsigned MO_SPIN_LIMIT = 1u << 24;   // polls (each >= ~100 ns): a stuck grid gives up after seconds (default of
+                                               // mo_solve_args.spin_limit; ZF_MO_SPIN_LIMIT in the environment overrides it)
 
 struct mo_solve_result {
     double w[MO_MAX_M];
@@ -338,6 +339,8 @@ struct mo_solve_args {
     double* F_new_out;
     int decay_is_one;
     double accept_tol;
+    unsigned spin_limit;  // polls a grid-wide wait may take before the launch gives up (ok = -1)
+    int force_timeout;    // test hook (zf_mo_debug_force_timeout): the first hand-over reports a timeout
 };
 
 template <int M>
@@ -513,7 +516,8 @@ __device__ __forceinline__ bool mo_get(const mo_u64* rec, mo_u64 key, double* v)
 template <int QW>
 __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, count */, int count, int max_index,
                                                 mo_u64* partials /* [count][G] records */, mo_u64* totals /* [count + 1] */,
-                                                unsigned nonce, unsigned epoch, double* lds_tot, int* lds_flag) {
+                                                unsigned nonce, unsigned epoch, double* lds_tot, int* lds_flag,
+                                                unsigned spin_limit) {
     const int G = (int)gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const mo_u64 key = mo_key(nonce, epoch);
@@ -558,12 +562,15 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
                     }
             if (pending) {
                 __builtin_amdgcn_s_sleep(2);   // (do not hammer the memory system while the others still compute)
-                if (++spins > MO_SPIN_LIMIT) {
+                if (++spins > spin_limit) {
                     *lds_flag = 0;
                     break;
                 }
             }
         }
+        // a wave with a lane that gave up publishes NO totals (sums over records that never arrived are not
+        // totals); the "totals are out" record below then says ABORT and no workgroup reads any of them
+        const bool wave_ok = *lds_flag != 0;   // (this wave's own give-up is visible to it; another wave's may be)
 #pragma unroll
         for (int a = 0; a < QW; ++a) {
             const int q = wave + a * MO_SOLVE_WAVES;
@@ -572,30 +579,36 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
 #pragma unroll
             for (int c = 1; c < GL; ++c) v = is_max ? fmax(v, pv[a][c]) : v + pv[a][c];
             v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
-            if (lane == 0 && q < count) mo_put(totals + 2 * q, v, key);
+            if (wave_ok && lane == 0 && q < count) mo_put(totals + 2 * q, v, key);
         }
-        // "totals are out" record, after them in program order (its readers validate every total anyway)
+        // "totals are out" record, after them in program order (its readers validate every total anyway):
+        // 1 = read them, -1 = the reducer gave up - every workgroup leaves the search at once instead of
+        // spinning to its own limit
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) mo_put(totals + 2 * count, 1.0, key);
+        // (two threads, one store each: a select between the two values in one thread made k_dual_solve<3>,
+        //  which sits at 256 VGPRs, spill 20 bytes per thread)
+        if (tid == 0 && *lds_flag) mo_put(totals + 2 * count, 1.0, key);
+        if (tid == 64 && !*lds_flag) mo_put(totals + 2 * count, -1.0, key);
     }
     if (tid == 0) {   // ONE poller per workgroup (hundreds of threads spinning on three cache lines slow the writer down)
         unsigned spins = 0;
         double v = 0.0;
         while (!mo_get(totals + 2 * count, key, &v)) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > MO_SPIN_LIMIT) {
+            if (++spins > spin_limit) {
                 *lds_flag = 0;
                 break;
             }
         }
+        if (v < 0.0) *lds_flag = 0;   // the reducer's ABORT
     }
     __syncthreads();
     if (tid < count && *lds_flag) {
         unsigned spins = 0;
         double v = 0.0;
         while (!mo_get(totals + 2 * tid, key, &v)) {
-            if (++spins > MO_SPIN_LIMIT) {
+            if (++spins > spin_limit) {
                 *lds_flag = 0;
                 break;
             }
@@ -657,6 +670,17 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             A.out->skipped = 1;
             A.out->accepted = 0;
             A.out->ok = 0;
+            __threadfence_system();
+            __hip_atomic_store(&A.out->seq, (unsigned long long)A.nonce, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    if (A.force_timeout) {   // test hook (zf_mo_debug_force_timeout): the record of a launch whose grid-wide wait gave up
+        if (blockIdx.x == 0 && tid == 0) {
+            if (A.accept_out) *A.accept_out = 0;
+            A.out->skipped = 0;
+            A.out->accepted = 0;
+            A.out->ok = -1;
             __threadfence_system();
             __hip_atomic_store(&A.out->seq, (unsigned long long)A.nonce, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -743,7 +767,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
             if (tid < NP) s_prep[tid] = s_mine[tid];
             prep_merge = 1;
         } else {
-            if (!mo_grid_combine<1>(s_mine, NP, -1, A.partials, A.totals, A.nonce, epoch, s_tot, &s_flag)) timed_out = 1;
+            if (!mo_grid_combine<1>(s_mine, NP, -1, A.partials, A.totals, A.nonce, epoch, s_tot, &s_flag, A.spin_limit)) timed_out = 1;
             epoch += 1;
         }
         if (M != 2 && tid == 0) {
@@ -908,7 +932,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         const int64_t c1 = clock64();
         c_eval += c1 - c0;
         if (!mo_grid_combine<(NB * NQP + 2 + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, cnt, -1, A.partials + 2 * ((int64_t)parity * REC_CAP * gridDim.x),
-                             A.totals + 2 * (parity * REC_CAP), A.nonce, epoch, s_tot, &s_flag)) {
+                             A.totals + 2 * (parity * REC_CAP), A.nonce, epoch, s_tot, &s_flag, A.spin_limit)) {
             timed_out = 1;
             break;
         }
@@ -1049,7 +1073,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         __syncthreads();
         const int parity = (int)(epoch & 1u);
         if (!mo_grid_combine<(NT + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, NT, 0, A.partials + 2 * ((int64_t)parity * REC_CAP * gridDim.x),
-                             A.totals + 2 * (parity * REC_CAP), A.nonce, epoch, s_tot, &s_flag))
+                             A.totals + 2 * (parity * REC_CAP), A.nonce, epoch, s_tot, &s_flag, A.spin_limit))
             timed_out = 1;
     }
     if (blockIdx.x == 0 && tid == 0) {
@@ -1152,6 +1176,11 @@ struct zf_mo {
     bool prep_pending = false;   // f(y), J not formed yet
     double pend_beta = 0.0;
     int pend_nesterov = 0;
+    // the grid-wide waits of k_dual_solve need every workgroup resident at once
+    bool solve_unavailable = false;   // the occupancy query says the grid cannot be co-resident: never launched
+    struct { bool fused, make_y; double beta; int nesterov; } launched[2] = {};   // what each slot's launch was to form
+    unsigned spin_limit = MO_SPIN_LIMIT;
+    int force_timeouts = 0;           // test hook: this many of the next launches report a timeout
 };
 
 static int mo_prepare_async_now(zf_mo* s);
@@ -1591,6 +1620,7 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
     if (!fuse)
         if (int rc = mo_flush(s)) return rc;
     if (s->exchange || s->m > 3) return ZF_OK;   // sharded x: every evaluation needs an exchange; m > 3: register budget
+    if (s->solve_unavailable) return ZF_OK;      // (the grid cannot be co-resident on this device: the caller's host loop)
     if (!s->solve_partials) {
         int dev = 0, cus = 0;
         ZF_HIP(hipGetDevice(&dev));
@@ -1599,6 +1629,10 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
         if (g > cus) g = cus;      // one workgroup per CU: the whole grid is resident (grid-wide waits)
         if (g < 1) g = 1;
         s->solve_grid = (int)g;
+        if (const char* sl = getenv("ZF_MO_SPIN_LIMIT")) {
+            const long long v = atoll(sl);
+            if (v > 0) s->spin_limit = v > 0x7fffffffLL ? 0x7fffffffu : (unsigned)v;
+        }
         const size_t nq = 2 * MO_MAX_M + 2;
         // the hand-over records in UNCACHED device memory: every access is an agent-scope atomic that has to
         // reach memory anyway (the 8 XCDs' L2s are not coherent with each other); without the L2 in the way a
@@ -1667,18 +1701,39 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
     const int64_t cap = MO_SOLVE_LDS_BYTES / ((int64_t)(s->m + 1) * MO_SOLVE_TPB * sizeof(double));
     A.resident_rows = (int)(per_wg < cap ? per_wg : cap);
     const size_t lds = (size_t)A.resident_rows * (s->m + 1) * MO_SOLVE_TPB * sizeof(double);
-    const bool set_attr = s->solve_lds_set != lds;   // (a driver call of several microseconds: once, not per trial)
+    const bool set_attr = s->solve_lds_set != lds;   // (driver calls of several microseconds: once, not per trial)
     s->solve_lds_set = lds;
-    if (s->m == 2) {
-        if (set_attr) ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_dual_solve<2>, grid, block, lds, s->stream, A);
-    } else {
-        if (set_attr) ZF_HIP(hipFuncSetAttribute((const void*)k_dual_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_dual_solve<3>, grid, block, lds, s->stream, A);
+    A.spin_limit = s->spin_limit;
+    A.force_timeout = 0;
+    if (s->force_timeouts > 0) {
+        s->force_timeouts -= 1;
+        A.force_timeout = 1;
     }
+    const void* fn = s->m == 2 ? (const void*)k_dual_solve<2> : (const void*)k_dual_solve<3>;
+    if (set_attr) {
+        ZF_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // Every workgroup spins on grid-wide hand-overs: the whole grid has to be resident at once.  What the
+        // device can hold of THIS kernel (registers, LDS) is checked here, once per LDS size; what other work
+        // on the device takes away at run time cannot be known in advance - then a wait gives up after
+        // spin_limit polls, the record says ok = -1 and the caller continues with its host loop.
+        int per_cu = 0, dev = 0, cus = 0;
+        ZF_HIP(hipGetDevice(&dev));
+        ZF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (s->m == 2) ZF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dual_solve<2>, MO_SOLVE_TPB, lds));
+        else ZF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dual_solve<3>, MO_SOLVE_TPB, lds));
+        if ((int64_t)per_cu * cus < (int64_t)s->solve_grid) {
+            s->solve_unavailable = true;
+            s->solve_lds_set = (size_t)-1;
+            if (fuse) s->y_pending = A.make_y != 0, s->prep_pending = true;   // (nothing was formed: still due)
+            return ZF_OK;
+        }
+    }
+    if (s->m == 2) hipLaunchKernelGGL(k_dual_solve<2>, grid, block, lds, s->stream, A);
+    else hipLaunchKernelGGL(k_dual_solve<3>, grid, block, lds, s->stream, A);
     ZF_HIP(hipGetLastError());
     s->last_nonce[slot] = A.nonce;
     s->last_slot = slot;
+    s->launched[slot] = {fuse, fuse && A.make_y != 0, A.beta, A.nesterov};
     *slot_out = slot;
     *launched = 1;
     return ZF_OK;
@@ -1716,8 +1771,10 @@ int mo_trial_unpack(zf_mo* s, const mo_solve_result& r, double* w_out, double* f
     if (r.skipped) return ZF_OK;
     if (f_y_out)
         for (int i = 0; i < s->m; ++i) f_y_out[i] = r.f_y[i];
-    if (r.ok < 0) return zf_fail(ZF_ERR_STATE, "zf_mo_solve_dual_device: a grid-wide wait timed out (is another kernel "
-                                               "occupying the GPU?)%s");
+    if (r.ok < 0) {   // a grid-wide wait gave up (another kernel occupying the CUs?): nothing of this trial is usable
+        *ok_out = -1;
+        return ZF_OK;
+    }
     if (r.ok == 0) return ZF_OK;
     for (int i = 0; i < s->m; ++i) w_out[i] = r.w[i];
     *fun_out = r.fun;
@@ -1801,6 +1858,33 @@ extern "C" int zf_mo_trial_wait(zf_mo* s, int32_t ticket, double* w_out, double*
     return ZF_OK;
 }
 
+// After the device trial `ticket` gave up (*ok_out = -1; and after zf_mo_uncommit, if a trial had been launched
+// ahead of it): whatever its prologue was to form - y = x_k + beta (x_k - x_{k-1}), f(y), J = jac_f(y) - is not to
+// be trusted (the sums behind f(y), J never completed) and is due again; the next entry point that needs them
+// forms them the unfused way.
+extern "C" int zf_mo_invalidate_prepare(zf_mo* s, int32_t ticket) {
+    ZF_REQUIRE(s && ticket >= -1 && ticket <= 1, "zf_mo_invalidate_prepare: bad argument");
+    if (ticket < 0) ticket = s->last_slot;   // the most recent launch (zf_mo_solve_dual_device)
+    if (s->kind != ZF_MO_JOS1 && s->kind != ZF_MO_FDS) return ZF_OK;   // (f, J are the host's for this kind)
+    if (!s->launched[ticket].fused) return ZF_OK;                      // (the launch formed nothing itself)
+    if (!s->f_y_dev) ZF_HIP(hipMalloc(&s->f_y_dev, sizeof(double) * MO_MAX_M));
+    if (s->launched[ticket].make_y) {
+        s->y_pending = true;
+        s->pend_beta = s->launched[ticket].beta;
+        s->pend_nesterov = s->launched[ticket].nesterov;
+    }
+    s->prep_pending = true;
+    s->f_y_on_device = true;
+    return ZF_OK;
+}
+
+// test hook: the next `launches` device trials report a timeout at their first grid-wide hand-over
+extern "C" int zf_mo_debug_force_timeout(zf_mo* s, int32_t launches) {
+    ZF_REQUIRE(s && launches >= 0, "zf_mo_debug_force_timeout: bad argument");
+    s->force_timeouts = launches;
+    return ZF_OK;
+}
+
 // undo of a zf_mo_commit (+ zf_mo_prepare_async) whose gated trial was skipped: x_k, x_{k-1}, y, J and
 // f(y) are those of the rejected trial again
 extern "C" int zf_mo_uncommit(zf_mo* s) {
@@ -1812,8 +1896,9 @@ extern "C" int zf_mo_uncommit(zf_mo* s) {
 
 // diagnostics of the last zf_mo_solve_dual_device call: [0] batches, [1] evaluations, [2..5] shader-clock
 // cycles of workgroup 0: whole kernel, evaluation loops, grid-wide hand-overs, solver steps
-extern "C" int zf_mo_solve_stats(zf_mo* s, int64_t out[6]) {
-    ZF_REQUIRE(s && out && s->h_solve_out, "zf_mo_solve_stats: no device solve has run");
+extern "C" int zf_mo_solve_stats(zf_mo* s, int64_t* out, int64_t count) {
+    ZF_REQUIRE(s && out && count >= 6, "zf_mo_solve_stats: needs a buffer of >= 6 entries");
+    ZF_REQUIRE(s->h_solve_out, "zf_mo_solve_stats: no device solve has run");
     const mo_solve_result& r = s->h_solve_out[s->last_slot];
     out[0] = r.batches, out[1] = r.evals, out[2] = r.cyc_total, out[3] = r.cyc_eval, out[4] = r.cyc_combine,
     out[5] = r.cyc_step;
@@ -1851,8 +1936,9 @@ extern "C" int zf_mo_commit(zf_mo* s, double beta, int32_t nesterov) {
 }
 
 // which = 0: x_k, 1: y, 2: x+, 3: x_{k-1}
-extern "C" int zf_mo_get(zf_mo* s, int32_t which, double* host) {
+extern "C" int zf_mo_get(zf_mo* s, int32_t which, double* host, int64_t count) {
     ZF_REQUIRE(s && host, "zf_mo_get: null argument");
+    ZF_REQUIRE(count >= s->n, "zf_mo_get: the host buffer holds fewer than n doubles");
     if (int rc = mo_flush(s)) return rc;
     const double* x = mo_which(s, which);
     ZF_REQUIRE(x, "zf_mo_get: bad point selector");
@@ -1861,8 +1947,9 @@ extern "C" int zf_mo_get(zf_mo* s, int32_t which, double* host) {
     return ZF_OK;
 }
 
-extern "C" int zf_mo_get_jac(zf_mo* s, double* J_host) {
+extern "C" int zf_mo_get_jac(zf_mo* s, double* J_host, int64_t count) {
     ZF_REQUIRE(s && J_host, "zf_mo_get_jac: null argument");
+    ZF_REQUIRE(count >= (int64_t)s->m * s->n, "zf_mo_get_jac: the host buffer holds fewer than m * n doubles");
     if (int rc = mo_flush(s)) return rc;
     ZF_HIP(hipMemcpyAsync(J_host, s->J, sizeof(double) * s->m * s->n, hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));

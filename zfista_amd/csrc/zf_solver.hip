@@ -746,8 +746,10 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
 // resolves beta_next.  Least squares: A x_k and A x_{k-1} are recomputed by the same kernel that
 // produced them (unsharded only).
 extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev,
-                                 const zf_control* saved) {
+                                 const zf_control* saved, int64_t saved_bytes) {
     ZF_REQUIRE(s && xk_dev && xprev_dev && saved, "zf_solver_restore: null argument");
+    ZF_REQUIRE(saved_bytes == (int64_t)sizeof(zf_control),
+               "zf_solver_restore: saved_bytes differs from zf_sizeof_control() (a control block of another ABI version)");
     const zf_problem_desc& d = s->desc;
     ZF_REQUIRE(d.kind == ZF_PROBLEM_DIAG_QUAD_L1 || d.world == 1,
                "zf_solver_restore: sharded least squares is not supported");
@@ -801,8 +803,9 @@ extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const doubl
     return ZF_OK;
 }
 
-extern "C" int zf_solver_get_x_prev(zf_solver* s, double* x_host) {
+extern "C" int zf_solver_get_x_prev(zf_solver* s, double* x_host, int64_t count) {
     ZF_REQUIRE(s && x_host, "zf_solver_get_x_prev: null argument");
+    ZF_REQUIRE(count >= s->desc.n, "zf_solver_get_x_prev: the host buffer holds fewer than n doubles");
     zf_control c;
     ZF_HIP(hipMemcpyAsync(&c, s->ctl, sizeof(c), hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
@@ -1076,8 +1079,14 @@ static int zf_collect_timing(zf_solver* s) {
     return ZF_OK;
 }
 
-extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, double* trace_host) {
+extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_bytes, double* trace_host,
+                              int64_t trace_bytes) {
     ZF_REQUIRE(s && ctl_host, "zf_solver_poll: null argument");
+    // (a host built against an older, smaller zf_control is refused - not overrun)
+    ZF_REQUIRE(ctl_bytes >= (int64_t)sizeof(zf_control),
+               "zf_solver_poll: ctl_bytes is smaller than zf_sizeof_control() (host built against another ABI version?)");
+    ZF_REQUIRE(!trace_host || trace_bytes >= (int64_t)(sizeof(double) * ZF_RING * ZF_TRACE_COLS),
+               "zf_solver_poll: trace_bytes is smaller than ZF_RING * ZF_TRACE_COLS doubles");
     ZF_HIP(hipMemcpyAsync(ctl_host, s->ctl, sizeof(zf_control), hipMemcpyDeviceToHost, s->stream));
     if (trace_host)
         ZF_HIP(hipMemcpyAsync(trace_host, s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS,
@@ -1095,8 +1104,9 @@ extern "C" int zf_solver_x_dev(zf_solver* s, const double** x_dev) {
     return ZF_OK;
 }
 
-extern "C" int zf_solver_get_x(zf_solver* s, double* x_host) {
+extern "C" int zf_solver_get_x(zf_solver* s, double* x_host, int64_t count) {
     ZF_REQUIRE(s && x_host, "zf_solver_get_x: null argument");
+    ZF_REQUIRE(count >= s->desc.n, "zf_solver_get_x: the host buffer holds fewer than n doubles");
     const double* xd = nullptr;
     int rc = zf_solver_x_dev(s, &xd);
     if (rc) return rc;
@@ -1116,8 +1126,8 @@ extern "C" int zf_solver_set_timing(zf_solver* s, int32_t enabled) {
 // out[2], out[3] = mean ms and count of every other pass (shorter chains, replays, materialise-only).
 // Launches that found the solve finished are not counted.  Resets the window; call it INSTEAD of
 // zf_solver_trial_kernel_ms (which resets the same window).
-extern "C" int zf_solver_pass_stats(zf_solver* s, double out[4]) {
-    ZF_REQUIRE(s && out, "zf_solver_pass_stats: null argument");
+extern "C" int zf_solver_pass_stats(zf_solver* s, double* out, int64_t count) {
+    ZF_REQUIRE(s && out && count >= 4, "zf_solver_pass_stats: needs a buffer of >= 4 doubles");
     ZF_HIP(hipStreamSynchronize(s->stream));
     int rc = zf_collect_timing(s);
     if (rc) return rc;
@@ -1136,14 +1146,14 @@ extern "C" int zf_solver_pass_stats(zf_solver* s, double out[4]) {
 // The same window with the work of the other passes: out[4] = fresh trials, out[5] = replayed iterations
 // they carried in total (a pass of the shared tail before max_iter runs about left / 2 fresh trials, a pass
 // after a broken chain replays the lagging iterations first).
-extern "C" int zf_solver_pass_stats_ex(zf_solver* s, double out[6]) {
-    ZF_REQUIRE(s && out, "zf_solver_pass_stats_ex: null argument");
+extern "C" int zf_solver_pass_stats_ex(zf_solver* s, double* out, int64_t count) {
+    ZF_REQUIRE(s && out && count >= 6, "zf_solver_pass_stats_ex: needs a buffer of >= 6 doubles");
     ZF_HIP(hipStreamSynchronize(s->stream));
     int rc = zf_collect_timing(s);
     if (rc) return rc;
     out[4] = (double)s->fresh_part;
     out[5] = (double)s->lag_part;
-    return zf_solver_pass_stats(s, out);
+    return zf_solver_pass_stats(s, out, 4);
 }
 
 extern "C" int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches) {
@@ -1211,8 +1221,9 @@ extern "C" int zf_stream_synchronize(void* stream) {
     return ZF_OK;
 }
 
-extern "C" int zf_decide_host(zf_control* ctl, const double* packs, double* trace) {
+extern "C" int zf_decide_host(zf_control* ctl, int64_t ctl_bytes, const double* packs, double* trace) {
     ZF_REQUIRE(ctl && packs && trace, "zf_decide_host: null argument");
+    ZF_REQUIRE(ctl_bytes == (int64_t)sizeof(zf_control), "zf_decide_host: ctl_bytes differs from zf_sizeof_control()");
     zf_decide_pass(ctl, packs, trace);
     return ZF_OK;
 }

@@ -219,13 +219,13 @@ class DeviceSolver:
 
     def get_x_prev(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.float64)
-        _lib.check(self.lib.zf_solver_get_x_prev(self.handle, C.c_void_p(_lib.ptr(out))), "get_x_prev")
+        _lib.check(self.lib.zf_solver_get_x_prev(self.handle, C.c_void_p(_lib.ptr(out)), out.size), "get_x_prev")
         return out
 
     def restore(self, xk_dev_ptr: int, xprev_dev_ptr: int, ctl):
         """Instead of init(): continue from a saved (x_k, x_{k-1}, control block)."""
         _lib.check(self.lib.zf_solver_restore(self.handle, C.c_void_p(xk_dev_ptr), C.c_void_p(xprev_dev_ptr),
-                                              C.byref(ctl)), "restore")
+                                              C.byref(ctl), C.sizeof(ctl)), "restore")
         # launch geometry: a function of n only (it fixes the rounding of the reduced sums)
         t = C.c_int32(1)
         _lib.check(self.lib.zf_solver_autotune(self.handle, C.byref(t)), "geometry")
@@ -236,13 +236,13 @@ class DeviceSolver:
 
     def poll(self):
         """Synchronise and fetch the control block + trace ring."""
-        _lib.check(self.lib.zf_solver_poll(self.handle, C.byref(self.ctl), C.c_void_p(_lib.ptr(self.trace))),
-                   "poll")
+        _lib.check(self.lib.zf_solver_poll(self.handle, C.byref(self.ctl), C.sizeof(self.ctl),
+                                           C.c_void_p(_lib.ptr(self.trace)), self.trace.nbytes), "poll")
         return self.ctl, self.trace
 
     def get_x(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.float64)
-        _lib.check(self.lib.zf_solver_get_x(self.handle, C.c_void_p(_lib.ptr(out))), "get_x")
+        _lib.check(self.lib.zf_solver_get_x(self.handle, C.c_void_p(_lib.ptr(out)), out.size), "get_x")
         return out
 
     def x_dev_ptr(self) -> int:
@@ -258,13 +258,13 @@ class DeviceSolver:
     def pass_stats(self):
         """(mean ms, count) of full-chain passes and of all other passes since the last call."""
         out = np.zeros(4)
-        _lib.check(self.lib.zf_solver_pass_stats(self.handle, C.c_void_p(_lib.ptr(out))))
+        _lib.check(self.lib.zf_solver_pass_stats(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
         return (out[0], int(out[1])), (out[2], int(out[3]))
 
     def pass_stats_ex(self):
         """pass_stats() plus (fresh trials, replayed iterations) the other passes carried in total."""
         out = np.zeros(6)
-        _lib.check(self.lib.zf_solver_pass_stats_ex(self.handle, C.c_void_p(_lib.ptr(out))))
+        _lib.check(self.lib.zf_solver_pass_stats_ex(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
         return (out[0], int(out[1])), (out[2], int(out[3])), (int(out[4]), int(out[5]))
 
     def close(self):

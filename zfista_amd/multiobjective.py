@@ -93,6 +93,7 @@ class MoEngine:
         self.h = h
         self.n_dual_evals = 0
         self.n_exchanges = 0
+        self.device_search_lost = False   # a device trial gave up on its grid-wide wait: host loop from then on
         self._cb = None
         self._exchange_error = None
         if group is not None:
@@ -223,6 +224,8 @@ class MoEngine:
             scal = (C.c_double(0.0), C.c_int64(0), C.c_int32(0), C.c_int64(0), C.c_double(0.0))
             st = self._solve_bufs = (arrs, [C.c_void_p(_lib.ptr(a)) for a in arrs], scal, [C.byref(v) for v in scal])
         (b_fy, b_Fold, b_w0, w, f_x, g_x, f_y_used), ptrs, (fun, nit, ok, evals, err), refs = st
+        if self.device_search_lost:
+            return None
         if f_y is not None:
             b_fy[:] = f_y
         b_Fold[:] = F_old
@@ -235,10 +238,28 @@ class MoEngine:
         self.n_dual_evals += int(evals.value)
         if rc != _lib.ZF_OK:
             self._check(rc, "zf_mo_solve_dual_device")
+        if ok.value < 0:
+            self.device_timed_out()
+            return None
         if not ok.value:
             return None
         return (w.copy(), np.float64(fun.value), int(nit.value), np.float64(err.value),
                 None if np.isnan(f_x[0]) else f_x.copy(), g_x.copy(), f_y_used.copy())
+
+    def device_timed_out(self, ticket=None):
+        """A device trial gave up on a grid-wide wait (its workgroups were not all resident: another kernel,
+        process or a CU mask holds part of the GPU).  Nothing of that trial is used; f(y), J are formed again
+        the unfused way, and this engine keeps to the host loop from now on (a second attempt would wait out
+        the same seconds).  Call after zf_mo_uncommit when a trial was launched ahead."""
+        self.device_search_lost = True
+        if ticket is None:   # (solve_dual_device: the launch just made)
+            ticket = -1
+        _lib.check(self.lib.zf_mo_invalidate_prepare(self.h, int(ticket)), "zf_mo_invalidate_prepare")
+        warn("the device-side dual search gave up waiting for its grid (is another kernel occupying the GPU?); "
+             "continuing with the host-driven search", UserWarning, stacklevel=3)
+
+    def debug_force_timeout(self, launches=1):
+        _lib.check(self.lib.zf_mo_debug_force_timeout(self.h, int(launches)), "zf_mo_debug_force_timeout")
 
     # -- trials launched ahead of their predecessor's result (zf_mo_trial_launch / _wait) -------------
     def trial_launch(self, lr, F_old, deprecated, w0, tol, max_iter, accept_tol, decay_is_one, gated):
@@ -250,6 +271,8 @@ class MoEngine:
             arrs = [np.zeros(self.m) for _ in range(2)]   # F_old, w0
             st = self._launch_bufs = (arrs, [C.c_void_p(_lib.ptr(a)) for a in arrs], C.c_int32(0))
         (b_Fold, b_w0), ptrs, ticket = st
+        if self.device_search_lost:
+            return None
         if F_old is not None:
             b_Fold[:] = F_old
         if w0 is not None:
@@ -264,7 +287,8 @@ class MoEngine:
     def trial_wait(self, ticket):
         """Result of a launched trial: None if it was skipped (its gate was closed), else
         (weight, fun, nit, err, f_x, g_x, f_y, accepted) - or ("not attempted", f_y) when the search did not
-        run (non-finite start): the caller continues with the host path."""
+        run (non-finite start), ("timed out", None) when a grid-wide wait gave up: the caller continues with the
+        host path (after device_timed_out())."""
         st = self.__dict__.get("_wait_bufs")
         if st is None:
             arrs = [np.zeros(self.m) for _ in range(4)]   # w, f_x, g_x, f_y
@@ -277,6 +301,8 @@ class MoEngine:
             self._check(rc, "zf_mo_trial_wait")
         if skipped.value:
             return None
+        if ok.value < 0:
+            return ("timed out", None)
         self.n_dual_evals += int(evals.value)
         if not ok.value:
             return ("not attempted", f_y.copy())
@@ -290,7 +316,7 @@ class MoEngine:
         """Diagnostics of the last solve_dual_device(): batches, evaluations and the shader-clock
         cycles workgroup 0 spent in total / evaluating / in grid-wide hand-overs / advancing the solver."""
         out = np.zeros(6, dtype=np.int64)
-        _lib.check(self.lib.zf_mo_solve_stats(self.h, C.c_void_p(_lib.ptr(out))), "zf_mo_solve_stats")
+        _lib.check(self.lib.zf_mo_solve_stats(self.h, C.c_void_p(_lib.ptr(out)), out.size), "zf_mo_solve_stats")
         return dict(zip(("batches", "evals", "cyc_total", "cyc_eval", "cyc_combine", "cyc_step"), map(int, out)))
 
     def recover(self, lr, w):
@@ -304,7 +330,7 @@ class MoEngine:
 
     def get(self, which):
         out = np.empty(self.n)
-        _lib.check(self.lib.zf_mo_get(self.h, which, C.c_void_p(_lib.ptr(out))), "zf_mo_get")
+        _lib.check(self.lib.zf_mo_get(self.h, which, C.c_void_p(_lib.ptr(out)), out.size), "zf_mo_get")
         return out
 
     def put(self, which, x):
@@ -313,7 +339,7 @@ class MoEngine:
 
     def get_jac(self):
         out = np.empty((self.m, self.n))
-        _lib.check(self.lib.zf_mo_get_jac(self.h, C.c_void_p(_lib.ptr(out))), "zf_mo_get_jac")
+        _lib.check(self.lib.zf_mo_get_jac(self.h, C.c_void_p(_lib.ptr(out)), out.size), "zf_mo_get_jac")
         return out
 
     def prox_host(self, weight, x):
@@ -572,27 +598,34 @@ def solve_native(problem, x0, o):
 
     f0, g0 = eval_F(X_K)
     F_old = f0 + g0                     # F(x_k); cached between iterations instead of recomputed (:279)
+    lr = o["lr"]
+    t_state = None
+    betas = []
+    nit_done = trials_done = 0
     if (lazy_f_y and not o["return_all"] and not o["warm_start"] and o["max_iter"] >= 1
             and os.environ.get("ZF_MO_LAUNCH_AHEAD", "1") != "0"):
         out = _solve_native_ahead(eng, o, m, F_old, res, t0)
-        if out is not None:
+        if isinstance(out, _HandOver):
+            # a device trial gave up in the middle of the solve: the loop below continues from the state it
+            # left - x_k, x_{k-1}, y in the engine, the line search of iteration nit_done + 1 under way
+            nit_done, trials_done, lr, F_old, t_state, betas = out
+        elif out is not None:
             return out
-        eng.set_x0(x0)                  # (no device trial for this problem: the loop below, from the start)
-        eng.set_fused(lazy_f_y)
+        else:
+            eng.set_x0(x0)              # (no device trial for this problem: the loop below, from the start)
+            eng.set_fused(lazy_f_y)
     w0 = np.ones(m) / m
-    lr = o["lr"]
     allvecs = allfuns = allerrs = None
     if o["return_all"]:
         allvecs, allfuns, allerrs = [x0], [f0 + g0], []
-    t_state = None
-    betas = []
     status = _lib.ZF_MAXITER
-    nit = 0
-    for nit in range(1, o["max_iter"] + 1):
+    nit = nit_done
+    for nit in range(nit_done + 1, o["max_iter"] + 1):
         try:
             f_y = prepare()             # f(y_k), J = jac_f(y_k): once per line search (y_k is fixed)
             accepted = False
-            for _ in range(o["max_backtrack_iter"]):
+            first, trials_done = trials_done, 0
+            for _ in range(first, o["max_backtrack_iter"]):
                 out = err = F_dev = None
                 if dual_solver == "device":   # search + recovery + F(x+) in one persistent kernel
                     out = eng.solve_dual_device(lr, f_y, F_old, o["deprecated"], w0, o["tol_internal"],
@@ -660,6 +693,11 @@ def solve_native(problem, x0, o):
     return res, status
 
 
+class _HandOver(tuple):
+    """(nit_done, trials_done, lr, F(x_k), t_state, betas): where _solve_native_ahead left a solve whose device
+    trial gave up; solve_native's sequential loop continues from it."""
+
+
 def _solve_native_ahead(eng, o, m, F_old, res, t0):
     """The outer loop (:474-538) with every trial launched AHEAD of its predecessor's result
     (dual_solver="device", built-in problems): while the host reads the record of trial k and does its
@@ -703,6 +741,17 @@ def _solve_native_ahead(eng, o, m, F_old, res, t0):
                 eng.prepare_async()
                 ahead = (eng.trial_launch(lr, None, dep, None, tol_i, max_i, tol_i, decay_one, True), beta)
             out = eng.trial_wait(ticket)
+            if out is not None and isinstance(out[0], str) and out[0] == "timed out":
+                # a grid-wide wait of the kernel gave up (its workgroups were not all resident): its record says
+                # "not accepted", so the trial launched ahead found its gate closed.  Nothing of this trial is
+                # used; the sequential loop continues this line search with the host-driven search.
+                if ahead is not None:
+                    eng.trial_wait(ahead[0])
+                    eng.uncommit()
+                    if o["nesterov"]:
+                        betas.append(ahead[1])
+                eng.device_timed_out(ticket)
+                return _HandOver((nit - 1, trials - 1, lr, F_k, t_state, betas))
             if out is None or isinstance(out[0], str):
                 # the search did not run on the device (non-finite dual values, e.g. F(x_0) = inf outside the
                 # box): its record says "not accepted", so a trial launched ahead found its gate closed

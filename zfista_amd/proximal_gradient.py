@@ -107,17 +107,22 @@ def minimize_proximal_gradient(
         of every trial with the reference's two SciPy calls (:179-205).  "native" uses the library's
         own simplex Newton / bracketing solver (host loop, one kernel per evaluation); "device"
         runs that same search inside one persistent kernel per trial (recognised problems only).
-        The default can be set with the environment variable ZF_DUAL_SOLVER.
+        The keyword decides.  Only when it is not given, the environment variable ZF_DUAL_SOLVER may
+        override the default (for running an unmodified caller against another search); the result then
+        says so in an extra field ``dual_solver`` - numerics never change silently with the environment.
     sub_iters : {1, 2, 4, 8, 16}, separable single-objective problems only: iterations chained per
         pass over the data (temporal blocking).  Results do not depend on it.  Default 16 (8 with
         ``return_all``).
     """
     if deprecated:
         warn(_MSG_DEPRECATED, stacklevel=2)
+    from_env = False
     if dual_solver is None:
         import os
 
-        dual_solver = os.environ.get("ZF_DUAL_SOLVER", "scipy")
+        dual_solver = os.environ.get("ZF_DUAL_SOLVER")
+        from_env = dual_solver is not None
+        dual_solver = dual_solver or "scipy"
     if dual_solver not in ("scipy", "native", "device"):
         raise ValueError(f"dual_solver must be 'scipy', 'native' or 'device', got {dual_solver!r}")
     opts = dict(
@@ -142,6 +147,8 @@ def minimize_proximal_gradient(
         res, status = multiobjective.solve_native(native_multi, x0, opts)
     else:
         res, status = _solve_generic(f, g, jac_f, prox_wsum_g, x0, opts)
+    if from_env:
+        res["dual_solver"] = f"{dual_solver} (from the environment: ZF_DUAL_SOLVER)"
     if status == _lib.ZF_MAXITER:
         warn(res.message, stacklevel=2)   # :543
     return res
