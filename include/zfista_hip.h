@@ -346,6 +346,12 @@ int zf_mo_create(zf_mo** out, int32_t kind, int32_t m, int64_t n, const double* 
  * so that every rank continues with identical scalars; returns nonzero on failure. */
 typedef int (*zf_mo_exchange_fn)(void* ctx, double* vals, int32_t count, int32_t max_index);
 int zf_mo_set_shard(zf_mo* s, int64_t n_global, int64_t offset, zf_mo_exchange_fn fn, void* ctx);
+/* the same sharding over a communicator of the library instead of a callback: the totals of every reduction are
+ * all-gathered on the stream and added in rank order on the device, and zf_mo_solve_dual exchanges once per BATCH
+ * of its search (<= m + 1 points: ~3 collectives per trial) instead of once per dual evaluation.  The device-side
+ * search (zf_mo_solve_dual_device / zf_mo_trial_launch) stays single-rank.  zf_mo_exchange_count: collectives so far. */
+int zf_mo_set_comm(zf_mo* s, zf_comm* comm, int64_t n_global, int64_t offset);
+int zf_mo_exchange_count(zf_mo* s, int64_t* count);
 /* per-coordinate box bounds (host arrays of n) instead of the scalar pair given at creation */
 int zf_mo_set_bounds(zf_mo* s, const double* lo_host, const double* hi_host);
 int zf_mo_destroy(zf_mo* s);

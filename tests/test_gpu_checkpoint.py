@@ -1,6 +1,7 @@
 """GPU: checkpoint / resume of a device-resident solve.  The state is
 (x_k, x_{k-1}, control block); a solve resumed from it - in a new solver object, through a file,
-with the same or another chain length - continues bit for bit like the uninterrupted one."""
+with the same or another chain length - continues bit for bit like the uninterrupted one, and
+the resumed solve equals the ORACLE's uninterrupted solve (iterates 1e-10, lr / trial sequence exactly)."""
 import numpy as np
 import pytest
 
@@ -50,13 +51,33 @@ def test_resume_diag_is_bit_identical(kw, stop_after, tmp_path):
     first.solver.close()
     np.savez(tmp_path / "ckpt.npz", **state)                       # through a file
     state = dict(np.load(tmp_path / "ckpt.npz"))
+    # the ORACLE's uninterrupted solve of the same problem (zfista/proximal_gradient.py:463-554 restated in NumPy):
+    # what a resumed solve has to reproduce is the reference's run, not only this engine's own
+    import warnings
+
+    from conftest import rel_err
+    from oracle import cpu_ref
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*P.DiagQuadL1Ref(d, c, lam).callbacks(), x0,
+                                                 **(o | dict(return_all=True)))
     for sub in (0, 1, 4):                                          # same chain length, or another
         run = NativeRun.from_snapshot(prob, state, o | dict(sub_iters=sub))
         rows = np.concatenate(head + [_drain(run)])
         ctl = run.solver.ctl
         assert (int(ctl.nit), int(ctl.status), ctl.lr, int(ctl.total_trials)) == ref, sub
         assert np.array_equal(rows, ref_rows), sub
-        assert np.array_equal(run.solver.get_x(), ref_x), sub
+        x = run.solver.get_x()
+        assert np.array_equal(x, ref_x), sub
+        # ... and against the oracle: iteration count, final status, the lr / trial sequence across the
+        # snapshot, the error and objective traces, the final iterate
+        assert int(ctl.nit) == exp.nit and (int(ctl.status) == _lib.ZF_CONVERGED) == bool(exp.success), sub
+        assert np.array_equal(rows[:, _lib.TR_LR], np.asarray(exp.alllrs)), sub
+        assert np.array_equal(rows[:, _lib.TR_TRIALS], np.asarray(exp.alltrials, float)), sub
+        np.testing.assert_allclose(rows[:, _lib.TR_ERR], exp.allerrs, rtol=1e-10, atol=0)
+        np.testing.assert_allclose(rows[:, _lib.TR_F], exp.allfuns[1:], rtol=1e-10, atol=0)
+        assert rel_err(x, exp.x) <= 1e-10, sub
         run.solver.close()
 
 
@@ -99,3 +120,19 @@ def test_resume_least_squares_is_bit_identical(nesterov):
     rows = np.concatenate([head, _drain(run)])
     assert np.array_equal(rows, ref_rows)
     assert np.array_equal(run.solver.get_x(), ref_x)
+    # the resumed solve against the oracle's uninterrupted one
+    import warnings
+
+    from conftest import rel_err
+    from oracle import cpu_ref
+    from zfista_amd import _lib
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*P.LeastSquaresL1Ref(A, b, lam).callbacks(), np.zeros(200),
+                                                 **(o | dict(return_all=True)))
+    assert len(rows) == exp.nit == 40
+    assert np.array_equal(rows[:, _lib.TR_LR], np.asarray(exp.alllrs))
+    np.testing.assert_allclose(rows[:, _lib.TR_ERR], exp.allerrs, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(rows[:, _lib.TR_F], exp.allfuns[1:], rtol=1e-10, atol=0)
+    assert rel_err(run.solver.get_x(), exp.x) <= 1e-10

@@ -311,7 +311,7 @@ def test_device_dual_solver_cfg4_size():
     w_h, fun_h, nit_h = eng.solve_dual(lr, f_y, f0 + g0, False, None, 1e-12, 100000)
     before = eng.n_dual_evals
     w_d, fun_d, nit_d, err_d, f_d, g_d, _ = eng.solve_dual_device(lr, f_y, f0 + g0, False, None, 1e-12, 100000)
-    assert eng.n_dual_evals - before >= 4
+    assert eng.n_dual_evals - before >= 2
     # f(y) formed on the device (prepare_async): the same search, f(y) to the last bits of exp()
     eng.prepare_async()
     w_a, fun_a, nit_a, err_a, _, _, f_y_a = eng.solve_dual_device(lr, None, f0 + g0, False, None, 1e-12, 100000)
@@ -579,15 +579,18 @@ def test_dual_hessian_against_differences_of_the_gradient(variant):
     eng.close()
 
 
+@pytest.mark.parametrize("at", [1, 4])
 @pytest.mark.parametrize("ahead", ["1", "0"])
 @pytest.mark.parametrize("kind", ["jos1", "fds"])
-def test_device_trial_that_gives_up_falls_back_to_the_host_search(kind, ahead, monkeypatch):
+def test_device_trial_that_gives_up_falls_back_to_the_host_search(kind, ahead, at, monkeypatch):
     """k_dual_solve keeps its whole grid spinning on grid-wide hand-overs; when its workgroups are not all
     resident (another kernel / process / a CU mask holds CUs) a wait gives up, the record says ok = -1 and the
     solve must go on with the host-driven search - a UserWarning, not a failed solve.  The give-up is forced
-    here (zf_mo_debug_force_timeout) at the 4th device launch, with trials launched ahead and without: the
-    result equals the dual_solver="native" solve (the same search, host loop) to the accuracy the two agree
-    at anyway, with the same iteration count."""
+    here (zf_mo_debug_force_timeout) at the first device launch (a line search that then backtracks on the
+    host) and at the fourth (in the middle of a solve whose trials are all accepted, so that with trials
+    launched ahead the forced launch is one that runs: a gated launch behind a rejected trial exits at its gate
+    before any wait), with trials launched ahead and without.  The result equals the dual_solver="native"
+    solve (the same search, host loop) with the same iteration count."""
     from zfista_amd import minimize_proximal_gradient
     from zfista_amd.multiobjective import MoEngine
     from zfista_amd.problems import FDS, JOS1
@@ -597,11 +600,11 @@ def test_device_trial_that_gives_up_falls_back_to_the_host_search(kind, ahead, m
     if kind == "jos1":
         n = 20011
         make = lambda: JOS1(n, l1_ratios=np.array([1.0, 2.0]) / n, l1_shifts=[0.0, 1.0])   # noqa: E731
-        x0, kw = rng.uniform(-2, 4, n), dict(lr=64.0 * n, max_iter=12)     # backtracking line searches at the start
+        x0, kw = rng.uniform(-2, 4, n), dict(lr=(64.0 if at == 1 else 0.25) * n, max_iter=12)
     else:
         n = 3001
         make = lambda: FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0.0, 1.0, 2.0])   # noqa: E731
-        x0, kw = rng.uniform(-2, 2, n), dict(lr=1.0, max_iter=8)
+        x0, kw = rng.uniform(-2, 2, n), dict(lr=1.0 if at == 1 else 1e-9, max_iter=8)
     kw.update(nesterov=True, tol=0.0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -613,14 +616,14 @@ def test_device_trial_that_gives_up_falls_back_to_the_host_search(kind, ahead, m
 
         def counted(self, *a, _orig=orig, **k):
             launches["n"] += 1
-            if launches["n"] == 4:
+            if launches["n"] == at:
                 self.debug_force_timeout(1)
             return _orig(self, *a, **k)
 
         monkeypatch.setattr(MoEngine, name, counted)
     with pytest.warns(UserWarning, match="gave up waiting for its grid"):
         got = minimize_proximal_gradient(*make().callbacks(), x0, dual_solver="device", **kw)
-    assert launches["n"] >= 4
+    assert launches["n"] >= at
     assert (got.nit, got.status, got.success, got.message) == (want.nit, want.status, want.success, want.message)
     assert rel_err(got.x, want.x) <= 1e-9 and rel_err(got.x, clean.x) <= 1e-9
     np.testing.assert_allclose(got.fun, want.fun, rtol=1e-9)

@@ -140,6 +140,8 @@ SIGNATURES = {
     "zf_host_diag_grad": (C.c_int, [_P, _P, _P, _P, C.c_int64]),
     "zf_mo_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, C.c_int64, _P, _P, C.c_double, C.c_double, _P]),
     "zf_mo_set_shard": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "zf_mo_set_comm": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "zf_mo_exchange_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "zf_mo_set_bounds": (C.c_int, [_P, _P, _P]),
     "zf_mo_destroy": (C.c_int, [_P]),
     "zf_mo_set_x0": (C.c_int, [_P, _P]),

@@ -60,15 +60,20 @@ class LibComm:
         """One communicator per torch.distributed group and process (cached).  Collective."""
         import torch.distributed as dist
 
-        key = id(group) if group is not None else 0
-        if key in _CACHE:
-            return _CACHE[key]
+        # keyed on the group OBJECT (kept alive beside its communicator, so its id cannot be reused) and on
+        # (rank, world): after destroy_process_group + a new init the default group is another object and the
+        # stale communicator of the old world is never handed out
+        pg = group if group is not None else dist.group.WORLD
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        key = (id(pg), rank, world)
+        hit = _CACHE.get(key)
+        if hit is not None and hit[1] is pg:
+            return hit[0]
         box = [cls.new_unique_id() if rank == 0 else None]
         src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
         dist.broadcast_object_list(box, src=src, group=group)
         comm = cls(rank, world, box[0])
-        _CACHE[key] = comm
+        _CACHE[key] = (comm, pg)
         return comm
 
     def all_gather(self, send, recv, stream=None):

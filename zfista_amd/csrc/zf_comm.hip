@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <pthread.h>
 
+#include <mutex>
 #include <new>
 
 #include "zf_common.h"
@@ -33,23 +34,35 @@ struct rccl_api {
 };
 rccl_api g_rccl;
 
-int rccl_load() {
-    if (g_rccl.handle) return ZF_OK;
+std::once_flag g_rccl_once;
+char g_rccl_err[256] = "";
+
+// (once per process, whatever thread gets here first: rank threads of a local group may race to it)
+void rccl_load_once() {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names) {
         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
     }
-    if (!h) return zf_fail(ZF_ERR_STATE, "zf_comm: cannot load librccl (%s)", dlerror());
+    if (!h) {
+        snprintf(g_rccl_err, sizeof(g_rccl_err), "zf_comm: cannot load librccl (%s)", dlerror());
+        return;
+    }
     g_rccl.GetUniqueId = (int (*)(nccl_unique_id*))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(nccl_comm_t*, int, nccl_unique_id, int))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (int (*)(nccl_comm_t))dlsym(h, "ncclCommDestroy");
     g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t))dlsym(h, "ncclAllGather");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
-        return zf_fail(ZF_ERR_STATE, "zf_comm: librccl lacks an expected symbol%s");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
+        snprintf(g_rccl_err, sizeof(g_rccl_err), "zf_comm: librccl lacks an expected symbol");
+        return;
+    }
     g_rccl.handle = h;
+}
+int rccl_load() {
+    std::call_once(g_rccl_once, rccl_load_once);
+    if (!g_rccl.handle) return zf_fail(ZF_ERR_STATE, "%s", g_rccl_err);
     return ZF_OK;
 }
 int rccl_check(int rc, const char* what) {
@@ -121,16 +134,40 @@ extern "C" int zf_comm_create_local_group(zf_comm** out, int32_t world, int64_t 
     g->world = world;
     g->cap = cap_doubles;
     g->refs = world;
-    ZF_HIP(hipMalloc(&g->staging, sizeof(double) * 2 * world * cap_doubles));
-    g->ev = new hipEvent_t[2 * world];
-    for (int k = 0; k < 2 * world; ++k) ZF_HIP(hipEventCreateWithFlags(&g->ev[k], hipEventDisableTiming));
-    pthread_barrier_init(&g->barrier, nullptr, (unsigned)world);
-    for (int r = 0; r < world; ++r) {
-        zf_comm* c = new zf_comm();
-        c->rank = r;
-        c->world = world;
-        c->local = g;
-        out[r] = c;
+    // everything is released again on any failure below: nothing of a half-built group is handed out
+    int made_ev = 0, made_c = 0;
+    bool barrier_ok = false;
+    hipError_t e = hipMalloc(&g->staging, sizeof(double) * 2 * world * cap_doubles);
+    if (e == hipSuccess) {
+        g->ev = new (std::nothrow) hipEvent_t[2 * world];
+        if (!g->ev) e = hipErrorOutOfMemory;
+    }
+    for (; e == hipSuccess && made_ev < 2 * world; ++made_ev)
+        e = hipEventCreateWithFlags(&g->ev[made_ev], hipEventDisableTiming);
+    if (e != hipSuccess) made_ev = made_ev > 0 ? made_ev - 1 : 0;   // (the failing create made none)
+    if (e == hipSuccess) barrier_ok = pthread_barrier_init(&g->barrier, nullptr, (unsigned)world) == 0;
+    if (e == hipSuccess && barrier_ok) {
+        for (; made_c < world; ++made_c) {
+            zf_comm* c = new (std::nothrow) zf_comm();
+            if (!c) break;
+            c->rank = made_c;
+            c->world = world;
+            c->local = g;
+            out[made_c] = c;
+        }
+    }
+    if (e != hipSuccess || !barrier_ok || made_c < world) {
+        for (int r = 0; r < made_c; ++r) {
+            delete out[r];
+            out[r] = nullptr;
+        }
+        if (barrier_ok) pthread_barrier_destroy(&g->barrier);
+        for (int k = 0; k < made_ev; ++k) (void)hipEventDestroy(g->ev[k]);
+        delete[] g->ev;
+        if (g->staging) (void)hipFree(g->staging);
+        delete g;
+        if (e != hipSuccess) return zf_fail(ZF_ERR_HIP, "zf_comm_create_local_group: %s", hipGetErrorString(e));
+        return zf_fail(ZF_ERR_ARG, "zf_comm_create_local_group: out of host memory%s");
     }
     return ZF_OK;
 }
@@ -167,17 +204,28 @@ extern "C" int zf_comm_info(zf_comm* c, int32_t* rank, int32_t* world) {
 extern "C" int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream) {
     ZF_REQUIRE(c && send_dev && recv_dev && count >= 0, "zf_comm_all_gather: bad argument");
     if (c->local) {
+        // Every rank thread reaches BOTH barriers whatever happens in between: a failure (a bad count, a HIP error)
+        // is remembered, the barriers are met, and only then reported - a rank that returned early would leave the
+        // others of the group waiting forever.
         zf_local_group* g = c->local;
-        ZF_REQUIRE(count <= g->cap, "zf_comm_all_gather: count exceeds the local group's staging capacity");
+        hipError_t e = hipSuccess;
+        const bool fits = count <= g->cap;
         const int par = (int)(c->calls++ & 1u);
         double* stage = g->staging + (int64_t)par * g->world * g->cap;
         hipStream_t st = (hipStream_t)stream;
-        ZF_HIP(hipMemcpyAsync(stage + (int64_t)c->rank * count, send_dev, sizeof(double) * count, hipMemcpyDeviceToDevice, st));
-        ZF_HIP(hipEventRecord(g->ev[par * g->world + c->rank], st));
+        if (fits) {
+            e = hipMemcpyAsync(stage + (int64_t)c->rank * count, send_dev, sizeof(double) * count, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipEventRecord(g->ev[par * g->world + c->rank], st);
+        }
         pthread_barrier_wait(&g->barrier);   // every rank's copy-in is enqueued and its event recorded
-        for (int r = 0; r < g->world; ++r) ZF_HIP(hipStreamWaitEvent(st, g->ev[par * g->world + r], 0));
-        ZF_HIP(hipMemcpyAsync(recv_dev, stage, sizeof(double) * count * g->world, hipMemcpyDeviceToDevice, st));
+        if (fits && e == hipSuccess) {
+            for (int r = 0; r < g->world && e == hipSuccess; ++r) e = hipStreamWaitEvent(st, g->ev[par * g->world + r], 0);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(recv_dev, stage, sizeof(double) * count * g->world, hipMemcpyDeviceToDevice, st);
+        }
         pthread_barrier_wait(&g->barrier);   // nobody re-records an event of this parity before all waits are enqueued
+        if (!fits) return zf_fail(ZF_ERR_ARG, "zf_comm_all_gather: count exceeds the local group's staging capacity%s");
+        if (e != hipSuccess) return zf_fail(ZF_ERR_HIP, "zf_comm_all_gather (local group): %s", hipGetErrorString(e));
         return ZF_OK;
     }
     return rccl_check(g_rccl.AllGather(send_dev, recv_dev, (size_t)count, /*ncclDouble*/ 8, c->comm, (hipStream_t)stream),

@@ -352,6 +352,24 @@ struct machine {
         }
         phase = P_LS;
     }
+    // Acceptance of a step length t along d in the line search.  Armijo on the VALUES - or, where the values no
+    // longer resolve the decrease, on the DERIVATIVE along d.  Near the optimum the dual is a difference of sums
+    // of n terms: its value carries ~1e-12 |D| of rounding noise while a Newton step of length 1e-7 lowers it by
+    // ~1e-8 - Armijo then rejects steps that the gradient (accurate to ~1e-13 of its own scale, and what the KKT
+    // conditions are made of) shows to be right, and the search stalls five orders of magnitude short of what
+    // SciPy's gradient-driven trust-constr reaches on the same problem (G11 quad3: measured).  The approximate
+    // Wolfe conditions of Hager & Zhang (SIAM J. Optim. 16, 2005): phi(t) <= phi(0) + eps |phi(0)| and
+    // sigma phi'(0) <= phi'(t) <= (2 delta - 1) phi'(0) - the slope along d has shrunk, without overshooting.
+    ZF_DHD_INLINE bool ls_accept(double f_t, const double (&g_t)[M], double t) const {
+        if (f_t <= fun + 1e-4 * t * slope + 1e-15 * fabs(fun)) return true;
+        double gbar = 0.0, dphi = 0.0;   // (mean-free, like `slope`: see newton_model)
+#pragma unroll
+        for (int i = 0; i < M; ++i) gbar += g_t[i];
+        gbar /= M;
+#pragma unroll
+        for (int i = 0; i < M; ++i) dphi += (g_t[i] - gbar) * d[i];
+        return f_t <= fun + 1e-10 * fabs(fun) && dphi >= 0.9 * slope && dphi <= -(1.0 - 2e-4) * slope;
+    }
     ZF_DHD_INLINE void request_bracket_point() {
         if constexpr (M == 2) {
             br.s = (br.a * br.pb - br.b * br.pa) / (br.pb - br.pa);   // secant point of the bracket
@@ -428,24 +446,54 @@ struct machine {
         if (ev < 0.0)   // keep the model convex against finite-difference noise
 #pragma unroll
             for (int i = 0; i < M; ++i) Q[i][i] += 1e-12 - ev;
+        // The model is q . d + 1/2 d'Qd in the STEP d = w' - w; written in w' (what simplex_qp solves) its linear
+        // term is q - Q w.  Analytically Q w = T'H (T w) = 0, but a probed Q satisfies that only to ~1e-8 |Q|:
+        // leaving the term out moved every Newton point by ~1e-9 and the search stalled at a gradient residual
+        // 1e5 x the one an exact tangent-space Newton step reaches (measured on G11's quad3 problems).  Both are
+        // scaled to O(1) entries: the KKT systems couple Q with the constraint row of ones.
+        double qs = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) qs = fabs(Q[i][j]) > qs ? fabs(Q[i][j]) : qs;
+        qs = qs > 0.0 ? 1.0 / qs : 1.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
             double t = 0.0;
 #pragma unroll
             for (int r = 0; r < M; ++r) t += T[r][i] * grad[r];
-            q[i] = t;
+#pragma unroll
+            for (int j = 0; j < M; ++j) t -= Q[i][j] * w[j];
+            q[i] = t * qs;
             w_new[i] = 0.0;
         }
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) Q[i][j] *= qs;
         simplex_qp(q, Q, w_new);
+        // slope = grad . d with the mean of the gradient taken out first: d sums to zero only up to rounding, and
+        // the common part of the gradient (F_old - f_y and friends: 1e5 where the differences that matter are
+        // 1e-4) times that rounding residue is as large as the true slope of the last Newton steps
+        double gbar = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) gbar += grad[i];
+        gbar /= M;
         step = 0.0, slope = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
             d[i] = w_new[i] - w[i];
             step = fabs(d[i]) > step ? fabs(d[i]) : step;
-            slope += grad[i] * d[i];
+            slope += (grad[i] - gbar) * d[i];
         }
-        // stop at `tol` in w, or when the model predicts no decrease resolvable in double precision
-        if (step <= tol || slope >= -4e-16 * (fabs(fun) > 1.0 ? fabs(fun) : 1.0))
+        // stop at `tol` in w, or when the predicted decrease grad . d is below what the GRADIENT resolves: its
+        // components are sums of n terms with ~4e-16 (|D| + |grad|) of rounding noise each, so along a step of
+        // length `step` nothing below noise x step is information.  (Round 2 compared the slope with the noise of
+        // the VALUE, 4e-16 |D|, and stopped at |dw| ~ 1e-7 where SciPy's gradient-driven search reaches 1e-13.)
+        double gmax = fabs(fun) > 1.0 ? fabs(fun) : 1.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) gmax = fabs(grad[i]) > gmax ? fabs(grad[i]) : gmax;
+        if (step <= tol || slope >= -4e-16 * gmax * step)
             return finish(nit > max_iter ? max_iter : nit);
         return request_line_search(1.0);
     }
@@ -526,7 +574,7 @@ struct machine {
         for (int i = 0; i < M; ++i) g_pick[i] = p_pick[i] = 0.0;
 #pragma unroll
         for (int k = 0; k < LS_BATCH; ++k) {
-            const bool take = !picked && (funs[k] <= fun + 1e-4 * t * slope + 1e-15 * fabs(fun) || t < 1e-10);
+            const bool take = !picked && (ls_accept(funs[k], jacs[k], t) || t < 1e-10);
             if (take) {
                 picked = true;
                 t_acc = t;
@@ -680,7 +728,7 @@ struct machine {
             for (int i = 0; i < M; ++i) g_pick[i] = p_pick[i] = 0.0;
 #pragma unroll
             for (int k = 0; k < LS_BATCH; ++k) {
-                const bool take = !picked && (funs[k] <= fun + 1e-4 * t * slope + 1e-15 * fabs(fun) || t < 1e-10);
+                const bool take = !picked && (ls_accept(funs[k], jacs[k], t) || t < 1e-10);
                 if (take) {
                     picked = true;
                     t_acc = t;

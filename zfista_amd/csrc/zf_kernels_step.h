@@ -120,6 +120,7 @@ constexpr int ZF_TILE_U = 4;
 constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per tile
 constexpr int ZF_MAX_TILES_PER_WG = 24;               // upper bound of zf_step_args.tiles_per_wg
 constexpr int ZF_FIN_WGS = 48;                        // workgroups of the finalize kernel
+constexpr int ZF_FIN_GROUPS = 64;                     // groups of the in-kernel finalisation (zf_pass_tail)
 constexpr int ZF_FIN_THREADS = 256;
 
 typedef double zf_d2 __attribute__((ext_vector_type(2)));
@@ -159,11 +160,15 @@ typedef __attribute__((address_space(3))) void* zf_lds_ptr;
 #ifndef ZF_S16_GLDS
 #define ZF_S16_GLDS 1
 #endif
+// Two experiments of round 3, both measured and both left OFF (profiles/r03_variants_ab.json; one box, n = 1e8 and 1e7):
+// a third DMA stage (two units in flight ahead of the chain: full chain 1.181 vs 1.191 ms at n = 1e8, 0.131 vs 0.128
+// at 1e7 - the pipe is not latency-bound) and the DMA path for the 8-trial bodies that serve the short passes of a
+// 16-chain solver (passes after a rejection 1.22 - 1.30 ms vs 1.16 ms with plain register loads at 3 waves per SIMD).
 #ifndef ZF_S8_GLDS
-#define ZF_S8_GLDS 1   // the 8-trial bodies that serve the short passes of a 16-chain solver (PART 1) load by DMA too
+#define ZF_S8_GLDS 0   // 1: the 8-trial bodies of PART 1 load by DMA too
 #endif
 #ifndef ZF_GLDS_STAGES
-#define ZF_GLDS_STAGES 3   // LDS stages of the DMA pipeline: units in flight ahead of the one being computed + 1
+#define ZF_GLDS_STAGES 2   // LDS stages of the DMA pipeline: units in flight ahead of the one being computed + 1
 #endif
 // SP = packs per pass of the solver (S <= SP): the 8-trial bodies use the DMA path only inside a 16-chain solver
 template <int S, int MODE, bool HIST, bool GRAD_INLINE, int SP = S> constexpr bool zf_uses_glds() {
@@ -200,6 +205,18 @@ struct zf_step_args {
     double* hist;             // HIST kernels: ring of hist_cap iterates (n doubles each); the iterate of
     int64_t hist_cap;         //   iteration k goes to slot k % hist_cap, written by the trial that computes it
     int64_t hist_stride;      // doubles between slots (>= n, 512-B aligned)
+    // In-kernel finalisation (separable problems, zf_pass_tail): the workgroup rows are reduced by last arrivers
+    // inside the SAME launch - groups of fin_gsz workgroups first, then the fin_ng group rows - and the last of
+    // them builds the packs and (decide) runs the decide pass: a pass is ONE launch.
+    int fin_mode;             // 0: rows stored plainly, a zf_finalize_kernel launch follows (least squares); 1: in-kernel
+    int fin_gsz, fin_ng;      // workgroups per group and groups: functions of the grid - hence of n - only
+    double* grp_part;         // [S * ZF_NPART][fin_ng] group rows
+    unsigned* fin_cnt;        // [0] arrival counter of the groups, [1 + g] of group g's workgroups (zero between launches)
+    double fin_scale_f, fin_scale_g;   // f = fin_scale_f x sum, g = fin_scale_g x sum |x|
+    double* pack;             // local packs out (S x ZF_PACK_LEN)
+    zf_control* ctl_rw;       // the control block, writable: the decide pass of the last arriver
+    int decide;               // unsharded x: decide here; sharded: the packs are gathered first (zf_decide_kernel)
+    double* trace;
 };
 
 struct zf_finalize_args {
@@ -344,6 +361,118 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
     }
     // unsharded x: the decide pass right here, trial j evaluated by its lane
     if (F.decide) zf_decide_pass_wave(F.ctl, s_pack, pk, F.trace, F.beta_ring, lane, LSTR, s_pre);
+}
+
+// Finalisation INSIDE the trial launch (fin_mode 1).  Thread t < NQ of every workgroup holds row value t of its
+// workgroup (quantity t % 6 of trial t / 6).  The rows are published write-through (sc1: the L2s of the XCDs are not
+// coherent with each other), the workgroup takes a ticket in its GROUP of fin_gsz consecutive workgroups; the last
+// arriver of a group adds the group's rows in INDEX order (thread t: quantity t; the loads are independent, the
+// additions sequential), publishes the group row and takes a ticket among the fin_ng groups; the last of those adds
+// the group rows in group order, builds the S packs and (decide) runs zf_decide_pass: model value, acceptance, lr
+// decay, failure, termination, buffer hand-over, trace rows (proximal_gradient.py:149-155,:298-307,:510,:525,:539).
+// Deterministic - sums in index order, no float atomics - and a function of the grid only, hence of n only: every
+// chain length S, every process and every rank layout with equal shards reduces the same elements in the same
+// order.  Most groups finish while others still compute; on the critical path are the last group's fin_gsz rows
+// and the fin_ng <= 64 group rows: 2 - 3 us, against a separate finalize launch of 15 - 26 us behind a kernel
+// boundary (round 2).  Every other workgroup has taken its ticket - has read the control block for the last time -
+// before the one that writes it gets there.
+template <int SP>
+__device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double v) {
+    constexpr int NQ = SP * ZF_NPART;
+    __shared__ int s_role;
+    __shared__ double s_tot[NQ];
+    __shared__ double s_pack[ZF_MAX_SUB_ITERS * ZF_PACK_LEN];
+    __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
+    const int t = threadIdx.x, G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int gsz = A.fin_gsz, ng = A.fin_ng;
+    const bool grouped = gsz > 1;
+    const bool is_max = (t % ZF_NPART == ZF_NPART - 1);
+    if (t < NQ) zf_publish(A.blk_part + (int64_t)t * G + b, v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (NQ up to 96: the publishers sit in two waves)
+    if (t == 0) {
+        const int g = grouped ? b / gsz : 0;
+        unsigned* cnt = grouped ? A.fin_cnt + 1 + g : A.fin_cnt;
+        int members = G;
+        if (grouped) members = (g + 1) * gsz <= G ? gsz : G - g * gsz;
+        const unsigned tk = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int role = 0;
+        if (tk == (unsigned)(members - 1)) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            role = grouped ? 1 : 2;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_role = role;
+    }
+    __syncthreads();
+    if (s_role == 0) return;
+    // rows[0 .. count) of quantity t, added in index order with a COMPENSATED sum (Neumaier): the additions at this
+    // level run at the full magnitude of the total, where every plain addition costs half an ulp of F - and the
+    // acceptance test (:303) subtracts two such totals.  At the resolution limit of that test rounding
+    // noise in the sums is what rejects trials: with plain index-order sums of the rows a 400-iteration solve at
+    // n = 1e7 took 127 rejections and ended in "Backtracking failed", with the two-level tree of round 2 about 20,
+    // the reference's NumPy sums 5 in 110 iterations.  Up to 32 loads are in flight at once (one round trip to memory per
+    // 32 rows: the rows are read write-through / sc1, every load misses the caches by design).
+    auto sum_rows = [&](const double* rows, int count) -> double {
+        double acc = 0.0, comp = 0.0;
+        for (int k0 = 0; k0 < count; k0 += 32) {
+            double p[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) p[u] = (k0 + u < count) ? zf_consume(rows + k0 + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                if (is_max) {
+                    acc = fmax(acc, p[u]);
+                } else {
+                    const double tsum = acc + p[u];
+                    comp += (fabs(acc) >= fabs(p[u])) ? (acc - tsum) + p[u] : (p[u] - tsum) + acc;
+                    acc = tsum;
+                }
+            }
+        }
+        return is_max ? acc : acc + comp;
+    };
+    if (s_role == 1) {
+        const int g = b / gsz, b0 = g * gsz;
+        const int b1 = b0 + gsz <= G ? b0 + gsz : G;
+        if (t < NQ) zf_publish(A.grp_part + (int64_t)t * ng + g, sum_rows(A.blk_part + (int64_t)t * G + b0, b1 - b0));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            const unsigned tk = __hip_atomic_fetch_add(A.fin_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (tk == (unsigned)(ng - 1));
+            if (last) __hip_atomic_store(A.fin_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_role = last ? 2 : 0;
+        }
+        __syncthreads();
+        if (s_role != 2) return;
+    }
+    if (t < NQ) s_tot[t] = grouped ? sum_rows(A.grp_part + (int64_t)t * ng, ng) : sum_rows(A.blk_part + (int64_t)t * G, G);
+    __syncthreads();
+    if (t >= 64) return;
+    // wave 0: lane j * LSTR builds, keeps and stores pack j; then the decide pass, trial j evaluated by its lane
+    constexpr int SH = zf_chain_h(SP);
+    constexpr int LSTR = 64 >> SH;
+    const int trial = t / LSTR;
+    const double* q = s_tot + trial * ZF_NPART;
+    double pk[ZF_PACK_LEN];
+    pk[ZF_PK_FY] = A.fin_scale_f * q[0];
+    pk[ZF_PK_DOT] = q[1];
+    pk[ZF_PK_SS] = q[2];
+    pk[ZF_PK_GX] = A.fin_scale_g * q[3];
+    pk[ZF_PK_FX] = A.fin_scale_f * q[4];
+    pk[ZF_PK_ERR] = q[5];
+    pk[6] = 0.0;
+    pk[7] = 0.0;
+    if (t % LSTR == 0) {
+#pragma unroll
+        for (int k = 0; k < ZF_PACK_LEN; ++k) {
+            A.pack[trial * ZF_PACK_LEN + k] = pk[k];
+            s_pack[trial * ZF_PACK_LEN + k] = pk[k];
+        }
+    }
+    if (A.decide) zf_decide_pass_wave(A.ctl_rw, s_pack, pk, A.trace, A.beta_ring, t, LSTR, s_pre);
 }
 
 // GRAD_INLINE: true  -> separable quadratic, gradient computed from d, c
@@ -664,16 +793,18 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
         lds[wave * NQ + zf_wave_reduce_multi_index<S, H>(0, lane) * ZF_NPART + 5] = maxs[0];
     }
     __syncthreads();
-    if (threadIdx.x < SP * ZF_NPART) {
+    double v = 0.0;   // (rows of trials S .. SP - 1: no such trial in this pass)
+    if (threadIdx.x < NQ) {
         const int t = threadIdx.x;
-        double v = 0.0;   // (rows of trials S .. SP - 1: no such trial in this pass)
-        if (t < NQ) {
-            v = lds[t];
+        v = lds[t];
 #pragma unroll
-            for (int w = 1; w < ZF_WAVES; ++w) v = (t % ZF_NPART == 5) ? fmax(v, lds[w * NQ + t]) : v + lds[w * NQ + t];
-        }
-        A.blk_part[(int64_t)t * gridDim.x + blockIdx.x] = v;
+        for (int w = 1; w < ZF_WAVES; ++w) v = (t % ZF_NPART == 5) ? fmax(v, lds[w * NQ + t]) : v + lds[w * NQ + t];
     }
+    if (A.fin_mode == 0) {   // a zf_finalize_kernel launch follows
+        if (threadIdx.x < SP * ZF_NPART) A.blk_part[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+        return;
+    }
+    zf_pass_tail<SP>(A, v);
 }
 
 // PART (chains only, S > 1): a pass is launched as TWO kernels (S = 16: THREE), each of which exits at

@@ -239,6 +239,20 @@ __global__ __launch_bounds__(64 * MO_RED_WAVES) void k_mo_reduce(const double* _
 }
 
 
+// the gathered totals of all ranks (rank-major, `count` each) added in RANK ORDER - entry max_index a maximum -
+// so that every rank continues with bitwise-identical scalars (C3)
+__global__ void k_mo_combine_ranks(const double* __restrict__ gathered, int world, int count, int max_index,
+                                   double* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    double v = gathered[q];
+    for (int r = 1; r < world; ++r) {
+        const double p = gathered[(int64_t)r * count + q];
+        v = (q == max_index) ? fmax(v, p) : v + p;
+    }
+    out[q] = v;
+}
+
 // f(y) from the raw sums, on the device (zf_mo_prepare_async: no host round trip between the sums
 // of f(y), the Jacobian kernel that needs sum(y), and the dual search that needs f(y))
 __host__ __device__ __attribute__((always_inline)) inline void mo_f_from_sums(int kind, double dn, const double* t, double* f_out) {
@@ -1154,6 +1168,16 @@ struct zf_mo {
     double* bounds_v = nullptr;             // 2 n: per-coordinate lower, upper bounds (optional)
     zf_mo_exchange_fn exchange = nullptr;   // combines raw totals over the ranks, in place
     void* exchange_ctx = nullptr;
+    // ... or, instead of the callback: a communicator of the library (zf_mo_set_comm) - the totals of every
+    // reduction are all-gathered on the stream and added in rank order on the device; the library's own dual
+    // search then exchanges once per BATCH of its state machine, not once per evaluation
+    zf_comm* comm = nullptr;
+    int comm_world = 1;
+    double* cm_partials = nullptr;   // MO_CM_CAP x grid: block partials of every point of a batch
+    double* cm_totals = nullptr;     // MO_CM_CAP: this rank's totals of the batch
+    double* cm_gathered = nullptr;   // world x MO_CM_CAP, rank-major
+    double* h_cm = nullptr;          // pinned host mirror of the combined totals
+    int64_t n_exchanges = 0;         // collectives issued so far (diagnostics / tests)
     // device-side dual search (k_dual_solve): workspace, allocated at first use
     unsigned long long* solve_partials = nullptr;
     unsigned long long* solve_totals = nullptr;
@@ -1182,6 +1206,11 @@ struct zf_mo {
     unsigned spin_limit = MO_SPIN_LIMIT;
     int force_timeouts = 0;           // test hook: this many of the next launches report a timeout
 };
+
+struct zf_comm;
+extern "C" int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream);
+extern "C" int zf_comm_info(zf_comm* c, int32_t* rank, int32_t* world);
+constexpr int MO_CM_CAP = (zf_dual::MAXM + 1) * (2 * MO_MAX_M + 2);   // totals of one batch: <= m + 1 points x (2m + 2)
 
 static int mo_prepare_async_now(zf_mo* s);
 // pending work of the fused mode, done the unfused way (k_commit; the four launches of prepare_async)
@@ -1218,6 +1247,15 @@ static int mo_reduce_to_host(zf_mo* s, int nq, int max_index, double* host) {
     hipLaunchKernelGGL(k_mo_reduce, dim3(1), dim3(64 * MO_RED_WAVES), 0, s->stream, s->partials, s->grid, nq, max_index,
                        s->totals);
     ZF_HIP(hipGetLastError());
+    if (s->comm) {
+        // the library's communicator: all-gather on the stream, rank-ordered sum on the device (the totals stay
+        // there for the kernels that read them: FDS needs the global sum x), one copy to the host
+        if (int rc = zf_comm_all_gather(s->comm, s->totals, s->cm_gathered, nq, s->stream)) return rc;
+        s->n_exchanges += 1;
+        hipLaunchKernelGGL(k_mo_combine_ranks, dim3(1), dim3(64), 0, s->stream, s->cm_gathered, s->comm_world, nq, max_index,
+                           s->totals);
+        ZF_HIP(hipGetLastError());
+    }
     ZF_HIP(hipMemcpyAsync(s->h_totals, s->totals, sizeof(double) * nq, hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
     memcpy(host, s->h_totals, sizeof(double) * nq);
@@ -1311,6 +1349,37 @@ extern "C" int zf_mo_set_shard(zf_mo* s, int64_t n_global, int64_t offset, zf_mo
     return ZF_OK;
 }
 
+// The same sharding with a communicator of the library (zf_comm_create / zf_comm_create_local_group) in place of
+// the callback: every reduction all-gathers its raw totals on the stream and adds them in rank order on the
+// device (no host code per exchange), and zf_mo_solve_dual exchanges once per BATCH of its search - the start
+// point with its m curvature probes, the two step lengths of a line search - instead of once per evaluation.
+// The communicator must outlive the engine; rank / world are its own.
+extern "C" int zf_mo_set_comm(zf_mo* s, zf_comm* comm, int64_t n_global, int64_t offset) {
+    ZF_REQUIRE(s && comm, "zf_mo_set_comm: null argument");
+    ZF_REQUIRE(offset >= 0 && offset + s->n <= n_global, "zf_mo_set_comm: block outside the vector");
+    ZF_REQUIRE(!s->exchange, "zf_mo_set_comm: an exchange callback is already set (zf_mo_set_shard)");
+    int32_t rank = 0, world = 1;
+    if (int rc = zf_comm_info(comm, &rank, &world)) return rc;
+    if (!s->cm_partials) {
+        ZF_HIP(hipMalloc(&s->cm_partials, sizeof(double) * MO_CM_CAP * MO_GRID_MAX));
+        ZF_HIP(hipMalloc(&s->cm_totals, sizeof(double) * MO_CM_CAP));
+        ZF_HIP(hipHostMalloc((void**)&s->h_cm, sizeof(double) * MO_CM_CAP, hipHostMallocDefault));
+    }
+    if (s->cm_gathered) (void)hipFree(s->cm_gathered);
+    s->cm_gathered = nullptr;
+    ZF_HIP(hipMalloc(&s->cm_gathered, sizeof(double) * MO_CM_CAP * world));
+    s->comm = comm;
+    s->comm_world = world;
+    s->n_global = n_global;
+    s->offset = offset;
+    return ZF_OK;
+}
+extern "C" int zf_mo_exchange_count(zf_mo* s, int64_t* count) {
+    ZF_REQUIRE(s && count, "zf_mo_exchange_count: null argument");
+    *count = s->n_exchanges;
+    return ZF_OK;
+}
+
 // Per-coordinate box (arrays of n; this rank's block when sharded): replaces the scalar bounds.
 extern "C" int zf_mo_set_bounds(zf_mo* s, const double* lo_host, const double* hi_host) {
     ZF_REQUIRE(s && lo_host && hi_host, "zf_mo_set_bounds: null argument");
@@ -1334,6 +1403,10 @@ extern "C" int zf_mo_destroy(zf_mo* s) {
     if (s->h_solve_out) (void)hipHostFree(s->h_solve_out);
     if (s->accept_dev) (void)hipFree(s->accept_dev);
     if (s->F_dev) (void)hipFree(s->F_dev);
+    if (s->cm_partials) (void)hipFree(s->cm_partials);
+    if (s->cm_totals) (void)hipFree(s->cm_totals);
+    if (s->cm_gathered) (void)hipFree(s->cm_gathered);
+    if (s->h_cm) (void)hipHostFree(s->h_cm);
     (void)hipFree(s->buf);
     (void)hipFree(s->partials);
     (void)hipFree(s->totals);
@@ -1428,7 +1501,7 @@ extern "C" int zf_mo_prepare(zf_mo* s, double* f_y_out) {
 extern "C" int zf_mo_prepare_async(zf_mo* s) {
     ZF_REQUIRE(s, "zf_mo_prepare_async: null argument");
     ZF_REQUIRE(s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS, "zf_mo_prepare_async: f is a host callback for this kind");
-    ZF_REQUIRE(!s->exchange, "zf_mo_prepare_async: x is sharded over ranks (use zf_mo_prepare)");
+    ZF_REQUIRE(!s->exchange && !s->comm, "zf_mo_prepare_async: x is sharded over ranks (use zf_mo_prepare)");
     if (!s->f_y_dev) ZF_HIP(hipMalloc(&s->f_y_dev, sizeof(double) * MO_MAX_M));
     if (s->fused && s->m <= 3) {   // formed by the next zf_mo_solve_dual_device (or by mo_flush)
         s->prep_pending = true;
@@ -1569,6 +1642,73 @@ int mo_dual_fn(void* vctx, const double* w, double* fun, double* jac) {
 }
 }  // namespace
 
+// The same search with x sharded over the ranks of a library communicator: the points of a batch are evaluated
+// back to back (one k_dual_eval + one reduce each, nothing synchronised in between), their 2m + 2 totals travel
+// in ONE all-gather, are added in rank order on the device and come to the host in ONE copy - all ranks advance
+// identical copies of the state machine on identical numbers.
+namespace {
+template <int M>
+int mo_solve_dual_batched(zf_mo* s, double lr, const double* f_y, const double* F_old, int deprecated, const double* w0,
+                          double tol, long max_iter, double* w_out, double* fun_out, long* nit_out, int* ok_out,
+                          int64_t* evals) {
+    constexpr int NQ = 2 * M + 2;
+    using mach_t = zf_dual::machine<M>;
+    mach_t S;
+    S.start(w0, tol, max_iter);
+    double funs[mach_t::NB] = {0}, jacs[mach_t::NB][M] = {{0}};
+    static_assert(mach_t::NB * NQ <= MO_CM_CAP, "batch buffers too small");
+    while (!S.done()) {
+        const int npts = S.npts;
+        for (int k = 0; k < npts; ++k) {
+            mo_w W;
+            mo_fill_w(s, lr, S.pts[k], &W);
+            hipLaunchKernelGGL(k_dual_eval<M>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, W, s->n,
+                               s->cm_partials + (int64_t)k * NQ * s->grid);
+        }
+        // (quantity-major partials of consecutive points are one [npts * NQ][grid] array: one reduce launch)
+        hipLaunchKernelGGL(k_mo_reduce, dim3(1), dim3(64 * MO_RED_WAVES), 0, s->stream, s->cm_partials, s->grid, npts * NQ, -1,
+                           s->cm_totals);
+        ZF_HIP(hipGetLastError());
+        if (int rc = zf_comm_all_gather(s->comm, s->cm_totals, s->cm_gathered, npts * NQ, s->stream)) return rc;
+        s->n_exchanges += 1;
+        hipLaunchKernelGGL(k_mo_combine_ranks, dim3((npts * NQ + 63) / 64), dim3(64), 0, s->stream, s->cm_gathered,
+                           s->comm_world, npts * NQ, -1, s->cm_totals);
+        ZF_HIP(hipGetLastError());
+        ZF_HIP(hipMemcpyAsync(s->h_cm, s->cm_totals, sizeof(double) * npts * NQ, hipMemcpyDeviceToHost, s->stream));
+        ZF_HIP(hipStreamSynchronize(s->stream));
+        *evals += npts;
+        for (int k = 0; k < npts; ++k) {   // D(w), grad D(w) as mo_dual_fn composes them (:165-177)
+            const double* t = s->h_cm + k * NQ;
+            const double* w = S.pts[k];
+            double g_p[M], inner = 0.0;
+            for (int i = 0; i < M; ++i) {
+                g_p[i] = s->G.has_l1 ? s->G.ratio[i] * t[i] : 0.0;
+                inner += w[i] * g_p[i];
+            }
+            const double n_pv = sqrt(t[M]), n_wJ = sqrt(t[M + 1]);
+            double f = -inner - n_pv * n_pv / 2 / lr + lr / 2 * (n_wJ * n_wJ);
+            for (int i = 0; i < M; ++i) jacs[k][i] = -g_p[i] - t[M + 2 + i];
+            if (!deprecated) {
+                double corr = 0.0;
+                for (int i = 0; i < M; ++i) {
+                    const double dF = F_old[i] - f_y[i];
+                    corr += w[i] * dF;
+                    jacs[k][i] += dF;
+                }
+                f += corr;
+            }
+            funs[k] = f;
+        }
+        S.advance(funs, jacs);
+    }
+    *ok_out = S.ok;
+    for (int i = 0; i < M; ++i) w_out[i] = S.w[i];
+    *fun_out = S.fun;
+    *nit_out = S.nit;
+    return ZF_OK;
+}
+}  // namespace
+
 // w0 may be NULL (uniform start).  *ok_out = 0: the start point is not finite (e.g. F(x_k) = inf
 // outside the box) - nothing was solved, use the reference's SciPy calls.  *evals_out counts the
 // dual evaluations spent.
@@ -1578,6 +1718,24 @@ extern "C" int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const do
     ZF_REQUIRE(s && f_y && F_old && w_out && fun_out && nit_out && ok_out, "zf_mo_solve_dual: null argument");
     ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_solve_dual: lr must be > 0 and max_iter >= 1");
     if (int rc = mo_flush(s)) return rc;
+    if (s->comm) {   // sharded over a library communicator: one exchange per batch of the search
+        long nit = 0;
+        int ok = 1;
+        double fun = 0.0;
+        int64_t evals = 0;
+        int rc = ZF_ERR_ARG;
+        switch (s->m) {
+#define ZF_MO_BATCHED(MM) case MM: rc = mo_solve_dual_batched<MM>(s, lr, f_y, F_old, (int)deprecated, w0, tol, (long)max_iter, w_out, &fun, &nit, &ok, &evals); break;
+            ZF_MO_BATCHED(2) ZF_MO_BATCHED(3) ZF_MO_BATCHED(4) ZF_MO_BATCHED(5) ZF_MO_BATCHED(6) ZF_MO_BATCHED(7) ZF_MO_BATCHED(8)
+#undef ZF_MO_BATCHED
+        }
+        if (evals_out) *evals_out = evals;
+        if (rc) return rc;
+        *fun_out = fun;
+        *nit_out = nit;
+        *ok_out = ok;
+        return ZF_OK;
+    }
     mo_dual_ctx ctx = {s, lr, f_y, F_old, (int)deprecated};
     zf_dual::evaluator E = {mo_dual_fn, &ctx, 0};
     long nit = 0;
@@ -1615,11 +1773,11 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
                     double tol, int64_t max_iter, const mo_launch_opts& L, int* slot_out, int* launched) {
     *launched = 0;
     // fused outer iteration: y (deferred commit), f(y) and J are formed by this launch itself
-    const bool fuse = s->fused && s->prep_pending && !f_y && !s->exchange && s->m <= 3 &&
+    const bool fuse = s->fused && s->prep_pending && !f_y && !s->exchange && !s->comm && s->m <= 3 &&
                       (s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS);
     if (!fuse)
         if (int rc = mo_flush(s)) return rc;
-    if (s->exchange || s->m > 3) return ZF_OK;   // sharded x: every evaluation needs an exchange; m > 3: register budget
+    if (s->exchange || s->comm || s->m > 3) return ZF_OK;   // sharded x: every evaluation needs an exchange; m > 3: register budget
     if (s->solve_unavailable) return ZF_OK;      // (the grid cannot be co-resident on this device: the caller's host loop)
     if (!s->solve_partials) {
         int dev = 0, cus = 0;

@@ -129,7 +129,8 @@ struct zf_solver {
     double* partials = nullptr;   // init-time evaluation partials
     double* blk_part = nullptr;   // ZF_NPART x max_grid per-workgroup partials of the trial kernel
     double* slice_part = nullptr; // ZF_NPART x ZF_FIN_WGS
-    unsigned* fin_cnt = nullptr;  // arrival counter of the finalize workgroups
+    unsigned* fin_cnt = nullptr;  // arrival counters: of the finalize workgroups / of the in-kernel finalisation (zf_pass_tail)
+    double* grp_part = nullptr;   // ZF_NPART x S x ZF_FIN_GROUPS group rows of the in-kernel finalisation
     bool nt = true;               // nontemporal policy for once-touched streams
     zf_control* ctl = nullptr;
     double* trace = nullptr;      // ZF_RING * ZF_TRACE_COLS
@@ -172,6 +173,14 @@ struct zf_solver {
     int64_t n_full = 0, n_part = 0;
     int64_t fresh_part = 0, lag_part = 0;   // fresh trials / replayed iterations carried by the other passes
     zf_comm* comm = nullptr;              // RCCL communicator (zf_solver_set_comm): the solver gathers itself
+    // Which shape-specific kernel a pass needs is decided on the device; the host PREDICTS it from the control
+    // block of its last poll (zf_predict_parts) and launches only that one.  A wrong prediction costs passes that
+    // do nothing (no kernel finds its shape, the control block stays as it is), never a wrong result.
+    int part_mask = 7;
+    zf_control shadow;                    // the control block as the host expects it after the passes enqueued so far
+    bool shadow_valid = false;            // false until the next poll (after init / restore / flush / set_max_iter ...)
+    bool careful = false;                 // the last chunk saw rejections: launch every kernel of a pass
+    int64_t polled_rejections = 0;
     // streaming return_all: caller-owned ring of iterates in HBM (zf_solver_set_history)
     double* hist = nullptr;
     int64_t hist_cap = 0, hist_stride = 0;
@@ -179,7 +188,7 @@ struct zf_solver {
 constexpr int ZF_PASS_LOG = 4096;
 
 static int zf_solver_free_all(zf_solver* s) {
-    void* ptrs[] = {s->row_part, s->ls_cnt, s->pass_log, s->blk_part, s->slice_part, s->fin_cnt, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
+    void* ptrs[] = {s->row_part, s->ls_cnt, s->pass_log, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
                     s->own_svec ? s->s_part : nullptr, s->own_svec ? s->s_all : nullptr};
@@ -264,8 +273,9 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         ZF_TRY(hipMalloc(&s->blk_part, sizeof(double) * ZF_NPART * s->sub * parts));
     }
     ZF_TRY(hipMalloc(&s->slice_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_WGS));
-    ZF_TRY(hipMalloc(&s->fin_cnt, 64));
-    ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, 64, s->stream));
+    ZF_TRY(hipMalloc(&s->fin_cnt, sizeof(unsigned) * (ZF_FIN_GROUPS + 16)));
+    ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, sizeof(unsigned) * (ZF_FIN_GROUPS + 16), s->stream));
+    ZF_TRY(hipMalloc(&s->grp_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_GROUPS));
     ZF_TRY(hipMalloc(&s->ctl, sizeof(zf_control)));
     ZF_TRY(hipMalloc(&s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS));
     ZF_TRY(hipMalloc(&s->beta_ring, sizeof(double) * ZF_RING));
@@ -328,9 +338,12 @@ extern "C" int zf_solver_destroy(zf_solver* s) {
 template <bool GI, bool NEST, bool BOX, bool NT, int S, bool HIST>
 static void zf_launch_trial_parts(zf_solver* s, const zf_step_args& a) {
     dim3 g(s->grid), b(ZF_BLOCK);
-    hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 0>), g, b, 0, s->stream, a);
-    if constexpr (S > 1) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 1>), g, b, 0, s->stream, a);
-    if constexpr (S >= 16) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 2>), g, b, 0, s->stream, a);
+    const int mask = s->part_mask;   // which of the shape-specific kernels this pass launches (zf_predict_parts)
+    if (mask & 1) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 0>), g, b, 0, s->stream, a);
+    if constexpr (S > 1)
+        if (mask & 2) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 1>), g, b, 0, s->stream, a);
+    if constexpr (S >= 16)
+        if (mask & 4) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 2>), g, b, 0, s->stream, a);
 }
 
 // history-recording variants (nontemporal policy only: the history is write-once)
@@ -416,9 +429,10 @@ static void zf_launch_finalize(zf_solver* s, bool decide) {
     else hipLaunchKernelGGL(zf_finalize_kernel<1>, dim3(wgs), dim3(ZF_FIN_THREADS), 0, s->stream, F);
 }
 
-static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false) {
+// the arguments every trial launch shares; the in-kernel finalisation off (fin_mode 0)
+static void zf_fill_step_args(const zf_solver* s, zf_step_args& a) {
     const zf_problem_desc& d = s->desc;
-    zf_step_args a;
+    memset(&a, 0, sizeof(a));
     a.ctl = s->ctl;
     a.beta_ring = s->beta_ring;
     for (int k = 0; k < ZF_MAX_RING; ++k) a.xb[k] = s->xb[k < s->ring ? k : 0];
@@ -428,12 +442,60 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
     a.n = d.n;
     a.tiles_per_wg = s->tiles;
     a.blk_part = s->blk_part;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     a.pass_log = nullptr;
     a.pass_slot = 0;
     a.hist = s->hist;
     a.hist_cap = s->hist_cap > 0 ? s->hist_cap : 1;
     a.hist_stride = s->hist_stride;
+    a.fin_mode = 0;
+}
+
+// Groups of the in-kernel finalisation: up to ZF_FIN_GROUPS workgroups reduce as ONE level (every workgroup its
+// own "group"); beyond that ceil(grid / ZF_FIN_GROUPS) consecutive workgroups form a group.  A function of the
+// grid only.
+static void zf_fin_groups(int grid, int* gsz, int* ng) {
+    if (grid <= ZF_FIN_GROUPS) {
+        *gsz = 1;
+        *ng = grid;
+        return;
+    }
+    *gsz = (grid + ZF_FIN_GROUPS - 1) / ZF_FIN_GROUPS;
+    *ng = (grid + *gsz - 1) / *gsz;
+}
+
+// The kernels of the next pass (bit p = PART p of zf_trial_kernel), and the shadow control block moved past that pass
+// on the assumption that every fresh trial is accepted and nothing terminates but max_iter - true for whole chunks
+// in the regime a line search settles in.  The shape rule is the kernel's own (zf_trial_kernel, zf_fresh_len).
+// All kernels (7) when nothing is known, the last chunk saw a rejection, x is sharded, or ZF_SPECULATE=0.
+static int zf_predict_parts(zf_solver* s) {
+    static const bool off = [] { const char* e = getenv("ZF_SPECULATE"); return e && atoi(e) == 0; }();
+    if (off || s->sub <= 1 || !s->shadow_valid || s->careful || s->desc.world != 1 || s->comm ||
+        s->desc.kind != ZF_PROBLEM_DIAG_QUAD_L1)
+        return 7;
+    zf_control& c = s->shadow;
+    if (c.status != ZF_RUNNING) return 7;   // (expected to be finished; if the device is not - a chain broke - any shape may be due)
+    const int S = s->sub;
+    const int lag = c.lag;
+    const int nf = zf_fresh_len(&c);
+    const bool full = (lag == 0 && nf == S);
+    const int part = full ? 0 : ((S >= 16 && nf > S / 2) ? 2 : 1);
+    if (c.pend_status != 0) {
+        c.lag = 0;
+        if (c.pend_status > 0) c.status = c.pend_status;
+        c.pend_status = 0;
+    } else {
+        c.nit += nf;
+        c.lag = 0;
+        if (c.nit >= c.max_iter) c.status = ZF_MAXITER;
+    }
+    return 1 << part;
+}
+
+static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false) {
+    const zf_problem_desc& d = s->desc;
+    zf_step_args a;
+    zf_fill_step_args(s, a);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing && !dry) {
         if (!s->pass_log) {
             ZF_HIP(hipMalloc(&s->pass_log, sizeof(int) * ZF_PASS_LOG));
@@ -458,10 +520,24 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
     if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
         a.p0 = d.d;
         a.p1 = d.c;
+        if (!dry) {
+            // the pass finalises itself (zf_pass_tail): packs, and - unsharded - the decide pass, in the same launch
+            a.fin_mode = 1;
+            zf_fin_groups(s->grid, &a.fin_gsz, &a.fin_ng);
+            a.grp_part = s->grp_part;
+            a.fin_cnt = s->fin_cnt;
+            a.fin_scale_f = 0.5;   // f = 0.5 * sum(d (x-c)^2)
+            a.fin_scale_g = d.lam; // g = lam * sum|x|
+            a.pack = s->pack_local;
+            a.ctl_rw = s->ctl;
+            a.decide = (d.world == 1 && decide_in_launch) ? 1 : 0;
+            a.trace = s->trace;
+        }
+        s->part_mask = (dry || !decide_in_launch) ? 7 : zf_predict_parts(s);
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
         zf_launch_trial_t<true>(s, a);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
-        if (!dry) zf_launch_finalize(s, d.world == 1 && decide_in_launch);
+        s->part_mask = 7;
     } else if (s->ls_small && !dry && decide_in_launch) {
         // cache-resident A: the whole trial in two launches (zf_kernels_ls_small.h)
         zf_ls_small_args P;
@@ -487,6 +563,8 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         P.hist = s->hist;
         P.hist_cap = s->hist_cap > 0 ? s->hist_cap : 1;
         P.hist_stride = s->hist_stride;
+        P.pass_log = a.pass_log;
+        P.pass_slot = a.pass_slot;
         const bool nest = s->opt.nesterov != 0;
         dim3 gs(P.grid_step), gr((unsigned)((d.m_rows + ZF_WAVES - 1) / ZF_WAVES)), b(ZF_BLOCK);
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
@@ -523,6 +601,13 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         hipLaunchKernelGGL(zf_gemvT_combine_kernel, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, s->stream,
                            rows ? nullptr : s->ctl, s->slab, rows ? s->s_part : s->grad, 2 * d.scale, n, s->slices);
         if (rows) {
+            // (the prox step of a row-sharded trial runs in zf_solver_enqueue_trial_finish, after the exchange: the
+            //  event pair and the log slot taken above belong to a launch that does not happen here - give them back,
+            //  or zf_collect_timing would read events that were never recorded)
+            if (s->timing) {
+                s->ev_used -= 1;
+                if (a.pass_log) s->launches -= 1;
+            }
             ZF_HIP(hipGetLastError());
             return ZF_OK;
         }
@@ -571,20 +656,7 @@ extern "C" int zf_solver_enqueue_trial_finish(zf_solver* s) {
         hipLaunchKernelGGL(zf_sum_parts_kernel, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, s->stream, nullptr, s->s_all,
                            (int)d.world, n, g3, -1);
         zf_step_args a;
-        a.ctl = s->ctl;
-        a.beta_ring = s->beta_ring;
-        for (int k = 0; k < ZF_MAX_RING; ++k) a.xb[k] = s->xb[k < s->ring ? k : 0];
-        a.lam = d.lam;
-        a.lo = d.box_lo;
-        a.hi = d.box_hi;
-        a.n = n;
-        a.tiles_per_wg = s->tiles;
-        a.blk_part = s->blk_part;
-        a.pass_log = nullptr;
-        a.pass_slot = 0;
-        a.hist = s->hist;
-        a.hist_cap = s->hist_cap > 0 ? s->hist_cap : 1;
-        a.hist_stride = s->hist_stride;
+        zf_fill_step_args(s, a);
         a.p0 = s->grad;
         a.p1 = nullptr;
         zf_launch_trial_t<false>(s, a);
@@ -668,6 +740,7 @@ extern "C" int zf_solver_set_svec_buffers(zf_solver* s, double* s_part_dev, doub
 
 extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
     ZF_REQUIRE(s && x0_dev, "zf_solver_enqueue_init: null argument");
+    s->shadow_valid = false;   // (the control block changes behind the host's back: predict again after the next poll)
     const zf_problem_desc& d = s->desc;
     const int64_t n = d.n;
     // x_k = x_{k-1} = y = x0  (proximal_gradient.py:463-465)
@@ -748,6 +821,7 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
 extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev,
                                  const zf_control* saved, int64_t saved_bytes) {
     ZF_REQUIRE(s && xk_dev && xprev_dev && saved, "zf_solver_restore: null argument");
+    s->shadow_valid = false;   // (the control block changes behind the host's back: predict again after the next poll)
     ZF_REQUIRE(saved_bytes == (int64_t)sizeof(zf_control),
                "zf_solver_restore: saved_bytes differs from zf_sizeof_control() (a control block of another ABI version)");
     const zf_problem_desc& d = s->desc;
@@ -897,6 +971,12 @@ extern "C" int zf_solver_sub_iters(zf_solver* s, int32_t* sub_iters) {
 extern "C" int zf_solver_set_max_iter(zf_solver* s, int64_t max_iter) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_set_max_iter: solver not initialised");
     ZF_REQUIRE(max_iter >= 1, "zf_solver_set_max_iter: max_iter must be >= 1");
+    if (s->shadow_valid) {   // (mirror of zf_set_max_iter_kernel on the host's expectation)
+        zf_control& c = s->shadow;
+        c.max_iter = max_iter;
+        if (c.status == ZF_MAXITER && c.nit < max_iter) c.status = ZF_RUNNING;
+        if (c.pend_status == ZF_MAXITER && c.nit < max_iter) c.pend_status = 0;
+    }
     s->opt.max_iter = max_iter;
     hipLaunchKernelGGL(zf_set_max_iter_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, max_iter);
     ZF_HIP(hipGetLastError());
@@ -907,6 +987,10 @@ extern "C" int zf_solver_set_max_iter(zf_solver* s, int64_t max_iter) {
 // that x_k, x_{k-1} are in buffers `cur`, `prev` at the next poll - snapshots, history taps
 extern "C" int zf_solver_flush(zf_solver* s) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_flush: solver not initialised");
+    if (s->shadow_valid) {   // (mirror of zf_flush_kernel)
+        zf_control& c = s->shadow;
+        if (c.status == ZF_RUNNING && c.lag > 0 && c.pend_status == 0) c.pend_status = ZF_PEND_FLUSH;
+    }
     hipLaunchKernelGGL(zf_flush_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl);
     ZF_HIP(hipGetLastError());
     return ZF_OK;
@@ -989,21 +1073,18 @@ static void zf_set_tiles(zf_solver* s, int tiles) {
 // accept / reject decision - so it is a FUNCTION OF n ONLY (never of a timing measurement, the
 // chain length or the device found at run time): the same problem takes the same decisions in every
 // process, on every rank layout with equal shard sizes, for every S and after every restore.
-// Below 4096 tiles (64 MiB per stream) the launch is latency-bound: T = 1.  From there T = 8 amortises
-// the per-workgroup reduction of long chains (6 S wave reductions, ~5 % of a 16-chain workgroup's
-// instructions at T = 8).  From 16384 tiles on (n >= 3.4e7) the grid is many rounds deep and T follows
-// the rounds: the chained kernels keep two workgroups per CU resident - 512 on the 256 CUs of an
-// MI355X - and a workgroup costs its T tiles plus ~0.3 of a tile for its start and epilogue, so a pass
-// takes  rounds(T) x (T + 0.3)  tile times with rounds = ceil(ceil(tiles / T) / 512); T is the smallest
-// minimiser in 8 .. 24 (n = 1e8: 4 rounds of 24 tiles instead of 12 of 8: 1.285 -> 1.26 ms per 16-chain
-// pass; the sweep T = 2 .. 96 is in DESIGN.md 4.1).  Whole rounds were also tried for n = 1e7 (489
-// workgroups of 10 tiles instead of 611 of 8): no faster - that size is bound by launch, start and
-// epilogue, not by the second round - so the smaller sizes keep the geometry they were measured with.
+// Below 4096 tiles (64 MiB per stream) the launch is latency-bound: T = 1.  From there on the grid is a
+// round or more deep and T follows the rounds: the chained kernels keep two workgroups per CU resident - 512
+// on the 256 CUs of an MI355X - and a workgroup costs its T tiles plus ~0.3 of a tile for its start and
+// epilogue (6 S wave reductions), so a pass takes  rounds(T) x (T + 0.3)  tile times with
+// rounds = ceil(ceil(tiles / T) / 512); T is the smallest minimiser in 8 .. 24 (n = 1e8: 4 rounds of 24
+// tiles instead of 12 of 8: 1.285 -> 1.26 ms per 16-chain pass; the sweep T = 2 .. 96 is in DESIGN.md 4.1;
+// n = 1e7: ONE round of 489 workgroups of 10 tiles instead of 611 of 8 - a second round 19 % full: 0.149 ->
+// 0.128 ms per 16-chain pass, round 3; round 2 had measured "no faster" through a 22 us finalize launch).
 // (Round 1 picked T by timing; tools/tune_trial.hip keeps that experiment.)  ZF_TILES_PER_WG=<n>
 // overrides it for experiments and changes the rounding of the sums with it.
 static int zf_tiles_for(int64_t ntiles) {
     if (ntiles < 4096) return 1;
-    if (ntiles < 16384) return 8;
     constexpr int64_t SLOTS = 512;
     int best_t = 8;
     double best_cost = 0.0;
@@ -1092,6 +1173,13 @@ extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_by
         ZF_HIP(hipMemcpyAsync(trace_host, s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS,
                               hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
+    {   // what the host now knows about the device: the basis of the next chunk's predictions
+        const int64_t rej = ctl_host->total_trials - ctl_host->nit;
+        s->careful = s->shadow_valid ? (rej != s->polled_rejections) : (rej != 0);
+        s->polled_rejections = rej;
+        s->shadow = *ctl_host;
+        s->shadow_valid = true;
+    }
     return zf_collect_timing(s);
 }
 

@@ -107,13 +107,18 @@ class DeviceSolver:
         if isinstance(group, LibComm):
             self.comm = group
         elif self.world > 1 and group is not None and os.environ.get("ZF_COMM", "lib") == "lib":
-            try:
-                import torch.distributed as dist
+            import torch.distributed as dist
 
-                if dist.get_backend(group) == "nccl":
-                    self.comm = LibComm.from_group(group)
-            except Exception:   # (in-process stand-ins of the tests have no backend)
-                self.comm = None
+            try:   # only the QUESTION "is this an nccl process group" may fail quietly (the tests' in-process
+                   # stand-ins are no process groups at all)
+                is_nccl = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+            except (RuntimeError, ValueError, TypeError, AttributeError):
+                is_nccl = False
+            if is_nccl:
+                # collective (an object broadcast + ncclCommInitRank): a failure must surface on the rank it happens
+                # on - swallowing it would leave this rank on the torch.distributed sequence while the others
+                # issue RCCL all-gathers inside zf_solver_enqueue_steps: a hang instead of an error
+                self.comm = LibComm.from_group(group)
         if self.comm is not None:
             _lib.check(self.lib.zf_solver_set_comm(self.handle, self.comm.handle), "zf_solver_set_comm")
         self.split = self.comm is None and (self.world > 1 or os.environ.get("ZF_FORCE_SPLIT") == "1")

@@ -96,7 +96,13 @@ class MoEngine:
         self.device_search_lost = False   # a device trial gave up on its grid-wide wait: host loop from then on
         self._cb = None
         self._exchange_error = None
-        if group is not None:
+        from .comm import LibComm
+
+        if isinstance(group, LibComm) and os.environ.get("ZF_MO_COMM", "lib") == "lib":
+            # the library's own communicator: every reduction exchanges on the stream (all-gather + rank-ordered
+            # sum on the device), zf_mo_solve_dual once per batch of its search - no Python per exchange
+            _lib.check(self.lib.zf_mo_set_comm(h, group.handle, int(n_global), int(offset)), "zf_mo_set_comm")
+        elif group is not None:
             def exchange(_ctx, vals, count, max_index):
                 try:
                     arr = np.ctypeslib.as_array(vals, shape=(count,))
@@ -117,6 +123,12 @@ class MoEngine:
             exc, self._exchange_error = self._exchange_error, None
             raise _lib.ZfError(f"{what}: the exchange between ranks failed") from exc
         _lib.check(rc, what)
+
+    def exchange_count(self):
+        """Collectives issued so far: by the library over its communicator, or through the Python callback."""
+        c = C.c_int64(0)
+        _lib.check(self.lib.zf_mo_exchange_count(self.h, C.byref(c)), "zf_mo_exchange_count")
+        return int(c.value) + self.n_exchanges
 
     def set_bounds(self, lo, hi):
         lo = np.ascontiguousarray(lo, dtype=np.float64)
@@ -509,18 +521,30 @@ def solve_dual_native(dual, m, w0, tol, max_iter):
         if ev.min() < 0:                            # keep the model convex against FD noise
             Q = Q + (1e-12 - ev.min()) * np.eye(m)
         # model in w' (sum w' = 1, w' - w = T w'):  grad.T w' + 1/2 w'Qw'
-        w_new = _simplex_qp(T.T @ grad, Q)
+        # (scaled to O(1) entries: the KKT systems couple Q with the constraint row of ones - left at |Q| ~ 1e5 they
+        #  are conditioned like |Q|^2 and the Newton point comes out with an absolute error of 1e-9 in w)
+        scale = max(np.max(np.abs(Q)), 1e-300)
+        # The model is q . d + 1/2 d'Qd in the STEP d = w' - w.  Written in w' it reads (q - Q w) . w' + 1/2 w'Qw';
+        # analytically Q w = T'H(T w) = 0, but the probed Q satisfies that only to ~1e-8 |Q|, and leaving the term
+        # out shifted every Newton point by ~1e-9: the search stalled at a gradient residual of 1e-4 where one
+        # exact tangent-space Newton step reaches 3e-11 (measured on G11's quad3).
+        w_new = _simplex_qp((T.T @ grad - Q @ w) / scale, Q / scale)
         d = w_new - w
         step = np.max(np.abs(d))
-        slope = grad @ d
-        # stop at `tol` in w, or when the model predicts no decrease resolvable in double
-        # precision (the reductions behind `fun` carry ~1e-16 relative noise)
-        if step <= tol or slope >= -4e-16 * max(1.0, abs(fun)):
+        slope = (grad - grad.mean()) @ d    # (mean-free: d sums to zero only up to rounding, the common part of grad is 1e5)
+        # stop at `tol` in w, or when the predicted decrease grad . d is below what the gradient resolves
+        # (its components carry ~4e-16 (|D| + |grad|) of rounding noise: zf_dual::machine::newton_model)
+        if step <= tol or slope >= -4e-16 * max(1.0, abs(fun), np.max(np.abs(grad))) * step:
             break
         t = 1.0
         while True:
             f_try, g_try = dual(w + t * d)
             if f_try <= fun + 1e-4 * t * slope + 1e-15 * abs(fun) or t < 1e-10:
+                break
+            # where the values no longer resolve the decrease (~1e-12 |D| of rounding noise near the optimum) the
+            # derivative along d decides: the approximate Wolfe conditions of Hager & Zhang (zf_dual::machine::ls_accept)
+            dphi = (g_try - g_try.mean()) @ d
+            if f_try <= fun + 1e-10 * abs(fun) and 0.9 * slope <= dphi <= -(1.0 - 2e-4) * slope:
                 break
             t *= 0.5
         w_prev = w

@@ -220,17 +220,20 @@ class NativeRun:
 
     # -- streaming return_all -------------------------------------------------------------------
     def _init_history(self, x0, x0_dev, max_iter, slots=None):
-        """A ring of iterates in HBM: as many slots as the solve can need, bounded by half of the free
-        device memory and - for small n - 2 GiB or 4096 slots (or ``history_slots``); what the ring cannot keep is moved
-        to the host in blocks between chunks of passes (PCIe-bound: 0.8 GB per iterate at n = 1e8)."""
+        """A ring of iterates in HBM, MODEST by default: what the solve can need, at most 256 MiB (and never more than
+        a quarter of the free device memory) - but always the 2 S + 2 slots two chains of a pass take (n = 1e8: 18
+        slots = 14 GB).  What the ring cannot keep is moved to the host in blocks between chunks of passes
+        (PCIe-bound: 0.8 GB per iterate at n = 1e8).  ``history_slots`` asks for a larger ring (solves whose whole
+        history should stay on the device; the default max_iter of 1e6 must not make every small ``return_all``
+        solve - or every worker sharing a GPU - allocate gigabytes up front)."""
         import torch
 
         n = x0_dev.numel()
         stride = (n + 63) // 64 * 64
         S = int(self.solver.sub_iters)
         free, _ = torch.cuda.mem_get_info()
-        budget = max(2 * S + 2, (free // 2) // (8 * stride))
-        cap = int(slots) if slots else min(max_iter + 1, budget, max(4096, (2 << 30) // (8 * stride)))
+        budget = min(free // 4, 256 << 20) // (8 * stride)
+        cap = int(slots) if slots else min(max_iter + 1, budget)
         cap = max(cap, 2 * S + 2)
         self._hist = torch.empty(cap * stride, dtype=torch.float64, device=x0_dev.device)
         self._hist[:n].copy_(x0_dev)
@@ -272,7 +275,12 @@ class NativeRun:
     @classmethod
     def from_snapshot(cls, problem, state, opts, timing=False):
         """Continue a solve from ``snapshot()`` (possibly in another process, with another
-        max_iter or chain length).  The continuation is bit-identical to the uninterrupted solve."""
+        max_iter or chain length).  The continuation is bit-identical to the uninterrupted solve.
+        ``return_all`` is refused: the iterates before the snapshot are not part of it, and a history
+        whose first ``nit`` entries are uninitialised memory is worse than none."""
+        if opts.get("return_all"):
+            raise ValueError("return_all is not available for a solve resumed from a snapshot (the iterates before "
+                             "the snapshot are not part of the saved state)")
         return cls(problem, np.asarray(state["x"]), opts, timing=timing, _snapshot=state)
 
     def _fill_beta(self, upto):
