@@ -151,6 +151,14 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket every trial kernel with HIP events (roofline becomes null); "
                          "shows what the per-kernel timing itself costs")
+    ap.add_argument("--no-regimes", action="store_true",
+                    help="skip the brief second measurement of the other regime (config.iterations_per_sec_by_regime)")
+    ap.add_argument("--thread-ranks", type=int, default=0,
+                    help="DRY RUN of the N > 1 code path on ONE GPU: this many rank THREADS in this process, one stream "
+                         "and one solver each, x sharded over them through the library's own communicator "
+                         "(zf_comm_create_local_group - the all-gather RCCL serves on a real node).  Same step "
+                         "sequence, same JSON line (n_gpus stays 1, config.thread_ranks says how many); use a "
+                         "smaller --n (8 x 1e7 fits the time of a test).  Not a scaling measurement.")
     args = ap.parse_args()
 
     # Only the JSON line may reach stdout: libraries (RCCL prints "Hostname : ..." banners at
@@ -162,6 +170,8 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.thread_ranks > 1:
+        return thread_rank_main(args, real_stdout)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -182,6 +192,82 @@ def main():
             dist.init_process_group(backend)
         group = dist.group.WORLD
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(dt):
+        if world == 1:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.libcomm and world == 1:
+        from zfista_amd.comm import LibComm
+
+        group = LibComm(0, 1, LibComm.new_unique_id())
+    line = rank_body(args, rank, world, group, barrier, max_over_ranks)
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if use_pg:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def thread_rank_main(args, real_stdout):
+    """--thread-ranks N: the N > 1 code path of this file with N rank threads on one GPU (see the option)."""
+    import threading
+
+    import torch
+
+    from zfista_amd.comm import LibComm
+
+    world = args.thread_ranks
+    torch.cuda.set_device(0)
+    comms = LibComm.local_group(world, cap_doubles=4096)
+    bar = threading.Barrier(world)
+    slots = [0.0] * world
+    out, errs = [None] * world, []
+
+    def barrier():
+        bar.wait()
+
+    def make_max(rank):
+        def max_over_ranks(dt):
+            slots[rank] = dt
+            bar.wait()
+            m = max(slots)
+            bar.wait()
+            return m
+        return max_over_ranks
+
+    def rank_main(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out[r] = rank_body(args, r, world, comms[r], barrier, make_max(r), thread_ranks=world)
+        except Exception as exc:   # pragma: no cover - reported below
+            errs.append(exc)
+            bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    os.write(real_stdout, (json.dumps(out[0]) + "\n").encode())
+    for c_ in comms:
+        c_.close()
+
+
+def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0):
+    """What one rank does: warm-up, the timed blocks, and (rank 0) the JSON line.  `barrier` /
+    `max_over_ranks` are the two rank-to-rank operations of the contract (torch.distributed between
+    processes, a thread barrier in the dry run); the per-pass exchange is the library's."""
+    import torch
+
     from zfista_amd import _lib
     from zfista_amd.problems import DiagQuadL1
     from zfista_amd.proximal_gradient import NativeRun
@@ -190,10 +276,6 @@ def main():
     if args.total_n:
         n = args.total_n * (rank + 1) // world - args.total_n * rank // world   # this rank's block
     K, W = args.steps, args.warmup
-    if args.libcomm and world == 1:
-        from zfista_amd.comm import LibComm
-
-        group = LibComm(0, 1, LibComm.new_unique_id())
     d, c = make_inputs(n, seed=1 + rank, device="cuda")
     prob = DiagQuadL1(d, c, LAM, group=group)
     opts = dict(lr=LR, tol=0.0, tol_internal=1e-12, max_iter=max(W, 1), max_backtrack_iter=100, decay_rate=0.5,
@@ -203,52 +285,74 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize()
 
-    run = NativeRun(prob, x0, opts, timing=timing)
-    S = run.sub_iters
-    blocks, full_ms, full_n, part_ms, part_n, passes = [], 0.0, 0, 0.0, 0, 0
-    part_fresh = part_lag = 0
-    timed = 0.0
-    while True:
-        while W > 0 and run.status == _lib.ZF_RUNNING:   # warm-up: exactly W iterations, then MAXITER
-            run.advance((W - run.nit_seen + S - 1) // S)
-        if timing:
-            run.solver.pass_stats()                      # reset the event window after warm-up
-        nit0 = run.nit_seen
-        run.set_max_iter(nit0 + K)
-        sync_all()
-        t0 = time.perf_counter()
-        while run.status == _lib.ZF_RUNNING:
-            # exactly the passes the remaining iterations need if no chain breaks; a rejected trial
-            # (lr halves, :305) costs further rounds
-            run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S)
-            run.collect()
-        sync_all()
-        dt = time.perf_counter() - t0
-        assert run.status == _lib.ZF_MAXITER and run.nit_seen - nit0 == K, \
-            f"expected {K} accepted iterations, got {run.nit_seen - nit0} (status {run.status})"
-        if timing:
-            (fm, fn), (pm, pn), (pf, pl) = run.solver.pass_stats_ex()
-            full_ms, full_n, part_ms, part_n = full_ms + fm * fn, full_n + fn, part_ms + pm * pn, part_n + pn
-            part_fresh, part_lag = part_fresh + pf, part_lag + pl
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        blocks.append(dt)
-        timed += dt
-        tiles = getattr(run.solver, "tiles_per_wg", None)
-        if timed >= args.min_seconds or len(blocks) >= args.max_blocks:   # (dt is the max over ranks: same decision everywhere)
-            break
-        run.solver.close()
-        run = NativeRun(prob, x0, opts, timing=timing)   # the same workload again, on a warmer device
+    def measure(K, W, min_seconds, max_blocks):
+        """Blocks of W untimed + K timed iterations (a fresh solve each) until min_seconds are timed."""
+        o = dict(opts, max_iter=max(W, 1))
+        run = NativeRun(prob, x0, o, timing=timing)
+        S = run.sub_iters
+        m = dict(blocks=[], timed=0.0, full_ms=0.0, full_n=0, part_ms=0.0, part_n=0, part_fresh=0, part_lag=0, S=S,
+                 tiles=None)
+        while True:
+            while W > 0 and run.status == _lib.ZF_RUNNING:   # warm-up: exactly W iterations, then MAXITER
+                run.advance((W - run.nit_seen + S - 1) // S)
+            if timing:
+                run.solver.pass_stats()                      # reset the event window after warm-up
+            nit0 = run.nit_seen
+            run.set_max_iter(nit0 + K)
+            sync_all()
+            t0 = time.perf_counter()
+            while run.status == _lib.ZF_RUNNING:
+                # exactly the passes the remaining iterations need if no chain breaks; a rejected trial
+                # (lr halves, :305) costs further rounds
+                run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S)
+                run.collect()
+            sync_all()
+            dt = time.perf_counter() - t0
+            assert run.status == _lib.ZF_MAXITER and run.nit_seen - nit0 == K, \
+                f"expected {K} accepted iterations, got {run.nit_seen - nit0} (status {run.status})"
+            if timing:
+                (fm, fn), (pm, pn), (pf, pl) = run.solver.pass_stats_ex()
+                m["full_ms"] += fm * fn
+                m["full_n"] += fn
+                m["part_ms"] += pm * pn
+                m["part_n"] += pn
+                m["part_fresh"] += pf
+                m["part_lag"] += pl
+            dt = max_over_ranks(dt)
+            m["blocks"].append(dt)
+            m["timed"] += dt
+            m["tiles"] = getattr(run.solver, "tiles_per_wg", None)
+            run.solver.close()
+            if m["timed"] >= min_seconds or len(m["blocks"]) >= max_blocks:   # (dt is the max over ranks: same decision everywhere)
+                break
+            run = NativeRun(prob, x0, o, timing=timing)   # the same workload again, on a warmer device
+        return m
+
+    M = measure(K, W, args.min_seconds, args.max_blocks)
+    S, blocks, timed, tiles = M["S"], M["blocks"], M["timed"], M["tiles"]
+    full_ms, full_n, part_ms, part_n = M["full_ms"], M["full_n"], M["part_ms"], M["part_n"]
+    part_fresh, part_lag = M["part_fresh"], M["part_lag"]
     dt = statistics.median(blocks)
     passes = full_n + part_n
+    # The two regimes of this workload side by side, whatever the flags: 20 iterations from iteration 5 stay clear of
+    # the resolution limit of the acceptance test (no trial is rejected); 100 iterations from iteration 10 cross it
+    # at iteration ~89 (DESIGN.md 2) and pay for two or three rounding-noise rejections.  The other one is measured
+    # briefly after the main measurement (every rank takes part: the exchanges are collective).
+    regimes = {}
+    for (k2, w2), tag in (((20, 5), "clean_regime_K20_W5"), ((100, 10), "across_the_noise_floor_K100_W10")):
+        if (k2, w2) == (K, W):
+            regimes[tag] = (world * K / dt * (n / N_PER_GPU)) if not args.total_n else K / dt
+        elif not args.no_regimes:
+            m2 = measure(k2, w2, 0.2, 60)
+            d2 = statistics.median(m2["blocks"])
+            regimes[tag] = (world * k2 / d2 * (n / N_PER_GPU)) if not args.total_n else k2 / d2
 
+    line = None
     if rank == 0:
+        n_gpus = 1 if thread_ranks else world
         line = {
             "metric": f"fista_iterations_per_sec_n{args.total_n:.0e}_total" if args.total_n
                       else "fista_iterations_per_sec_n1e8_per_gpu_shard",
@@ -256,7 +360,7 @@ def main():
             # strong (--total-n): iterations/s of the one fixed-size problem
             "value": (K / dt) if args.total_n else world * K / dt * (n / N_PER_GPU),
             "unit": "iterations/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": K,
             "warmup": W,
             "ms_per_step": dt / K * 1e3,
@@ -283,7 +387,11 @@ def main():
                 "full_chain_passes": full_n if timing else None,
                 "other_passes": part_n if timing else None,
                 "tiles_per_workgroup": tiles,
-                "parallelism": f"x sharded over {world} GPU(s); per-pass scalar pack all-gather (RCCL inside the library)"
+                "iterations_per_sec_by_regime": regimes,
+                "thread_ranks": thread_ranks or None,
+                "parallelism": (f"DRY RUN: x sharded over {world} rank threads on ONE GPU (in-process communicator group of the "
+                                "library); the N > 1 step sequence, not a scaling measurement") if thread_ranks else
+                               f"x sharded over {world} GPU(s); per-pass scalar pack all-gather (RCCL inside the library)"
                                if world > 1 else ("single GPU, 1-rank RCCL all-gather per pass" if args.libcomm
                                                   else "single GPU"),
             },
@@ -356,11 +464,7 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, c)
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    run.solver.close()
-    if use_pg:
-        dist.barrier()
-        dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

@@ -102,7 +102,7 @@ typedef struct zf_control {
      * reached while iterates were lagging) or, for ZF_PEND_FLUSH, the solve simply continues. */
     int32_t lag;
     int32_t pend_status;
-    int32_t reserved0;
+    int32_t pass_seq;     /* number of the step whose pass was decided inside its trial launch (0: none yet) */
     double lag_lr[ZF_MAX_LAG];
 } zf_control;
 

@@ -85,3 +85,30 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert d["config"]["n_total"] == 4000000 and d["config"]["passes_per_block"] >= 2
     # whole-job aggregate: two shards' worth of iterations per unit time
     assert abs(d["value"] - 2 * 24 / (d["ms_per_step"] * 24 / 1e3) * (2000000 / 1e8)) < 1e-6 * d["value"]
+
+
+def test_bench_n_gt_1_code_path_with_eight_thread_ranks():
+    """What the driver executes on a whole node - bench.py's N > 1 path: x sharded over the ranks, the library's own
+    communicator issuing the per-pass pack exchange, zf_decide_kernel on the gathered packs, barrier-bracketed
+    timing, max over ranks, ONE JSON line from rank 0 - as a dry run on this one GPU: 8 rank THREADS x n = 1e7
+    (BASELINE cfg5's layout at an eighth of its size) through the in-process communicator group behind the same
+    zf_comm_all_gather RCCL serves (--thread-ranks).  The JSON contract must hold; n_gpus stays 1."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--thread-ranks", "8", "--n", "10000000",
+                          "--steps", "20", "--warmup", "5", "--min-seconds", "0.2", "--no-regimes"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["dtype"]) == (1, 20, 5, "weak", "f64")
+    cfg = d["config"]
+    assert cfg["thread_ranks"] == 8 and cfg["n_total"] == 80000000 and cfg["n_per_gpu"] == 10000000
+    assert "DRY RUN" in cfg["parallelism"] and "cpu_baseline" not in d
+    assert cfg["passes_per_block"] >= 2 and cfg["temporal_blocking_chain"] == 16
+    # whole-job aggregate in units of one 1e8-element shard: 8 ranks x 0.1 shard each
+    assert abs(d["value"] - 8 * 20 / (d["ms_per_step"] * 20 / 1e3) * 0.1) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert 0 < r["frac"] <= 1.0 and r["kernel_launches_timed"] >= 2

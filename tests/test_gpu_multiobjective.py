@@ -2,14 +2,14 @@
 against the golden vectors of the reference solver (G4), the reference's literal
 known answers (G5) and its own m = 2 / m = 3 solver tests (closures, generic path).
 
-Tolerances: problem callables 1e-13 (elementwise + one reduction).  Iterates:
-the dual search is SciPy's on both sides but sees function values that differ in
-the last bits.  A derivative-free / quasi-Newton search on a function known to
-~1e-16 relative cannot place its minimiser better than ~sqrt(eps) = 1e-8 (Brent,
-m = 2), and trust-constr's barrier path ends at visibly different interior points
-(m = 3: weights move at the 1e-5 level, the model value at 1e-6 relative), so the
-dual path is "parity unpinned" (SURVEY 8c); what is pinned is the primal iterate:
-asserted at 1e-7 relative (m = 2) and 1e-6 (m = 3), with equal iteration counts."""
+Tolerances: problem callables 1e-13 (elementwise + one reduction).  Iterates with
+dual_solver="scipy" (the reference's calls): max(1e-10, 10 x the reference's OWN spread when
+its feature order is permuted - fixture G10): five of the eight G4 cases reproduce to 1e-13
+and are held to 1e-10; where SciPy's Brent / barrier end point itself moves with the last
+bits of the dual values nothing tighter is defined.  The library's own search ("native",
+"device") stops at the stated 2e-5 of the reference's runs and 1e-9 of itself (host loop
+against persistent kernel); at grid-wide sizes it is judged in the oracle's arithmetic too
+(tests/test_gpu_mo_fullsize.py).  Equal iteration counts throughout."""
 import warnings
 
 import numpy as np

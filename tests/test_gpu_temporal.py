@@ -2,7 +2,7 @@
 consecutive iterations in registers and the decide step examines them in order, discarding
 the speculative rest at the first rejection / termination (csrc/zf_kernels_step.h).  The
 results must not depend on S: every trace row, branch decision and iterate is compared
-bit for bit across S in {1, 2, 4, 8} and against the golden vectors of the reference solver
+bit for bit across S in {1, 2, 4, 8, 16} and against the golden vectors of the reference solver
 (zfista/proximal_gradient.py:279-307,510,525-543)."""
 import numpy as np
 import pytest

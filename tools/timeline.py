@@ -15,7 +15,9 @@ import os
 import sys
 
 d = sys.argv[1]
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+LIST = "--list" in sys.argv
+args = [a for a in sys.argv[2:] if not a.startswith("--")]
+skip = int(args[0]) if args else 0
 rows = []
 for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(path, newline="")):
@@ -33,6 +35,16 @@ def cls(name, dur):
 
 
 busy = [i for i, (s, e, n) in enumerate(rows) if cls(n, e - s) == "trial_busy"]
+if LIST:   # every busy trial launch: the PART of the kernel (last integer template argument) and its duration
+    import re
+
+    prev = None
+    for s_, e_, n_ in rows:
+        if cls(n_, e_ - s_) != "trial_busy":
+            continue
+        ints = re.findall(r"(?<![\w])(\d+)(?=[,>])", n_)
+        print(f"part {ints[-1] if ints else '?'}  S {ints[-2] if len(ints) > 1 else '?'}  {(e_ - s_) / 1e3:9.1f} us   gap {0 if prev is None else (s_ - prev) / 1e3:8.1f} us")
+        prev = e_
 if len(busy) <= skip + 1:
     raise SystemExit("no busy trial launches found")
 lo, hi = busy[skip], busy[-1]

@@ -50,7 +50,7 @@ class Control(C.Structure):
         ("deprecated", C.c_int32), ("need_grad", C.c_int32), ("world", C.c_int32),
         ("beta_next", C.c_double),
         ("ring_size", C.c_int32), ("sub_iters", C.c_int32), ("prev", C.c_int32),
-        ("lag", C.c_int32), ("pend_status", C.c_int32), ("reserved0", C.c_int32),
+        ("lag", C.c_int32), ("pend_status", C.c_int32), ("pass_seq", C.c_int32),
         ("lag_lr", C.c_double * ZF_MAX_LAG),
     ]
 

@@ -121,6 +121,7 @@ constexpr int ZF_TILE_UNITS = ZF_TILE_U * ZF_BLOCK;   // 16-byte units per tile
 constexpr int ZF_MAX_TILES_PER_WG = 24;               // upper bound of zf_step_args.tiles_per_wg
 constexpr int ZF_FIN_WGS = 48;                        // workgroups of the finalize kernel
 constexpr int ZF_FIN_GROUPS = 64;                     // groups of the in-kernel finalisation (zf_pass_tail)
+constexpr int ZF_FIN_CNT_STRIDE = 32;                 // unsigned words between its arrival counters (one 128-B line each)
 constexpr int ZF_FIN_THREADS = 256;
 
 typedef double zf_d2 __attribute__((ext_vector_type(2)));
@@ -217,6 +218,7 @@ struct zf_step_args {
     zf_control* ctl_rw;       // the control block, writable: the decide pass of the last arriver
     int decide;               // unsharded x: decide here; sharded: the packs are gathered first (zf_decide_kernel)
     double* trace;
+    int pass_seq;             // number of this step (> 0): written to ctl->pass_seq by the pass that decides in-kernel
 };
 
 struct zf_finalize_args {
@@ -387,12 +389,16 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     const int gsz = A.fin_gsz, ng = A.fin_ng;
     const bool grouped = gsz > 1;
     const bool is_max = (t % ZF_NPART == ZF_NPART - 1);
-    if (t < NQ) zf_publish(A.blk_part + (int64_t)t * G + b, v);
+    // (rows are ROW-major here - the NQ values of a workgroup side by side: whole cache lines written through,
+    //  not 96 masked 8-byte pieces of lines that sixteen workgroups share - and every counter has a 128-byte
+    //  line of its own: 2000 tickets on counters packed into two lines serialise in the memory system while
+    //  the workgroups that wait for them hold their CU slots)
+    if (t < NQ) zf_publish(A.blk_part + (int64_t)b * NQ + t, v);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // (NQ up to 96: the publishers sit in two waves)
     if (t == 0) {
         const int g = grouped ? b / gsz : 0;
-        unsigned* cnt = grouped ? A.fin_cnt + 1 + g : A.fin_cnt;
+        unsigned* cnt = grouped ? A.fin_cnt + (1 + g) * ZF_FIN_CNT_STRIDE : A.fin_cnt;
         int members = G;
         if (grouped) members = (g + 1) * gsz <= G ? gsz : G - g * gsz;
         const unsigned tk = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -413,12 +419,12 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     // n = 1e7 took 127 rejections and ended in "Backtracking failed", with the two-level tree of round 2 about 20,
     // the reference's NumPy sums 5 in 110 iterations.  Up to 32 loads are in flight at once (one round trip to memory per
     // 32 rows: the rows are read write-through / sc1, every load misses the caches by design).
-    auto sum_rows = [&](const double* rows, int count) -> double {
+    auto sum_rows = [&](const double* rows, int count) -> double {   // rows: quantity t of row 0; rows are NQ apart
         double acc = 0.0, comp = 0.0;
         for (int k0 = 0; k0 < count; k0 += 32) {
             double p[32];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) p[u] = (k0 + u < count) ? zf_consume(rows + k0 + u) : 0.0;
+            for (int u = 0; u < 32; ++u) p[u] = (k0 + u < count) ? zf_consume(rows + (int64_t)(k0 + u) * NQ) : 0.0;
 #pragma unroll
             for (int u = 0; u < 32; ++u) {
                 if (is_max) {
@@ -435,7 +441,7 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     if (s_role == 1) {
         const int g = b / gsz, b0 = g * gsz;
         const int b1 = b0 + gsz <= G ? b0 + gsz : G;
-        if (t < NQ) zf_publish(A.grp_part + (int64_t)t * ng + g, sum_rows(A.blk_part + (int64_t)t * G + b0, b1 - b0));
+        if (t < NQ) zf_publish(A.grp_part + (int64_t)g * NQ + t, sum_rows(A.blk_part + (int64_t)b0 * NQ + t, b1 - b0));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) {
@@ -448,7 +454,7 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
         __syncthreads();
         if (s_role != 2) return;
     }
-    if (t < NQ) s_tot[t] = grouped ? sum_rows(A.grp_part + (int64_t)t * ng, ng) : sum_rows(A.blk_part + (int64_t)t * G, G);
+    if (t < NQ) s_tot[t] = grouped ? sum_rows(A.grp_part + t, ng) : sum_rows(A.blk_part + t, G);
     __syncthreads();
     if (t >= 64) return;
     // wave 0: lane j * LSTR builds, keeps and stores pack j; then the decide pass, trial j evaluated by its lane
@@ -472,7 +478,12 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
             s_pack[trial * ZF_PACK_LEN + k] = pk[k];
         }
     }
-    if (A.decide) zf_decide_pass_wave(A.ctl_rw, s_pack, pk, A.trace, A.beta_ring, t, LSTR, s_pre);
+    if (A.decide) {
+        zf_decide_pass_wave(A.ctl_rw, s_pack, pk, A.trace, A.beta_ring, t, LSTR, s_pre);
+        // this step has had its pass: the other shape kernels of the same step find the control block already
+        // decided - describing the NEXT pass - and must not run it (zf_trial_kernel)
+        if (t == 0) A.ctl_rw->pass_seq = A.pass_seq;
+    }
 }
 
 // GRAD_INLINE: true  -> separable quadratic, gradient computed from d, c
@@ -827,6 +838,10 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     __shared__ zf_d2 stage[GLDS ? ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS : 1];   // the stages of the LDS-DMA pipeline (16 KiB each)
     // wave-uniform control reads (scalar loads); written by the previous step's decide
     if (A.ctl->status != ZF_RUNNING) return;
+    // an earlier kernel of THIS step ran the pass and decided it in its own launch: the control block now describes
+    // the next pass, which belongs to the next step (one step = at most one pass: the trace / momentum / history
+    // rings are sized by that)
+    if (A.fin_mode != 0 && A.decide && A.ctl->pass_seq == A.pass_seq) return;
     if constexpr (S == 1) {
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = 1;
         zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, 1);

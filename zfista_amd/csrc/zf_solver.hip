@@ -177,6 +177,7 @@ struct zf_solver {
     // block of its last poll (zf_predict_parts) and launches only that one.  A wrong prediction costs passes that
     // do nothing (no kernel finds its shape, the control block stays as it is), never a wrong result.
     int part_mask = 7;
+    int pass_seq = 0;                     // step counter (zf_step_args.pass_seq)
     zf_control shadow;                    // the control block as the host expects it after the passes enqueued so far
     bool shadow_valid = false;            // false until the next poll (after init / restore / flush / set_max_iter ...)
     bool careful = false;                 // the last chunk saw rejections: launch every kernel of a pass
@@ -273,8 +274,8 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         ZF_TRY(hipMalloc(&s->blk_part, sizeof(double) * ZF_NPART * s->sub * parts));
     }
     ZF_TRY(hipMalloc(&s->slice_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_WGS));
-    ZF_TRY(hipMalloc(&s->fin_cnt, sizeof(unsigned) * (ZF_FIN_GROUPS + 16)));
-    ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, sizeof(unsigned) * (ZF_FIN_GROUPS + 16), s->stream));
+    ZF_TRY(hipMalloc(&s->fin_cnt, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2)));
+    ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2), s->stream));
     ZF_TRY(hipMalloc(&s->grp_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_GROUPS));
     ZF_TRY(hipMalloc(&s->ctl, sizeof(zf_control)));
     ZF_TRY(hipMalloc(&s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS));
@@ -520,7 +521,10 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
     if (d.kind == ZF_PROBLEM_DIAG_QUAD_L1) {
         a.p0 = d.d;
         a.p1 = d.c;
-        if (!dry) {
+        // (ZF_FIN_KERNEL=1: the round-2 sequence - plain rows, a separate zf_finalize_kernel launch - for A/B
+        //  measurements on one box; its sums are added in another order, so knife-edge decisions may differ)
+        static const bool fin_kernel = [] { const char* e = getenv("ZF_FIN_KERNEL"); return e && atoi(e) != 0; }();
+        if (!dry && !fin_kernel) {
             // the pass finalises itself (zf_pass_tail): packs, and - unsharded - the decide pass, in the same launch
             a.fin_mode = 1;
             zf_fin_groups(s->grid, &a.fin_gsz, &a.fin_ng);
@@ -532,12 +536,15 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             a.ctl_rw = s->ctl;
             a.decide = (d.world == 1 && decide_in_launch) ? 1 : 0;
             a.trace = s->trace;
+            s->pass_seq = s->pass_seq >= 0x7ffffff0 ? 1 : s->pass_seq + 1;
+            a.pass_seq = s->pass_seq;
         }
         s->part_mask = (dry || !decide_in_launch) ? 7 : zf_predict_parts(s);
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
         zf_launch_trial_t<true>(s, a);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
         s->part_mask = 7;
+        if (!dry && fin_kernel) zf_launch_finalize(s, d.world == 1 && decide_in_launch);
     } else if (s->ls_small && !dry && decide_in_launch) {
         // cache-resident A: the whole trial in two launches (zf_kernels_ls_small.h)
         zf_ls_small_args P;
@@ -850,6 +857,7 @@ extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const doubl
                "zf_solver_restore: the saved state lags more iterations than this chain length can replay "
                "(zf_solver_flush before taking the snapshot)");
     c.sub_iters = s->sub;
+    c.pass_seq = 0;   // (step numbers are this solver's own)
     if (c.status == ZF_MAXITER && c.nit < c.max_iter) c.status = ZF_RUNNING;   // a larger max_iter continues (:539)
     ZF_HIP(hipMemcpyAsync(s->ctl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));   // `c` is a stack object

@@ -519,7 +519,8 @@ def _scalar(v):
     """A callback's objective value as a NumPy float (0-dim / 1-element tensors allowed)."""
     if hasattr(v, "numel"):
         if v.numel() != 1:
-            raise NotImplementedError("tensor callbacks support one objective; use NumPy callbacks for m > 1")
+            raise TypeError(f"expected one objective value, got a tensor of {v.numel()} (m >= 2 problems return (m,) "
+                            "tensors from f AND g: _solve_tensor_multi)")
         return np.float64(v.item())
     return np.float64(v)
 
@@ -534,33 +535,34 @@ def _values(v, m):
     return v
 
 
-def _solve_tensor_multi(f, g, jac_f, prox, x0, o, f0, m):
-    """The loop of proximal_gradient.py:463-554 with the m >= 2 trial (:161-209) for callbacks on device
-    tensors: f, g return (m,) tensors, jac_f an (m, n) tensor, prox_wsum_g(weight, x) receives the weight
-    lr * w as an (m,) device tensor.  Iterates, J and every O(n) expression stay in HBM; the solver's own
-    vector expressions (v = y - lr w@J, |w@J|^2, J(p - y), |p - v|^2, max|x+ - y|) are HIP kernels
-    (zf_dev_mo_*), the m-dimensional dual search runs on the host exactly as for NumPy callbacks
-    (``dual_solver=``), and one transfer of 2m + 2 scalars per dual evaluation crosses PCIe.
-    f(y), jac_f(y) are evaluated once per line search and F(x_k) is carried over from its acceptance
-    (the reference re-evaluates them per trial, :140-142, :279: the same numbers for deterministic callbacks)."""
-    import torch
+# ---------------------------------------------------------------------------
+# callback paths: ONE outer loop (proximal_gradient.py:463-554), three providers of its trial
+# ---------------------------------------------------------------------------
+class _TrialResult:
+    """What one line-search trial hands to the loop: the trial point, the model value (:149-155 / :207), the
+    inner iteration count, the dual weights (m >= 2), max|x+ - y| (:510), F(x+) (:295) and f(x+) - f(y) for the
+    deprecated acceptance test (:301)."""
 
-    from . import multiobjective
+    def __init__(self, x, fun, nit_int, weight, err, F_new, df):
+        self.x, self.fun, self.nit_int, self.weight, self.err, self.F_new, self.df = x, fun, nit_int, weight, err, F_new, df
+        self.f_new = None   # (tensor paths: f(x+), carried to the next line search as f(x_k))
 
-    ops = _DevOps()
+
+def _solve_callbacks(P, x0, o):
+    """The loop of proximal_gradient.py:463-554 for callbacks, written once.  ``P`` provides what differs between
+    opaque NumPy callbacks (_GenericOps), callbacks on device tensors (_TensorOps) and their m >= 2 form
+    (_TensorMultiOps): ``start`` (F(x0)), ``begin`` (what a line search fixes: F(x_k) and, for the tensor paths,
+    f(y), jac_f(y)), ``trial`` (one trial at a step size), ``momentum`` (:534) and the values reported with
+    results (``F_record``, ``F_final``, ``F_error``)."""
     t0 = time.time()
     res = OptimizeResult(x0=x0, tol=o["tol"], tol_internal=o["tol_internal"],
                          nesterov=o["nesterov"], nesterov_ratio=o["nesterov_ratio"])
     if o["verbose"]:
         _print_header()
     x_old = x_cur = y = x0
-    f_old = _values(f0, m)
-    F_old = f_old + _values(g(x0), m)
-    w0 = np.ones(m) / m
+    F_old = P.start(x0)
+    w0 = np.ones(P.m) / P.m if P.m > 1 else None
     lr = o["lr"]
-    solver = o.get("dual_solver", "scipy")
-    if solver == "device":
-        solver = "native"   # (the persistent-kernel search needs the library's own prox: built-in problems)
     allvecs = allfuns = allerrs = None
     if o["return_all"]:
         allvecs, allfuns, allerrs = [x0], [F_old], []
@@ -569,174 +571,242 @@ def _solve_tensor_multi(f, g, jac_f, prox, x0, o, f0, m):
     nit = 0
     for nit in range(1, o["max_iter"] + 1):
         try:
-            f_y = f_old if y is x_old else _values(f(y), m)   # :140
-            J = jac_f(y)                                       # :142
+            ls = P.begin(x_old, y, F_old)                      # :279 (and :140, :142 where they are cached)
             accepted = False
             for _ in range(o["max_backtrack_iter"]):
-                def dual(w, lr=lr, f_y=f_y, J=J):              # _dual_minimized_fun_jac, :162-177
-                    v, ss_wJ = ops.mo_combine(y, J, w, lr)
-                    p = prox(torch.as_tensor(lr * w, dtype=torch.float64, device=x0.device), v)   # :164
-                    g_p = g(p)                                                                     # :165
-                    post = ops.mo_post_terms(J, y, p, v)
-                    if _is_device_tensor(g_p):
-                        host = torch.cat([ss_wJ, post, g_p.reshape(-1).to(torch.float64)]).cpu().numpy()
-                        g_pv = host[m + 2:]
-                    else:
-                        host = torch.cat([ss_wJ, post]).cpu().numpy()
-                        g_pv = _values(g_p, m)
-                    ss_w, dots, ss_pv = np.float64(host[0]), host[1:m + 1], np.float64(host[m + 1])
-                    fun = -np.inner(w, g_pv) - np.sqrt(ss_pv) ** 2 / 2 / lr + lr / 2 * np.sqrt(ss_w) ** 2
-                    jac = -g_pv - dots
-                    if not o["deprecated"]:
-                        fun += np.inner(w, F_old - f_y)
-                        jac = jac + (F_old - f_y)
-                    return fun, jac
-
-                weight, dual_fun, nit_int = multiobjective.solve_dual(dual, m, w0, o["tol_internal"],
-                                                                      o["max_iter_internal"], solver)
-                v, _ = ops.mo_combine(y, J, weight, lr)
-                x_cur = prox(torch.as_tensor(lr * weight, dtype=torch.float64, device=x0.device), v)   # :206
-                fun = -dual_fun                                                                          # :207
-                err = np.float64(ops.model_terms_dev(v, x_cur, y).cpu().numpy()[2])                      # :510
-                f_new, g_new = _values(f(x_cur), m), _values(g(x_cur), m)
-                F_new = f_new + g_new                                                                    # :295
-                if o["warm_start"]:
-                    w0 = weight
-                if o["decay_rate"] == 1:
+                tr = P.trial(ls, lr, x_old, y, w0)
+                if w0 is not None and o["warm_start"]:
+                    w0 = tr.weight
+                if o["decay_rate"] == 1:                       # :298
                     accepted = True
-                elif o["deprecated"]:
-                    accepted = bool(np.all(f_new - f_y <= fun + o["tol_internal"]))
-                else:
-                    accepted = bool(np.all(F_new - F_old <= fun + o["tol_internal"]))
+                elif o["deprecated"]:                          # :301
+                    accepted = bool(np.all(tr.df() <= tr.fun + o["tol_internal"]))
+                else:                                          # :303
+                    accepted = bool(np.all(tr.F_new - ls.F_old <= tr.fun + o["tol_internal"]))
                 if accepted:
                     break
-                lr *= o["decay_rate"]
+                lr *= o["decay_rate"]                          # :305
             if not accepted:
-                raise RuntimeError(_MSG_BACKTRACK)
-        except Exception as exc:   # :493-509
+                raise RuntimeError(_MSG_BACKTRACK)             # :306-307
+        except Exception as exc:   # :493-509: reported, not raised
             print(f"An error occurred: {exc}")
             bad = OptimizeResult()
-            bad.update(success=False, message=f"Error: {str(exc)}", x=x_old, fun=F_old,
+            bad.update(success=False, message=f"Error: {str(exc)}", x=x_old, fun=P.F_error(x_old, F_old),
                        nit=nit - 1, time=time.time() - t0,
                        allvecs=allvecs, allfuns=allfuns, allerrs=allerrs)
             return bad, _lib.ZF_BACKTRACK_FAILED
+        x_cur = tr.x
         if o["verbose"]:
-            _print_row(nit, nit_int, err, fun, lr)
+            _print_row(nit, tr.nit_int, tr.err, tr.fun, lr)
         if o["return_all"]:
             allvecs.append(x_cur)
-            allfuns.append(F_new)
-            allerrs.append(err)
-        F_old, f_old = F_new, f_new
-        if err < o["tol"]:   # :525
+            allfuns.append(P.F_record(tr))
+            allerrs.append(tr.err)
+        F_old = tr.F_new
+        P.accepted(tr)
+        if tr.err < o["tol"]:   # :525
             res.status, res.message, res.success = 1, _MSG_OK, True
             status = _lib.ZF_CONVERGED
             break
-        if o["nesterov"]:
+        if o["nesterov"]:       # :531-535
             beta, t_state = momentum_factors(1, o["nesterov_ratio"], t_state)
-            y = ops.momentum(x_cur, x_old, beta[0])
+            y = P.momentum(x_cur, x_old, beta[0])
         else:
             y = x_cur
         x_old = x_cur
     if status == _lib.ZF_MAXITER:
         res.status, res.message, res.success = 0, _MSG_MAXITER, False
-    res.update(x=x_cur, fun=F_old, nit=nit, allvecs=allvecs, allfuns=allfuns, allerrs=allerrs,
+    res.update(x=x_cur, fun=P.F_final(x_cur, F_old), nit=nit, allvecs=allvecs, allfuns=allfuns, allerrs=allerrs,
                time=time.time() - t0)
     return res, status
+
+
+class _LineSearch:
+    __slots__ = ("F_old", "f_y", "jac")
+
+    def __init__(self, F_old, f_y=None, jac=None):
+        self.F_old, self.f_y, self.jac = F_old, f_y, jac
+
+
+class _GenericOps:
+    """Opaque NumPy callbacks: they are called where and as often as the reference calls them (:140-142, :279,
+    :295, :301, :501, :523, :547); the solver's own vector expressions run in HIP kernels (zf_host_*)."""
+
+    def __init__(self, f, g, jac_f, prox, o):
+        self.f, self.g, self.jac_f, self.prox, self.o = f, g, jac_f, prox, o
+        self.ops = _VecOps()
+        self.m = 1
+
+    def start(self, x0):
+        f0 = self.f(x0)
+        self.m = _objectives(f0)
+        return f0 + self.g(x0)
+
+    def begin(self, x_old, y, F_old):
+        return _LineSearch(self.f(x_old) + self.g(x_old))      # :279
+
+    def trial(self, ls, lr, x_old, y, w0):
+        o = self.o
+        if self.m == 1:
+            x, fun, nit_int, weight, err = _trial_generic_single(self.ops, self.f, self.g, self.jac_f, self.prox, lr,
+                                                                 x_old, y, o["deprecated"])
+        else:
+            from . import multiobjective
+
+            x, fun, nit_int, weight, err = multiobjective.trial_generic(
+                self.ops, self.f, self.g, self.jac_f, self.prox, lr, x_old, y, w0, o["tol_internal"],
+                o["max_iter_internal"], o["deprecated"], o.get("dual_solver", "scipy"))
+        F_new = self.f(x) + self.g(x)                           # :295
+        return _TrialResult(x, fun, nit_int, weight, err, F_new, lambda: self.f(x) - self.f(y))   # :301
+
+    def accepted(self, tr):
+        pass
+
+    def momentum(self, x, x_old, beta):
+        return self.ops.momentum(x, x_old, beta)
+
+    def F_record(self, tr):
+        return self.f(tr.x) + self.g(tr.x)                      # :523
+
+    def F_final(self, x, F_old):
+        return self.f(x) + self.g(x)                            # :547
+
+    def F_error(self, x_old, F_old):
+        return self.f(x_old) + self.g(x_old)                    # :501
+
+
+class _TensorOps:
+    """Callbacks on device tensors, m = 1.  f(y) and jac_f(y) are evaluated once per line search (y is fixed
+    while lr shrinks) and F(x_k) is the value obtained when x_k was accepted - the reference re-evaluates both
+    per trial (:140-142, :279), which returns the same numbers for deterministic callbacks.  Iterates never leave
+    HBM; one transfer of five scalars per trial crosses PCIe."""
+
+    m = 1
+
+    def __init__(self, f, g, jac_f, prox, o, f0):
+        import torch
+
+        self.torch = torch
+        self.f, self.g, self.jac_f, self.prox, self.o = f, g, jac_f, prox, o
+        self.ops = _DevOps()
+        self.f0 = f0
+        self.f_old = None        # f(x_k) of the accepted iterate
+        self.x_k = None
+
+    def start(self, x0):
+        self.f_old = _scalar(self.f0)
+        self.x_k = x0
+        return self.f_old + _scalar(self.g(x0))
+
+    def begin(self, x_old, y, F_old):
+        f_y = self.f_old if y is x_old else _scalar(self.f(y))   # :140
+        return _LineSearch(F_old, f_y, self.jac_f(y))             # :142
+
+    def trial(self, ls, lr, x_old, y, w0):
+        torch, ops, o = self.torch, self.ops, self.o
+        x = self.prox(lr, ops.grad_step(y, ls.jac, lr))                  # :148
+        terms = ops.model_terms_dev(ls.jac, x, y)                        # :150-152, :510 (device)
+        g_val, f_val = self.g(x), self.f(x)
+        if _is_device_tensor(g_val) and _is_device_tensor(f_val) and g_val.numel() == 1 == f_val.numel():
+            # one transfer for all five scalars of the trial
+            five = torch.cat([terms, g_val.reshape(1).to(torch.float64),
+                              f_val.reshape(1).to(torch.float64)]).cpu().numpy()
+            dot, ss, err, g_new, f_new = (np.float64(v) for v in five)
+        else:
+            dot, ss, err = (np.float64(v) for v in terms.cpu().numpy())
+            g_new, f_new = _scalar(g_val), _scalar(f_val)
+        fun = np.float64(dot + g_new + np.sqrt(ss) ** 2 / 2 / lr)       # :149-152
+        if not o["deprecated"]:
+            fun = fun + (ls.f_y - ls.F_old)                              # :155
+        tr = _TrialResult(x, fun, 1, None, err, f_new + g_new, lambda: f_new - ls.f_y)   # :295, :301
+        tr.f_new = f_new
+        return tr
+
+    def accepted(self, tr):
+        self.f_old = tr.f_new
+
+    def momentum(self, x, x_old, beta):
+        return self.ops.momentum(x, x_old, beta)
+
+    def F_record(self, tr):
+        return tr.F_new
+
+    def F_final(self, x, F_old):
+        return F_old
+
+    def F_error(self, x_old, F_old):
+        return F_old
+
+
+class _TensorMultiOps(_TensorOps):
+    """The m >= 2 trial (:161-209) for callbacks on device tensors: f, g return (m,) tensors, jac_f an (m, n)
+    tensor, prox_wsum_g(weight, x) receives the weight lr * w as an (m,) device tensor.  Iterates, J and every
+    O(n) expression stay in HBM; the solver's own vector expressions (v = y - lr w@J, |w@J|^2, J(p - y),
+    |p - v|^2, max|x+ - y|) are HIP kernels (zf_dev_mo_*), the m-dimensional dual search runs on the host exactly
+    as for NumPy callbacks (``dual_solver=``), and one transfer of 2m + 2 scalars per dual evaluation crosses PCIe."""
+
+    def __init__(self, f, g, jac_f, prox, o, f0, m, x0):
+        super().__init__(f, g, jac_f, prox, o, f0)
+        self.m = m
+        self.device = x0.device
+        solver = o.get("dual_solver", "scipy")
+        # (the persistent-kernel search needs the library's own prox: built-in problems)
+        self.solver = "native" if solver == "device" else solver
+
+    def start(self, x0):
+        self.f_old = _values(self.f0, self.m)
+        return self.f_old + _values(self.g(x0), self.m)
+
+    def begin(self, x_old, y, F_old):
+        f_y = self.f_old if y is x_old else _values(self.f(y), self.m)   # :140
+        return _LineSearch(F_old, f_y, self.jac_f(y))                     # :142
+
+    def trial(self, ls, lr, x_old, y, w0):
+        from . import multiobjective
+
+        torch, ops, o, m = self.torch, self.ops, self.o, self.m
+        J, f_y, F_old = ls.jac, ls.f_y, ls.F_old
+
+        def dual(w):                                                     # _dual_minimized_fun_jac, :162-177
+            v, ss_wJ = ops.mo_combine(y, J, w, lr)
+            p = self.prox(torch.as_tensor(lr * w, dtype=torch.float64, device=self.device), v)   # :164
+            g_p = self.g(p)                                                                        # :165
+            post = ops.mo_post_terms(J, y, p, v)
+            if _is_device_tensor(g_p):
+                host = torch.cat([ss_wJ, post, g_p.reshape(-1).to(torch.float64)]).cpu().numpy()
+                g_pv = host[m + 2:]
+            else:
+                host = torch.cat([ss_wJ, post]).cpu().numpy()
+                g_pv = _values(g_p, m)
+            ss_w, dots, ss_pv = np.float64(host[0]), host[1:m + 1], np.float64(host[m + 1])
+            fun = -np.inner(w, g_pv) - np.sqrt(ss_pv) ** 2 / 2 / lr + lr / 2 * np.sqrt(ss_w) ** 2
+            jac = -g_pv - dots
+            if not o["deprecated"]:
+                fun += np.inner(w, F_old - f_y)
+                jac = jac + (F_old - f_y)
+            return fun, jac
+
+        weight, dual_fun, nit_int = multiobjective.solve_dual(dual, m, w0, o["tol_internal"], o["max_iter_internal"],
+                                                              self.solver)
+        v, _ = ops.mo_combine(y, J, weight, lr)
+        x = self.prox(torch.as_tensor(lr * weight, dtype=torch.float64, device=self.device), v)   # :206
+        err = np.float64(ops.model_terms_dev(v, x, y).cpu().numpy()[2])                            # :510
+        f_new, g_new = _values(self.f(x), m), _values(self.g(x), m)
+        tr = _TrialResult(x, -dual_fun, nit_int, weight, err, f_new + g_new, lambda: f_new - f_y)   # :207, :295, :301
+        tr.f_new = f_new
+        return tr
 
 
 def _solve_tensor(f, g, jac_f, prox, x0, o):
-    """The loop of proximal_gradient.py:463-554 for callbacks on device tensors (m = 1; m >= 2:
-    _solve_tensor_multi).
-
-    Call structure: f(y) and jac_f(y) are evaluated once per line search (y is fixed while lr
-    shrinks) and F(x_k) is the value obtained when x_k was accepted - the reference re-evaluates
-    both per trial (:140-142, :279), which returns the same numbers for deterministic callbacks."""
+    """Callbacks on device tensors: the shared loop with the tensor providers above."""
     import torch
 
-    ops = _DevOps()
-    t0 = time.time()
     if x0.dtype != torch.float64:
         raise TypeError("x0 must be a float64 tensor (the reference is float64 throughout)")
-    res = OptimizeResult(x0=x0, tol=o["tol"], tol_internal=o["tol_internal"],
-                         nesterov=o["nesterov"], nesterov_ratio=o["nesterov_ratio"])
-    if o["verbose"]:
-        _print_header()
-    x_old = x_cur = y = x0
     f0 = f(x0)
     m = int(f0.numel()) if hasattr(f0, "numel") else (f0.shape[0] if isinstance(f0, np.ndarray) else 1)   # :143,:467
-    if m > 1:
-        return _solve_tensor_multi(f, g, jac_f, prox, x0, o, f0, m)
-    f_old = _scalar(f0)
-    F_old = f_old + _scalar(g(x0))
-    lr = o["lr"]
-    allvecs = allfuns = allerrs = None
-    if o["return_all"]:
-        allvecs, allfuns, allerrs = [x0], [F_old], []
-    t_state = None
-    status = _lib.ZF_MAXITER
-    nit = 0
-    for nit in range(1, o["max_iter"] + 1):
-        try:
-            f_y = f_old if y is x_old else _scalar(f(y))   # :140
-            jac = jac_f(y)                                  # :142
-            accepted = False
-            for _ in range(o["max_backtrack_iter"]):
-                x_cur = prox(lr, ops.grad_step(y, jac, lr))                  # :148
-                terms = ops.model_terms_dev(jac, x_cur, y)                   # :150-152, :510 (device)
-                g_val, f_val = g(x_cur), f(x_cur)
-                if _is_device_tensor(g_val) and _is_device_tensor(f_val) and g_val.numel() == 1 == f_val.numel():
-                    # one transfer for all five scalars of the trial
-                    five = torch.cat([terms, g_val.reshape(1).to(torch.float64),
-                                      f_val.reshape(1).to(torch.float64)]).cpu().numpy()
-                    dot, ss, err, g_new, f_new = (np.float64(v) for v in five)
-                else:
-                    dot, ss, err = (np.float64(v) for v in terms.cpu().numpy())
-                    g_new, f_new = _scalar(g_val), _scalar(f_val)
-                fun = np.float64(dot + g_new + np.sqrt(ss) ** 2 / 2 / lr)   # :149-152
-                if not o["deprecated"]:
-                    fun = fun + (f_y - F_old)                                # :155
-                F_new = f_new + g_new                                        # :295
-                if o["decay_rate"] == 1:
-                    accepted = True
-                elif o["deprecated"]:
-                    accepted = bool(f_new - f_y <= fun + o["tol_internal"])
-                else:
-                    accepted = bool(F_new - F_old <= fun + o["tol_internal"])
-                if accepted:
-                    break
-                lr *= o["decay_rate"]
-            if not accepted:
-                raise RuntimeError(_MSG_BACKTRACK)
-        except Exception as exc:   # :493-509
-            print(f"An error occurred: {exc}")
-            bad = OptimizeResult()
-            bad.update(success=False, message=f"Error: {str(exc)}", x=x_old, fun=F_old,
-                       nit=nit - 1, time=time.time() - t0,
-                       allvecs=allvecs, allfuns=allfuns, allerrs=allerrs)
-            return bad, _lib.ZF_BACKTRACK_FAILED
-        if o["verbose"]:
-            _print_row(nit, 1, err, fun, lr)
-        if o["return_all"]:
-            allvecs.append(x_cur)
-            allfuns.append(F_new)
-            allerrs.append(err)
-        if err < o["tol"]:   # :525
-            res.status, res.message, res.success = 1, _MSG_OK, True
-            status = _lib.ZF_CONVERGED
-            F_old, f_old = F_new, f_new
-            break
-        if o["nesterov"]:
-            beta, t_state = momentum_factors(1, o["nesterov_ratio"], t_state)
-            y = ops.momentum(x_cur, x_old, beta[0])
-        else:
-            y = x_cur
-        x_old = x_cur
-        F_old, f_old = F_new, f_new
-    if status == _lib.ZF_MAXITER:
-        res.status, res.message, res.success = 0, _MSG_MAXITER, False
-    res.update(x=x_cur, fun=F_old, nit=nit, allvecs=allvecs, allfuns=allfuns, allerrs=allerrs,
-               time=time.time() - t0)
-    return res, status
+    P = _TensorMultiOps(f, g, jac_f, prox, o, f0, m, x0) if m > 1 else _TensorOps(f, g, jac_f, prox, o, f0)
+    return _solve_callbacks(P, x0, o)
 
 
 def _objectives(value):
@@ -757,76 +827,5 @@ def _trial_generic_single(ops, f, g, jac_f, prox, lr, x_old, y, deprecated):
 
 
 def _solve_generic(f, g, jac_f, prox, x0, o):
-    from . import multiobjective
-
-    ops = _VecOps()
-    t0 = time.time()
-    res = OptimizeResult(x0=x0, tol=o["tol"], tol_internal=o["tol_internal"],
-                         nesterov=o["nesterov"], nesterov_ratio=o["nesterov_ratio"])
-    if o["verbose"]:
-        _print_header()
-    x_old = x_cur = y = x0
-    f_x0 = f(x0)
-    m = _objectives(f_x0)
-    w0 = np.ones(m) / m if m > 1 else None
-    lr = o["lr"]
-    allvecs = allfuns = allerrs = None
-    if o["return_all"]:
-        allvecs, allfuns, allerrs = [x0], [f_x0 + g(x0)], []
-    t_state = None
-    status = _lib.ZF_MAXITER
-    nit = 0
-    for nit in range(1, o["max_iter"] + 1):
-        try:
-            F_old = f(x_old) + g(x_old)   # :279
-            accepted = False
-            for _ in range(o["max_backtrack_iter"]):
-                if m == 1:
-                    x_cur, fun, nit_int, weight, err = _trial_generic_single(
-                        ops, f, g, jac_f, prox, lr, x_old, y, o["deprecated"])
-                else:
-                    x_cur, fun, nit_int, weight, err = multiobjective.trial_generic(
-                        ops, f, g, jac_f, prox, lr, x_old, y, w0, o["tol_internal"],
-                        o["max_iter_internal"], o["deprecated"], o.get("dual_solver", "scipy"))
-                F_new = f(x_cur) + g(x_cur)   # :295
-                if w0 is not None and o["warm_start"]:
-                    w0 = weight
-                if o["decay_rate"] == 1:
-                    accepted = True
-                elif o["deprecated"]:
-                    accepted = bool(np.all(f(x_cur) - f(y) <= fun + o["tol_internal"]))
-                else:
-                    accepted = bool(np.all(F_new - F_old <= fun + o["tol_internal"]))
-                if accepted:
-                    break
-                lr *= o["decay_rate"]
-            if not accepted:
-                raise RuntimeError(_MSG_BACKTRACK)
-        except Exception as exc:   # :493-509
-            print(f"An error occurred: {exc}")
-            bad = OptimizeResult()
-            bad.update(success=False, message=f"Error: {str(exc)}", x=x_old, fun=f(x_old) + g(x_old),
-                       nit=nit - 1, time=time.time() - t0,
-                       allvecs=allvecs, allfuns=allfuns, allerrs=allerrs)
-            return bad, _lib.ZF_BACKTRACK_FAILED
-        if o["verbose"]:
-            _print_row(nit, nit_int, err, fun, lr)
-        if o["return_all"]:
-            allvecs.append(x_cur)
-            allfuns.append(f(x_cur) + g(x_cur))
-            allerrs.append(err)
-        if err < o["tol"]:   # :525
-            res.status, res.message, res.success = 1, _MSG_OK, True
-            status = _lib.ZF_CONVERGED
-            break
-        if o["nesterov"]:
-            beta, t_state = momentum_factors(1, o["nesterov_ratio"], t_state)
-            y = ops.momentum(x_cur, x_old, beta[0])
-        else:
-            y = x_cur
-        x_old = x_cur
-    if status == _lib.ZF_MAXITER:
-        res.status, res.message, res.success = 0, _MSG_MAXITER, False
-    res.update(x=x_cur, fun=f(x_cur) + g(x_cur), nit=nit, allvecs=allvecs, allfuns=allfuns,
-               allerrs=allerrs, time=time.time() - t0)
-    return res, status
+    """Opaque NumPy callbacks: the shared loop with _GenericOps."""
+    return _solve_callbacks(_GenericOps(f, g, jac_f, prox, o), x0, o)
