@@ -180,7 +180,7 @@ template <int S, int MODE, bool HIST, bool GRAD_INLINE, int SP = S> constexpr bo
 constexpr int ZF_GLDS_STREAMS = 4;                                   // x_k, x_{k-1}, d, c
 constexpr int ZF_GLDS_STAGE_UNITS = ZF_GLDS_STREAMS * ZF_BLOCK;      // 16-byte units per stage (16 KiB)
 constexpr int ZF_GLDS_NST = ZF_GLDS_STAGES;
-static_assert(ZF_GLDS_NST == 2 || ZF_GLDS_NST == 3, "2 or 3 stages");
+static_assert(ZF_GLDS_NST >= 2 && ZF_GLDS_NST <= 4, "2 .. 4 stages");
 
 constexpr int ZF_MAX_SUB = ZF_MAX_SUB_ITERS;   // trials chained per pass (temporal blocking), upper bound
 // levels of the transposing wave butterfly for a chain of S = 2^h trials: slot q < 5 of lane j * (64 >> h)
@@ -660,10 +660,12 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
             // ONE wait with ONE immediate; a branch between two waits inside one loop cost the full chain its
             // register allocation just like the switch.  Bodies that may store one iterate per unit instead of
             // two count one store per unit (a smaller count only waits for more).
-            static_assert(NST == 2 || NST == 3, "the counted waits below are written for 2 or 3 stages");
             constexpr int NSTORE = FULL ? 2 : 1;
-            auto trip = [&](int k, auto more_c) {
+            // AHEAD: DMAs still in flight behind the one this trip has to wait for (NST - 2 while there is something
+            // to issue; in the last NST - 1 trips one fewer per trip)
+            auto trip = [&](int k, auto more_c, auto ahead_c) {
                 constexpr bool MORE = decltype(more_c)::value;
+                constexpr int AHEAD = decltype(ahead_c)::value;
                 const zf_d2* sp = stage + st * ZF_GLDS_STAGE_UNITS + threadIdx.x;
                 st = (st + 1 == NST) ? 0 : st + 1;
                 const zf_d2 a = sp[0];
@@ -690,15 +692,18 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
                     }
                     advance(a1, o1, q, cc, unit_of(k));
                 }
-                if constexpr (MORE) zf_wait_vm<NL * (NST - 2) + NSTORE * (NST - 1)>();
-                else zf_wait_vm<NSTORE * (NST - 1)>();
+                zf_wait_vm<NL * AHEAD + NSTORE * (NST - 1)>();
             };
             const int steady = total - (NST - 1);   // trips that still have a unit to issue
             int k = 0;
 #pragma unroll 1
-            for (; k < steady; ++k) trip(k, std::true_type{});
-#pragma unroll 1
-            for (; k < total; ++k) trip(k, std::false_type{});
+            for (; k < steady; ++k) trip(k, std::true_type{}, std::integral_constant<int, NST - 2>{});
+            // the last NST - 1 trips, one statement each: trip `left` units before the end waits with left - 2 DMAs behind its own
+            if constexpr (NST >= 4)
+                if (k == total - 3 && k < total) trip(k++, std::false_type{}, std::integral_constant<int, 1>{});
+            if constexpr (NST >= 3)
+                if (k == total - 2 && k < total) trip(k++, std::false_type{}, std::integral_constant<int, 0>{});
+            if (k < total) trip(k++, std::false_type{}, std::integral_constant<int, 0>{});
         }
     } else if constexpr (UB == ZF_TILE_U || MODE == 1 || HIST || S >= 16) {
         // short chains (<= 148 VGPRs, three or more waves per SIMD): the other waves of the SIMD
