@@ -161,15 +161,21 @@ typedef __attribute__((address_space(3))) void* zf_lds_ptr;
 #ifndef ZF_S16_GLDS
 #define ZF_S16_GLDS 1
 #endif
-// Two experiments of round 3, both measured and both left OFF (profiles/r03_variants_ab.json; one box, n = 1e8 and 1e7):
-// a third DMA stage (two units in flight ahead of the chain: full chain 1.181 vs 1.191 ms at n = 1e8, 0.131 vs 0.128
-// at 1e7 - the pipe is not latency-bound) and the DMA path for the 8-trial bodies that serve the short passes of a
-// 16-chain solver (passes after a rejection 1.22 - 1.30 ms vs 1.16 ms with plain register loads at 3 waves per SIMD).
+// Two experiments of round 3 (profiles/r03_variants_ab.json, r03_stages_ab.json; same-box A/B, n = 1e8 and 1e7):
+// * a THIRD DMA stage - two units in flight ahead of the chain.  The full chain is bound by the vector pipe and does
+//   not care (1.181 vs 1.191 ms at n = 1e8, 0.131 vs 0.128 at 1e7); the HBM-bound 10-trial passes of the driver's
+//   K = 20 blocks do: 1.06 - 1.08 ms against 1.13 - 1.19 with two stages, +5 % on that line, twice on one box.  A
+//   fourth stage: no further gain.  ON.
+// * the DMA path for the 8-trial bodies that serve the short passes of a 16-chain solver: passes after a rejection
+//   1.22 - 1.30 ms vs 1.16 ms with plain register loads at 3 waves per SIMD.  OFF.
 #ifndef ZF_S8_GLDS
 #define ZF_S8_GLDS 0   // 1: the 8-trial bodies of PART 1 load by DMA too
 #endif
+#ifndef ZF_GENERAL_SINGLE_LOOP
+#define ZF_GENERAL_SINGLE_LOOP 1   // the general (non-full-chain) DMA bodies as one loop with run-time issue / wait selection
+#endif
 #ifndef ZF_GLDS_STAGES
-#define ZF_GLDS_STAGES 2   // LDS stages of the DMA pipeline: units in flight ahead of the one being computed + 1
+#define ZF_GLDS_STAGES 3   // LDS stages of the DMA pipeline: units in flight ahead of the one being computed + 1
 #endif
 // SP = packs per pass of the solver (S <= SP): the 8-trial bodies use the DMA path only inside a 16-chain solver
 template <int S, int MODE, bool HIST, bool GRAD_INLINE, int SP = S> constexpr bool zf_uses_glds() {
@@ -658,9 +664,11 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
             // trips, which have nothing left to issue, the stores alone.  (The first NST - 2 trips have fewer
             // stores behind them: their unit k + 1 landed with the prologue's wait.)  Each of the two loops has
             // ONE wait with ONE immediate; a branch between two waits inside one loop cost the full chain its
-            // register allocation just like the switch.  Bodies that may store one iterate per unit instead of
-            // two count one store per unit (a smaller count only waits for more).
-            constexpr int NSTORE = FULL ? 2 : 1;
+            // register allocation just like the switch.  The general bodies store one or two iterates per unit
+            // (wave-uniform, fixed for the pass): they choose between two immediates - counting one store where two
+            // were issued made every trip wait for a STORE to retire, a memory round trip per unit (+15-25 % on the
+            // 10-trial passes of the driver's K = 20 blocks, measured).
+            const bool two_stores = FULL || FRESH_FULL || ntr >= 2;   // iterate stores per unit: 2 or 1
             // AHEAD: DMAs still in flight behind the one this trip has to wait for (NST - 2 while there is something
             // to issue; in the last NST - 1 trips one fewer per trip)
             auto trip = [&](int k, auto more_c, auto ahead_c) {
@@ -692,10 +700,56 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
                     }
                     advance(a1, o1, q, cc, unit_of(k));
                 }
-                zf_wait_vm<NL * AHEAD + NSTORE * (NST - 1)>();
+                if constexpr (FULL) {
+                    zf_wait_vm<NL * AHEAD + 2 * (NST - 1)>();
+                } else {
+                    if (two_stores) zf_wait_vm<NL * AHEAD + 2 * (NST - 1)>();
+                    else zf_wait_vm<NL * AHEAD + (NST - 1)>();
+                }
             };
             const int steady = total - (NST - 1);   // trips that still have a unit to issue
             int k = 0;
+#if ZF_GENERAL_SINGLE_LOOP
+            if constexpr (!FULL) {
+                // the general bodies: ONE loop, the issue and the wait chosen at run time (wave-uniform branches; these
+                // bodies branch per trial anyway).  Three instances of the 16-trial general body - a steady loop and
+                // two peeled end trips - ran the driver's 10-trial passes at 1.00-1.03 ms against 0.90 with one
+                // (same-box A/B against round 2, profiles/r03_vs_r02_same_box.txt).
+                static_assert(NST <= 3, "the run-time waits are written for 2 or 3 stages");
+#pragma unroll 1
+                for (; k < total; ++k) {
+                    const zf_d2* sp = stage + st * ZF_GLDS_STAGE_UNITS + threadIdx.x;
+                    st = (st + 1 == NST) ? 0 : st + 1;
+                    const zf_d2 a = sp[0];
+                    const zf_d2 o = NESTEROV ? sp[ZF_BLOCK] : a;
+                    const zf_d2 q = sp[2 * ZF_BLOCK];
+                    const zf_d2 cc = sp[3 * ZF_BLOCK];
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool more = k < steady;
+                    if (more) issue(k + NST - 1);
+                    zf_d2 a1 = a, o1 = o;
+                    for (int i = 0; i < lag; ++i) {
+                        const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
+                        const double lr_i = A.ctl->lag_lr[i];
+                        const double tau_i = A.lam * lr_i;
+                        zf_d2 r;
+                        r.x = zf_elem_diag_replay<NESTEROV, BOX>(a1.x, o1.x, q.x, cc.x, b_i, lr_i, tau_i, A.lo, A.hi);
+                        r.y = zf_elem_diag_replay<NESTEROV, BOX>(a1.y, o1.y, q.y, cc.y, b_i, lr_i, tau_i, A.lo, A.hi);
+                        o1 = a1;
+                        a1 = r;
+                    }
+                    advance(a1, o1, q, cc, unit_of(k));
+                    // (with three stages the trip before the last has no DMA behind its own either: `more` is false)
+                    if (more) {
+                        if (two_stores) zf_wait_vm<NL * (NST - 2) + 2 * (NST - 1)>();
+                        else zf_wait_vm<NL * (NST - 2) + (NST - 1)>();
+                    } else {
+                        if (two_stores) zf_wait_vm<2 * (NST - 1)>();
+                        else zf_wait_vm<NST - 1>();
+                    }
+                }
+            }
+#endif
 #pragma unroll 1
             for (; k < steady; ++k) trip(k, std::true_type{}, std::integral_constant<int, NST - 2>{});
             // the last NST - 1 trips, one statement each: trip `left` units before the end waits with left - 2 DMAs behind its own
