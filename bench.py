@@ -60,8 +60,11 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_LANES_PER_CYCLE = 256 * 4 * 16
 CLOCK_GHZ = 2.4
 LR, LAM = 0.45, 0.1
-PMC_PROFILE = "r02_s{S}_pmc_traffic.json"
+PMC_PROFILE = "r02_s{S}_pmc_traffic.json"          # round-2 sets (chains of 1 / 8; the full chain of 16 before round 3)
 ISA_PROFILE = "r02_isa_mix_trial_kernel_s{S}.json"
+# round 3: one PMC set per FLAG SET of this file, summarised per shape-specific kernel (tools/profile_r3.sh):
+# the line names the kernel that dominates its timed region and reads THAT kernel's counters
+PMC_R3 = {"full": ("r03_pmc_defaults_k100_w10.json", "part0"), "general": ("r03_pmc_driver_k20_w5.json", "part2")}
 
 
 def make_inputs(n, seed, device):
@@ -98,6 +101,21 @@ def measured_clock_ghz(n, sub_iters):
     if not prof or prof.get("n") != n or "engine_clock_GHz" not in prof:
         return None
     return prof["engine_clock_GHz"]["median"]
+
+
+def kernel_profile(n, sub_iters, on_full):
+    """The committed PMC summary of the kernel this line is about - the full chain (PART 0) under the default
+    flags, the general 16-trial body (PART 2) under the driver's - or None (another n / chain length)."""
+    if sub_iters != 16:
+        return None
+    name, part = PMC_R3["full" if on_full else "general"]
+    prof = _profile(name)
+    if not prof or prof.get("n") != n or part not in prof.get("kernels", {}):
+        return None
+    k = dict(prof["kernels"][part])
+    k["file"], k["part"] = "profiles/" + name, part
+    k["trials_per_pass"] = prof.get("trials_per_pass", {}).get(part)
+    return k
 
 
 def valu_per_element_trial(sub_iters):
@@ -405,14 +423,23 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
             trials = float(S) if on_full else part_fresh / part_n      # fresh trials per pass
             replays = 0.0 if on_full else part_lag / part_n             # replayed iterations per pass
             pass_bytes = (PASS_BYTES_PER_ELEM if S > 1 else ALG_BYTES_PER_ELEM) * n
-            traffic = measured_traffic(n, S)
+            kp = kernel_profile(n, S, on_full)          # the counters of THIS kernel under THESE flags (round 3)
+            traffic = kp.get("hbm_bytes_per_launch") if kp else measured_traffic(n, S)
+            traffic_file = kp["file"] + " [" + kp["part"] + "]" if kp else "profiles/" + PMC_PROFILE.format(S=S)
             achieved = pass_bytes / (ker_ms * 1e-3) / 1e9
             hbm_frac = achieved / HBM_PEAK_GBS
             vpe = valu_per_element_trial(S)
             valu_ms = valu_frac = None
-            clk = measured_clock_ghz(n, S)
+            clk = (kp.get("engine_clock_GHz") or {}).get("median") if kp else measured_clock_ghz(n, S)
             # a replayed iteration is the iterate arithmetic alone: 11 fp64 operations + the sign copy
             inst_per_elem = None if not vpe else vpe * trials + 12.0 * replays
+            inst_source = "profiles/" + ISA_PROFILE.format(S=S) + " (ISA: instructions per element and trial x trials per pass)"
+            if kp and kp.get("valu_lane_instructions_per_element") and (
+                    on_full or (kp.get("trials_per_pass") and abs(kp["trials_per_pass"] - trials) < 0.01 and replays == 0)):
+                # measured for exactly this pass shape: SQ_INSTS_VALU per launch x 64 lanes / n
+                inst_per_elem = kp["valu_lane_instructions_per_element"]
+                vpe = vpe or inst_per_elem / max(trials, 1.0)
+                inst_source = kp["file"] + " [" + kp["part"] + "]: SQ_INSTS_VALU per launch x 64 / n (measured for this pass shape)"
             if vpe:
                 valu_ms = inst_per_elem * n / (FP64_LANES_PER_CYCLE * CLOCK_GHZ * 1e9) * 1e3
                 valu_frac = valu_ms / ker_ms
@@ -427,7 +454,9 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 "unit": "T lane-instructions/s",
                 "frac": valu_frac,
                 "valu_instructions_per_element_trial": vpe,
-                "source": "profiles/" + ISA_PROFILE.format(S=S),
+                "valu_instructions_per_element_and_pass": inst_per_elem,
+                "valu_busy_fraction_measured": kp.get("valu_busy_fraction") if kp else None,
+                "source": inst_source,
                 "min_ms_at_2.4GHz": valu_ms,
                 "engine_clock_GHz_under_this_kernel": clk,
                 "frac_at_that_clock": None if clk is None else valu_frac * CLOCK_GHZ / clk,
@@ -445,8 +474,8 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 "unit": top["unit"],
                 "frac": top["frac"],
                 "traffic": traffic,
-                "traffic_source": f"profiles/{PMC_PROFILE.format(S=S)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                  "passes, bytes per full-chain launch)" if traffic else None,
+                "traffic_source": f"{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch "
+                                  "of the kernel named below)" if traffic else None,
                 "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (full-chain passes)" if on_full else
                           f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (general body: passes of {trials:.1f} fresh "
                           f"trials + {replays:.1f} replayed iterations on average; no full chain dominates K = {K})",

@@ -374,8 +374,9 @@ int zf_mo_set_fused(zf_mo* s, int32_t on);
  * the device.  A trial launched with gated = 1 - after zf_mo_commit + zf_mo_prepare_async, before the result of
  * the trial before it is known - runs only if that trial was accepted (else it exits at once having touched
  * nothing: *skipped_out = 1; call zf_mo_uncommit, then retry with a smaller step) and takes F(x_k) from that
- * trial's F(x+) on the device (F_old may then be NULL).  At most one trial may be in flight ahead of the one
- * waited for.  *ticket_out = -1: not a device trial (sharded x, m > 3) - use the host loop. */
+ * trial's F(x+) on the device (F_old may then be NULL); gated = 2: it also starts its search from that trial's
+ * weights (warm_start, :286-288), likewise taken on the device.  At most one trial may be in flight ahead of the
+ * one waited for.  *ticket_out = -1: not a device trial (sharded x, m > 3) - use the host loop. */
 int zf_mo_trial_launch(zf_mo* s, double lr, const double* F_old /* m or NULL */, int32_t deprecated,
                        const double* w0 /* m or NULL */, double tol, int64_t max_iter, double accept_tol,
                        int32_t decay_is_one, int32_t gated, int32_t* ticket_out);

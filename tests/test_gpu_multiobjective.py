@@ -481,7 +481,7 @@ def test_fused_outer_iteration_is_invisible(kind):
 
 
 @pytest.mark.parametrize("case", ["jos1_backtrack", "jos1_converge", "fds_backtrack", "fds_box_outside", "jos1_short",
-                                  "fds_deprecated", "jos1_decay1"])
+                                  "fds_deprecated", "jos1_decay1", "jos1_warm", "fds_warm"])
 def test_trials_launched_ahead_match_the_sequential_loop(case, monkeypatch):
     """dual_solver="device" launches every trial ahead of its predecessor's result (gated on the decision the
     kernel takes itself, zf_mo_trial_launch / _wait).  Against the same solve with the host reading every
@@ -497,8 +497,10 @@ def test_trials_launched_ahead_match_the_sequential_loop(case, monkeypatch):
         n = 20011
         prob = lambda: JOS1(n, l1_ratios=np.array([1.0, 2.0]) / n, l1_shifts=[0.0, 1.0])   # noqa: E731
         x0 = rng.uniform(-2, 4, n)
-        if case == "jos1_backtrack":
-            runs = [dict(kw, lr=64.0 * n, max_iter=15)]            # several halvings in the first line searches
+        if case in ("jos1_backtrack", "jos1_warm"):
+            # several halvings in the first line searches; warm: every search starts from the weights of the trial
+            # before it (:286-288) - of the accepted trial on the device (gated = 2), of a rejected one from its record
+            runs = [dict(kw, lr=64.0 * n, max_iter=15, warm_start=(case == "jos1_warm"))]
         elif case == "jos1_converge":
             runs = [dict(kw, lr=0.5 * n, tol=1e-3, max_iter=500)]
         elif case == "jos1_short":
@@ -513,7 +515,7 @@ def test_trials_launched_ahead_match_the_sequential_loop(case, monkeypatch):
         else:
             prob = lambda: FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0.0, 1.0, 2.0])   # noqa: E731
             x0 = rng.uniform(-2, 2, n)
-        runs = [dict(kw, lr=1.0, max_iter=10, deprecated=(case == "fds_deprecated"))]
+        runs = [dict(kw, lr=1.0, max_iter=10, deprecated=(case == "fds_deprecated"), warm_start=(case == "fds_warm"))]
     for opts in runs:
         out = []
         for ahead in ("1", "0"):

@@ -351,6 +351,10 @@ struct mo_solve_args {
     const double* F_old_dev;
     int* accept_out;
     double* F_new_out;
+    // warm start of a trial launched ahead (:192-205, :286-288): the weights the trial before it ended with, on the
+    // device (w_new_out of that launch); NULL: w0[] above / the uniform start
+    const double* w0_dev;
+    double* w_new_out;
     int decay_is_one;
     double accept_tol;
     unsigned spin_limit;  // polls a grid-wide wait may take before the launch gives up (ok = -1)
@@ -828,7 +832,10 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
     }
     if (tid == 0) {
         mach_t mach;
-        mach.start(A.has_w0 ? A.w0 : nullptr, A.tol, (long)A.max_iter);
+        double w_start[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) w_start[i] = A.w0_dev ? A.w0_dev[i] : A.w0[i];
+        mach.start((A.has_w0 || A.w0_dev) ? w_start : nullptr, A.tol, (long)A.max_iter);
         s_mach = mach;
     }
     __syncthreads();
@@ -1129,6 +1136,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
                 r.g_x[i] = gx;
                 const double F_new = fx[i] + gx;
                 if (A.F_new_out) A.F_new_out[i] = F_new;
+                if (A.w_new_out) A.w_new_out[i] = s_mach.w[i];
                 const double lhs = A.deprecated ? fx[i] - s_fy[i] : F_new - s_Fold[i];
                 if (!(lhs <= -s_mach.fun + A.accept_tol)) accepted = 0;   // (fun of the trial = - dual value, :207)
             }
@@ -1185,7 +1193,7 @@ struct zf_mo {
     mo_solve_result* solve_out = nullptr;      // device view of h_solve_out (two records: launches alternate)
     mo_solve_result* h_solve_out = nullptr;    // pinned host memory the kernel writes directly
     int* accept_dev = nullptr;                 // [2] acceptance decision of the launch of either parity
-    double* F_dev = nullptr;                   // [2][MO_MAX_M] F(x+) of the launch of either parity
+    double* F_dev = nullptr;                   // [2][MO_MAX_M] F(x+) of the launch of either parity; [2][MO_MAX_M] behind them: its weights
     unsigned last_nonce[2] = {0, 0};           // launch number whose record each slot is waiting for / holds
     int last_slot = 0;                         // slot of the most recent launch (zf_mo_solve_stats)
     int solve_grid = 0;
@@ -1764,6 +1772,7 @@ namespace {
 struct mo_launch_opts {
     int gated = 0;          // launched ahead: runs only if the launch before it accepted its trial, F(x_k) from there
     int decay_is_one = 0;   // decay_rate == 1: every trial is accepted (:299)
+    int warm = 0;           // warm_start: a gated trial starts its search from the weights of the trial before it
     double accept_tol = 0.0;
 };
 
@@ -1805,9 +1814,9 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
         memset(s->h_solve_out, 0, 2 * sizeof(mo_solve_result));
         ZF_HIP(hipHostGetDevicePointer((void**)&s->solve_out, s->h_solve_out, 0));
         ZF_HIP(hipMalloc(&s->accept_dev, 2 * sizeof(int)));
-        ZF_HIP(hipMalloc(&s->F_dev, 2 * MO_MAX_M * sizeof(double)));
+        ZF_HIP(hipMalloc(&s->F_dev, 4 * MO_MAX_M * sizeof(double)));
         ZF_HIP(hipMemsetAsync(s->accept_dev, 0, 2 * sizeof(int), s->stream));
-        ZF_HIP(hipMemsetAsync(s->F_dev, 0, 2 * MO_MAX_M * sizeof(double), s->stream));
+        ZF_HIP(hipMemsetAsync(s->F_dev, 0, 4 * MO_MAX_M * sizeof(double), s->stream));
     }
     mo_solve_args A;
     memset(&A, 0, sizeof(A));
@@ -1835,6 +1844,8 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
     A.out = s->solve_out + slot;
     A.accept_out = s->accept_dev + slot;
     A.F_new_out = s->F_dev + slot * MO_MAX_M;
+    A.w_new_out = s->F_dev + (2 + slot) * MO_MAX_M;
+    if (L.gated && L.warm) A.w0_dev = s->F_dev + (2 + (1 - slot)) * MO_MAX_M;   // the weights of the trial launched before
     A.decay_is_one = L.decay_is_one;
     A.accept_tol = L.accept_tol;
     if (L.gated) {   // the launch before this one has the other parity
@@ -1987,6 +1998,7 @@ extern "C" int zf_mo_trial_launch(zf_mo* s, double lr, const double* F_old, int3
     ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_trial_launch: lr must be > 0 and max_iter >= 1");
     mo_launch_opts L;
     L.gated = gated != 0;
+    L.warm = gated == 2;   // gated AND warm-started from the weights the trial before it ends with (on the device)
     L.decay_is_one = decay_is_one != 0;
     L.accept_tol = accept_tol;
     int slot = 0, launched = 0;

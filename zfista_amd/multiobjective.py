@@ -291,7 +291,7 @@ class MoEngine:
             b_w0[:] = w0
         rc = self.lib.zf_mo_trial_launch(self.h, float(lr), None if F_old is None else ptrs[0], int(bool(deprecated)),
                                          None if w0 is None else ptrs[1], float(tol), int(max_iter), float(accept_tol),
-                                         int(bool(decay_is_one)), int(bool(gated)), C.byref(ticket))
+                                         int(bool(decay_is_one)), int(gated), C.byref(ticket))
         if rc != _lib.ZF_OK:
             self._check(rc, "zf_mo_trial_launch")
         return None if ticket.value < 0 else int(ticket.value)
@@ -626,7 +626,7 @@ def solve_native(problem, x0, o):
     t_state = None
     betas = []
     nit_done = trials_done = 0
-    if (lazy_f_y and not o["return_all"] and not o["warm_start"] and o["max_iter"] >= 1
+    if (lazy_f_y and not o["return_all"] and o["max_iter"] >= 1
             and os.environ.get("ZF_MO_LAUNCH_AHEAD", "1") != "0"):
         out = _solve_native_ahead(eng, o, m, F_old, res, t0)
         if isinstance(out, _HandOver):
@@ -735,6 +735,7 @@ def _solve_native_ahead(eng, o, m, F_old, res, t0):
     lr = o["lr"]
     tol_i, max_i, dep = o["tol_internal"], o["max_iter_internal"], o["deprecated"]
     decay_one = o["decay_rate"] == 1
+    warm = bool(o["warm_start"])
     t_state, betas = None, []
 
     def next_beta():
@@ -763,7 +764,8 @@ def _solve_native_ahead(eng, o, m, F_old, res, t0):
                 beta = next_beta()
                 eng.commit(beta, o["nesterov"])
                 eng.prepare_async()
-                ahead = (eng.trial_launch(lr, None, dep, None, tol_i, max_i, tol_i, decay_one, True), beta)
+                # (warm_start: its search starts from the weights this trial ends with - taken on the device, gated = 2)
+                ahead = (eng.trial_launch(lr, None, dep, None, tol_i, max_i, tol_i, decay_one, 2 if warm else 1), beta)
             out = eng.trial_wait(ticket)
             if out is not None and isinstance(out[0], str) and out[0] == "timed out":
                 # a grid-wide wait of the kernel gave up (its workgroups were not all resident): its record says
@@ -805,7 +807,8 @@ def _solve_native_ahead(eng, o, m, F_old, res, t0):
                            time=time.time() - t0, allvecs=None, allfuns=None, allerrs=None)
                 return bad, _lib.ZF_BACKTRACK_FAILED
             lr *= o["decay_rate"]
-            ticket = eng.trial_launch(lr, F_k, dep, None, tol_i, max_i, tol_i, decay_one, False)
+            # (warm_start: the retry starts from the weights of the trial just rejected, :286-288)
+            ticket = eng.trial_launch(lr, F_k, dep, weight if warm else None, tol_i, max_i, tol_i, decay_one, False)
         if o["verbose"]:
             _print_row(nit, nit_int, err, fun, lr)
         F_k = F_new
