@@ -257,3 +257,58 @@ def test_sharded_multiobjective_native_search_through_the_library_communicator(c
         assert res0.nit == int(G(f"{tag}.fista.nit"))
     for c_ in comms:
         c_.close()
+
+
+def test_kernel_timing_of_a_row_sharded_solver_with_thread_ranks():
+    """zf_solver_set_timing on a ROW-sharded least-squares solver: the prox step of a trial runs after the exchange
+    (zf_solver_enqueue_trial_finish), so the first half of the trial must not reserve an event pair it never
+    records (zf_collect_timing then read unrecorded events: an error, or garbage).  Two rank threads; the timing
+    calls must succeed and report sane numbers; the cache-resident two-launch path logs its passes as well."""
+    import threading
+
+    import torch
+
+    from oracle import problems_ref as P
+    from zfista_amd import _lib
+    from zfista_amd.comm import LibComm
+    from zfista_amd.problems import LeastSquaresL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    m, n, world = 96, 192, 2
+    A, b, lam = P.make_plasso(m, n, seed=2)
+    o = dict(lr=1.0, tol=0.0, tol_internal=1e-12, max_iter=12, max_backtrack_iter=100, decay_rate=0.5, nesterov=True,
+             nesterov_ratio=(0, 0.25), deprecated=False)
+    comms = LibComm.local_group(world, cap_doubles=4096)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            r0, r1 = r * m // world, (r + 1) * m // world
+            with torch.cuda.stream(torch.cuda.Stream()):
+                prob = LeastSquaresL1(np.ascontiguousarray(A[r0:r1]), b[r0:r1], lam, group=comms[r], shard="rows")
+                run = NativeRun(prob, np.zeros(n), o, timing=True)
+                while run.status == _lib.ZF_RUNNING:
+                    run.advance(3)
+                out[r] = (run.nit_seen, run.solver.trial_kernel_ms())
+                run.solver.close()
+        except Exception as exc:   # pragma: no cover - reported below
+            errs.append(exc)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs, errs
+    for nit, (ms, cnt) in out:
+        assert nit == 12 and ms >= 0.0 and cnt >= 0
+    for c_ in comms:
+        c_.close()
+    # the cache-resident two-launch path (unsharded): its passes are logged, full-chain statistics are consistent
+    prob = LeastSquaresL1(A, b, lam)
+    run = NativeRun(prob, np.zeros(n), o, timing=True)
+    while run.status == _lib.ZF_RUNNING:
+        run.advance(3)
+    (fm, fn), (pm, pn) = run.solver.pass_stats()
+    assert fn + pn >= 12 and fm > 0.0   # (S = 1: every trial is a "full chain" of one)
+    run.solver.close()
