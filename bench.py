@@ -64,7 +64,9 @@ PMC_PROFILE = "r02_s{S}_pmc_traffic.json"          # round-2 sets (chains of 1 /
 ISA_PROFILE = "r02_isa_mix_trial_kernel_s{S}.json"
 # round 3: one PMC set per FLAG SET of this file, summarised per shape-specific kernel (tools/profile_r3.sh):
 # the line names the kernel that dominates its timed region and reads THAT kernel's counters
-PMC_R3 = {"full": ("r03_pmc_defaults_k100_w10.json", "part0"), "general": ("r03_pmc_driver_k20_w5.json", "part2")}
+PMC_R3 = {"full": ("r03_pmc_defaults_k100_w10.json", "part0"), "mid": ("r03_pmc_driver_k20_w5.json", "part3"),
+          "general": ("r03_pmc_driver_k20_w5.json", "part2")}
+MID_CHAIN = 10   # trials of the branch-free mid chain (csrc/zf_kernels_step.h: ZF_MID_CHAIN): the driver's K = 20 blocks run two
 
 
 def make_inputs(n, seed, device):
@@ -103,12 +105,13 @@ def measured_clock_ghz(n, sub_iters):
     return prof["engine_clock_GHz"]["median"]
 
 
-def kernel_profile(n, sub_iters, on_full):
+def kernel_profile(n, sub_iters, kind):
     """The committed PMC summary of the kernel this line is about - the full chain (PART 0) under the default
-    flags, the general 16-trial body (PART 2) under the driver's - or None (another n / chain length)."""
+    flags, the branch-free 10-trial chain (PART 3) or the general 16-trial body (PART 2) under the driver's - or
+    None (another n / chain length)."""
     if sub_iters != 16:
         return None
-    name, part = PMC_R3["full" if on_full else "general"]
+    name, part = PMC_R3[kind]
     prof = _profile(name)
     if not prof or prof.get("n") != n or part not in prof.get("kernels", {}):
         return None
@@ -423,7 +426,8 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
             trials = float(S) if on_full else part_fresh / part_n      # fresh trials per pass
             replays = 0.0 if on_full else part_lag / part_n             # replayed iterations per pass
             pass_bytes = (PASS_BYTES_PER_ELEM if S > 1 else ALG_BYTES_PER_ELEM) * n
-            kp = kernel_profile(n, S, on_full)          # the counters of THIS kernel under THESE flags (round 3)
+            mid = (not on_full) and S == 16 and abs(trials - MID_CHAIN) < 1e-9 and replays == 0
+            kp = kernel_profile(n, S, "full" if on_full else ("mid" if mid else "general"))   # THIS kernel's counters (round 3)
             traffic = kp.get("hbm_bytes_per_launch") if kp else measured_traffic(n, S)
             traffic_file = kp["file"] + " [" + kp["part"] + "]" if kp else "profiles/" + PMC_PROFILE.format(S=S)
             achieved = pass_bytes / (ker_ms * 1e-3) / 1e9
@@ -477,8 +481,10 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 "traffic_source": f"{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch "
                                   "of the kernel named below)" if traffic else None,
                 "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (full-chain passes)" if on_full else
-                          f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (general body: passes of {trials:.1f} fresh "
-                          f"trials + {replays:.1f} replayed iterations on average; no full chain dominates K = {K})",
+                          (f"zf_trial_kernel<grad inline, nesterov, nt, S={S}, PART 3> (branch-free chain of {MID_CHAIN} trials: "
+                           f"the K = {K} timed iterations are shared by passes of {MID_CHAIN}; no full chain runs)" if mid else
+                           f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (general body: passes of {trials:.1f} fresh "
+                           f"trials + {replays:.1f} replayed iterations on average; no full chain dominates K = {K})"),
                 "kernel_avg_ms": ker_ms,
                 "kernel_launches_timed": full_n if on_full else part_n,
                 "trials_per_pass": trials,

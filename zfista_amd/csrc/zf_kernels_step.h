@@ -191,7 +191,25 @@ static_assert(ZF_GLDS_NST >= 2 && ZF_GLDS_NST <= 4, "2 .. 4 stages");
 constexpr int ZF_MAX_SUB = ZF_MAX_SUB_ITERS;   // trials chained per pass (temporal blocking), upper bound
 // levels of the transposing wave butterfly for a chain of S = 2^h trials: slot q < 5 of lane j * (64 >> h)
 // ends up with quantity q of trial j
-constexpr int zf_chain_h(int S) { return S >= 16 ? 4 : S >= 8 ? 3 : S >= 4 ? 2 : S >= 2 ? 1 : 0; }
+// (S a power of two: log2 S; otherwise the largest h <= 4 with 2^h | S - the butterfly then leaves S / 2^h trials per lane group)
+constexpr int zf_chain_h(int S) {
+    int h = 0;
+    while (h < 4 && S % (2 << h) == 0) ++h;
+    return h;
+}
+// trials of the branch-free MID chain: the driver-sized tail before max_iter (S < left <= 2 x this: two passes of this many)
+constexpr int ZF_MID_CHAIN = 10;
+// Which shape-specific kernel runs a pass of `nf` fresh trials behind `lag` lagging iterations (S = chain length of
+// the solver): 0 the full chain; 3 (S = 16) exactly ZF_MID_CHAIN fresh trials, nothing replayed; 2 (S = 16) other
+// chains of more than S / 2; 1 everything else.  Shared by the kernels and the host's prediction.
+ZF_HD inline int zf_pass_part(int S, int lag, int nf) {
+    if (lag == 0 && nf == S) return 0;
+#ifndef ZF_MID_CHAIN_OFF   // (A/B builds: the general body takes these passes)
+    if (S >= 16 && lag == 0 && nf == ZF_MID_CHAIN) return 3;
+#endif
+    if (S >= 16 && nf > S / 2) return 2;
+    return 1;
+}
 #ifndef ZF_S16_UB
 #define ZF_S16_UB 1   // units per load batch of the 16-trial chain (192 VGPRs of running sums leave room for one)
 #endif
@@ -854,13 +872,15 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     }
     zf_wave_reduce_multi<5 * S, H, false>(sums, lane);
     zf_wave_reduce_multi<S, H, true>(maxs, lane);
-    if ((lane & ((64 >> H) - 1)) == 0) {
+    if ((lane & ((64 >> H) - 1)) == 0) {   // (S >> H trials per lane group: one when S is a power of two)
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < ((5 * S) >> H); ++q) {
             const int idx = zf_wave_reduce_multi_index<5 * S, H>(q, lane);
             lds[wave * NQ + (idx / 5) * ZF_NPART + idx % 5] = sums[q];
         }
-        lds[wave * NQ + zf_wave_reduce_multi_index<S, H>(0, lane) * ZF_NPART + 5] = maxs[0];
+#pragma unroll
+        for (int q = 0; q < (S >> H); ++q)
+            lds[wave * NQ + zf_wave_reduce_multi_index<S, H>(q, lane) * ZF_NPART + 5] = maxs[q];
     }
     __syncthreads();
     double v = 0.0;   // (rows of trials S .. SP - 1: no such trial in this pass)
@@ -883,17 +903,18 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
 //   1: every other shape (replays, shorter chains, materialise-only) - for S = 16: of up to 8 fresh
 //      trials, through the 8-trial bodies (pack rows of trials 8 .. 15 written as zeros);
 //   2: S = 16 only: 9 .. 15 fresh trials (the shared tail before max_iter, zf_fresh_len) through the
-//      general 16-trial body - a wave-uniform branch per trial, LDS-DMA loads.
+//      general 16-trial body - a wave-uniform branch per trial, LDS-DMA loads;
+//   3: S = 16 only: exactly ZF_MID_CHAIN = 10 fresh trials and nothing replayed - a branch-free 10-chain.
 // One kernel holding all bodies needs the registers of the largest plus what the compiler hoists across
 // the branches (S = 16: 274 VGPRs for parts 0 + 1, ~400 for parts 1 + 2 - one wave per SIMD instead of two;
 // S = 8: 207 instead of 190); every further launch costs a kernel boundary (~1.5-4 us) per pass.
 template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false, int PART = 0>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
-    static_assert(PART <= 1 || S >= 16, "the third kernel exists for chains of 16 only");
+    static_assert(PART <= 1 || S >= 16, "the third and fourth kernels exist for chains of 16 only");
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
-    constexpr bool GLDS = PART != 1 ? zf_uses_glds<S, PART == 0 ? 0 : 2, HIST, GRAD_INLINE>()
-                                    : (S >= 16 && zf_uses_glds<S / 2, 1, HIST, GRAD_INLINE, S>());
+    constexpr bool GLDS = PART == 3 ? false : PART != 1 ? zf_uses_glds<S, PART == 0 ? 0 : 2, HIST, GRAD_INLINE>()
+                                                         : (S >= 16 && zf_uses_glds<S / 2, 1, HIST, GRAD_INLINE, S>());
     __shared__ zf_d2 stage[GLDS ? ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS : 1];   // the stages of the LDS-DMA pipeline (16 KiB each)
     // wave-uniform control reads (scalar loads); written by the previous step's decide
     if (A.ctl->status != ZF_RUNNING) return;
@@ -907,12 +928,14 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     } else {
         const int lag = A.ctl->lag;
         const int nf = zf_fresh_len(A.ctl);   // fresh trials of this chain (0: materialise only)
-        const bool full = (lag == 0 && nf == S);
-        const int part = full ? 0 : ((S >= 16 && nf > S / 2) ? 2 : 1);
-        if (part != PART) return;
+        if (zf_pass_part(S, lag, nf) != PART) return;
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = (lag << 8) | nf;
         if constexpr (PART == 0) {
             zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, S, stage);
+        } else if constexpr (PART == 3) {
+            // the branch-free chain of ZF_MID_CHAIN trials through the register-load pipeline of the short chains:
+            // the HBM-bound passes of a tail shared by two passes (the driver's K = 20 blocks: 10 + 10)
+            zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, ZF_MID_CHAIN, 0, HIST, S>(A, lds, 0, ZF_MID_CHAIN);
         } else if constexpr (PART == 2) {
             // (nf is laundered through readfirstlane: knowing nf > S / 2 the compiler made the first
             //  trials unconditional, scheduled across them and needed 379 VGPRs instead of 227; an empty

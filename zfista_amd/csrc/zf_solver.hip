@@ -176,7 +176,7 @@ struct zf_solver {
     // Which shape-specific kernel a pass needs is decided on the device; the host PREDICTS it from the control
     // block of its last poll (zf_predict_parts) and launches only that one.  A wrong prediction costs passes that
     // do nothing (no kernel finds its shape, the control block stays as it is), never a wrong result.
-    int part_mask = 7;
+    int part_mask = 15;
     int pass_seq = 0;                     // step counter (zf_step_args.pass_seq)
     zf_control shadow;                    // the control block as the host expects it after the passes enqueued so far
     bool shadow_valid = false;            // false until the next poll (after init / restore / flush / set_max_iter ...)
@@ -343,8 +343,10 @@ static void zf_launch_trial_parts(zf_solver* s, const zf_step_args& a) {
     if (mask & 1) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 0>), g, b, 0, s->stream, a);
     if constexpr (S > 1)
         if (mask & 2) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 1>), g, b, 0, s->stream, a);
-    if constexpr (S >= 16)
+    if constexpr (S >= 16) {
         if (mask & 4) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 2>), g, b, 0, s->stream, a);
+        if (mask & 8) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 3>), g, b, 0, s->stream, a);
+    }
 }
 
 // history-recording variants (nontemporal policy only: the history is write-once)
@@ -472,14 +474,13 @@ static int zf_predict_parts(zf_solver* s) {
     static const bool off = [] { const char* e = getenv("ZF_SPECULATE"); return e && atoi(e) == 0; }();
     if (off || s->sub <= 1 || !s->shadow_valid || s->careful || s->desc.world != 1 || s->comm ||
         s->desc.kind != ZF_PROBLEM_DIAG_QUAD_L1)
-        return 7;
+        return 15;
     zf_control& c = s->shadow;
-    if (c.status != ZF_RUNNING) return 7;   // (expected to be finished; if the device is not - a chain broke - any shape may be due)
+    if (c.status != ZF_RUNNING) return 15;   // (expected to be finished; if the device is not - a chain broke - any shape may be due)
     const int S = s->sub;
     const int lag = c.lag;
     const int nf = zf_fresh_len(&c);
-    const bool full = (lag == 0 && nf == S);
-    const int part = full ? 0 : ((S >= 16 && nf > S / 2) ? 2 : 1);
+    const int part = zf_pass_part(S, lag, nf);
     if (c.pend_status != 0) {
         c.lag = 0;
         if (c.pend_status > 0) c.status = c.pend_status;
@@ -539,11 +540,11 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             s->pass_seq = s->pass_seq >= 0x7ffffff0 ? 1 : s->pass_seq + 1;
             a.pass_seq = s->pass_seq;
         }
-        s->part_mask = (dry || !decide_in_launch) ? 7 : zf_predict_parts(s);
+        s->part_mask = (dry || !decide_in_launch) ? 15 : zf_predict_parts(s);
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
         zf_launch_trial_t<true>(s, a);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
-        s->part_mask = 7;
+        s->part_mask = 15;
         if (!dry && fin_kernel) zf_launch_finalize(s, d.world == 1 && decide_in_launch);
     } else if (s->ls_small && !dry && decide_in_launch) {
         // cache-resident A: the whole trial in two launches (zf_kernels_ls_small.h)
