@@ -272,6 +272,11 @@ int zf_solver_get_x_prev(zf_solver* s, double* x_host, int64_t count /* >= n */)
 int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev, const zf_control* saved,
                       int64_t saved_bytes /* == zf_sizeof_control(): a block of another layout is refused */);
 int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches);
+/* since creation: out[0] = trial steps issued, out[1] = shape-specific trial kernels launched for them.  A chained
+ * pass has up to four shapes (full chain, short, long, mid) and needs one; the host launches only the one it
+ * expects once a poll has shown it the control block and the last chunk had no rejection - unsharded, and
+ * sharded through the library's communicator - otherwise all of them (the others exit at once). */
+int zf_solver_launch_counts(zf_solver* s, int64_t* out, int64_t count /* >= 2 */);
 /* the same window split by the shape of the pass, which the kernel logs itself: out[0], out[1] = mean
  * ms and count of full chains (sub_iters fresh trials, nothing replayed); out[2], out[3] = every other
  * pass (shorter chains, replays, materialise-only).  Resets the window. */

@@ -312,3 +312,79 @@ def test_kernel_timing_of_a_row_sharded_solver_with_thread_ranks():
     (fm, fn), (pm, pn) = run.solver.pass_stats()
     assert fn + pn >= 12 and fm > 0.0   # (S = 1: every trial is a "full chain" of one)
     run.solver.close()
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_a_sharded_pass_launches_only_the_kernel_of_its_shape(world):
+    """A chained pass has four shape-specific kernels and needs one.  Once a poll has shown the host the control
+    block it launches only the one it expects - through the library's communicator too: every rank predicts from the
+    same control block, the packs carry a stamp of the state they were computed from (zf_pack_stamp) and the decide
+    step ignores gathered packs of any other state.  Checked here: the launch counts, and bitwise agreement with
+    the solve that launches every kernel every time (ZF_SPECULATE=0)."""
+    import threading
+
+    import torch
+
+    from oracle import problems_ref as P
+    from zfista_amd import _lib
+    from zfista_amd.comm import LibComm
+    from zfista_amd.problems import DiagQuadL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    n, K = 3 * 40000 + 17, 16 * 3 + 20   # three full chains, then a shared tail of 10 + 10 (no rejections yet)
+    d, c, lam = P.make_pdiag(n, seed=3)
+    opts = dict(lr=0.45, tol=0.0, tol_internal=1e-12, max_iter=K, max_backtrack_iter=100, decay_rate=0.5,
+                nesterov=True, nesterov_ratio=(0, 0.25), deprecated=False, sub_iters=16)
+    dd, cc = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    x0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+
+    def solve(prob, x0, chunk):
+        run = NativeRun(prob, x0, opts)
+        counts, rows = [], []
+        while run.status == _lib.ZF_RUNNING:
+            rows.append(run.advance(chunk))
+            counts.append(run.solver.launch_counts())
+        x = run.solver.get_x()
+        nit = int(run.solver.ctl.nit)
+        run.solver.close()
+        return np.concatenate(rows), x, nit, counts
+
+    def sharded(chunk):
+        comms = LibComm.local_group(world, cap_doubles=4096) if world > 1 else [LibComm(0, 1, LibComm.new_unique_id())]
+        out, errs = [None] * world, []
+
+        def rank_main(r):
+            try:
+                lo, hi = r * n // world, (r + 1) * n // world
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    out[r] = solve(DiagQuadL1(dd[lo:hi].clone(), cc[lo:hi].clone(), lam, group=comms[r]), x0[lo:hi].clone(), chunk)
+                    torch.cuda.current_stream().synchronize()
+            except Exception as exc:   # pragma: no cover - reported below
+                errs.append(exc)
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errs, errs
+        assert all(o is not None for o in out), "a rank thread did not finish"
+        for c_ in comms:
+            c_.close()
+        return out
+
+    os.environ["ZF_SPECULATE"] = "0"   # (read when a solver is created)
+    try:
+        everything = sharded(2)    # every kernel of every pass
+    finally:
+        del os.environ["ZF_SPECULATE"]
+    for rows, x, nit, counts in everything:
+        assert nit == K and counts[-1] == (6, 24), counts
+    by_chunk = sharded(2)          # polled every two passes
+    for r, (rows, x, nit, counts) in enumerate(by_chunk):
+        assert nit == K
+        assert np.array_equal(rows, everything[r][0]) and np.array_equal(x, everything[r][1])
+        # 3 full chains + 10 + 10 = 5 passes in 3 chunks of 2 steps: one kernel each; the 6th step finds the solve
+        # finished, as the host expected - then it launches every shape, in case the device is NOT finished
+        assert np.all(rows[:, _lib.TR_TRIALS] == 1), "the test wants a solve without rejections"
+        assert counts[-1] == (6, 5 + 4), counts

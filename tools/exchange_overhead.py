@@ -26,7 +26,7 @@ from zfista_amd.proximal_gradient import NativeRun  # noqa: E402
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**8
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-K = 16 * passes
+K = 16 * (passes + 1)   # (+ 1: an untimed first pass and poll, after which the host launches one kernel per pass)
 o = dict(lr=LR, tol=0.0, tol_internal=1e-12, max_iter=K, max_backtrack_iter=100, decay_rate=0.5, nesterov=True,
          nesterov_ratio=(0, 0.25), deprecated=False)
 
@@ -35,6 +35,7 @@ def solve(prob, x0, sync, reps=12):
     best = 1e9
     for _ in range(reps):
         run = NativeRun(prob, x0, o)
+        run.advance(1)
         sync()
         t0 = time.perf_counter()
         run.enqueue_only(passes)

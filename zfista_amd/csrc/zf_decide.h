@@ -93,6 +93,15 @@ ZF_HD inline int zf_fresh_len(const zf_control* c) {
     return (int)n;
 }
 
+// Stamp of the control-block state a pass was computed from, carried in spare slot 6 of its packs (never 0, the
+// value every other producer of packs writes there).  Every decide step changes it: fresh trials raise
+// total_trials, a materialise-only step clears lag and pend_status.  The control block is identical on all ranks,
+// so the decide step of a sharded solve can tell packs of THIS step from packs an earlier step left behind when the
+// one kernel launched for the predicted shape of the pass was not the one the pass needed (zf_predict_parts).
+ZF_HD inline double zf_pack_stamp(const zf_control* c) {
+    return (double)(((c->total_trials + 1) << 6) | ((int64_t)(c->lag & 31) << 1) | (c->pend_status != 0 ? 1 : 0));
+}
+
 // The floating-point part of one trial: model value, F(x+) and the acceptance test for a given
 // F_old and step size (:149-155, :295, :298-303).  Pure: trials of a chain can be evaluated
 // independently (lane-parallel on the device) once F_old of trial j is taken as F(x+) of trial

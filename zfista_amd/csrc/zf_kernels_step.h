@@ -493,7 +493,7 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     pk[ZF_PK_GX] = A.fin_scale_g * q[3];
     pk[ZF_PK_FX] = A.fin_scale_f * q[4];
     pk[ZF_PK_ERR] = q[5];
-    pk[6] = 0.0;
+    pk[6] = A.decide ? 0.0 : zf_pack_stamp(A.ctl_rw);   // sharded x: zf_decide_kernel checks whose packs it was given
     pk[7] = 0.0;
     if (t % LSTR == 0) {
 #pragma unroll

@@ -43,11 +43,22 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_sum_parts_kernel(const zf_control
 
 // sharded x: packs = world x sub x ZF_PACK_LEN (rank-major).  The sub-iterations of a pass are
 // examined in order; the first rejection / termination discards the speculative rest.
+// stamped != 0 (separable problems): every rank's packs carry zf_pack_stamp of the control block their pass read.
+// A step whose predicted shape kernel did not match (zf_predict_parts) produced none: the gathered packs are those of
+// an earlier step, and this decide step must leave the control block alone - the host finds it unchanged at its next
+// poll and launches every shape again.  All ranks hold the same control block and see the same gathered packs, so
+// all of them skip together.
 __global__ __launch_bounds__(64) void zf_decide_kernel(zf_control* ctl, const double* packs, double* trace,
-                                                       const double* beta_ring, int sub) {
+                                                       const double* beta_ring, int sub, int stamped) {
     __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
     if (blockIdx.x != 0) return;
     const int lane = threadIdx.x;
+    if (stamped != 0) {
+        const double want = zf_pack_stamp(ctl);
+        const int world = ctl->world;
+        for (int r = 0; r < world; ++r)
+            if (packs[(int64_t)r * sub * ZF_PACK_LEN + 6] != want) return;
+    }
     double pk[ZF_PACK_LEN] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (lane < sub) zf_reduce_packs(packs + lane * ZF_PACK_LEN, ctl->world, sub * ZF_PACK_LEN, pk);   // rank order
     zf_decide_pass_wave(ctl, packs, pk, trace, beta_ring, lane, 1, s_pre);
@@ -177,6 +188,8 @@ struct zf_solver {
     // block of its last poll (zf_predict_parts) and launches only that one.  A wrong prediction costs passes that
     // do nothing (no kernel finds its shape, the control block stays as it is), never a wrong result.
     int part_mask = 15;
+    bool speculate = true;                // ZF_SPECULATE=0 at creation: always launch every shape
+    int64_t steps_issued = 0, kernels_issued = 0;   // trial steps and the shape kernels launched for them (zf_solver_launch_counts)
     int pass_seq = 0;                     // step counter (zf_step_args.pass_seq)
     zf_control shadow;                    // the control block as the host expects it after the passes enqueued so far
     bool shadow_valid = false;            // false until the next poll (after init / restore / flush / set_max_iter ...)
@@ -229,6 +242,7 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     if (!s) return zf_fail(ZF_ERR_ARG, "zf_solver_create: out of host memory");
     s->desc = *desc;
     s->opt = *opt;
+    if (const char* e = getenv("ZF_SPECULATE")) s->speculate = atoi(e) != 0;
     s->stream = reinterpret_cast<hipStream_t>(stream);
     s->box = !(desc->box_lo == -INFINITY && desc->box_hi == INFINITY);
     const int64_t n = desc->n;
@@ -466,14 +480,21 @@ static void zf_fin_groups(int grid, int* gsz, int* ng) {
     *ng = (grid + *gsz - 1) / *gsz;
 }
 
+static bool zf_fin_kernel_mode() {
+    static const bool on = [] { const char* e = getenv("ZF_FIN_KERNEL"); return e && atoi(e) != 0; }();
+    return on;
+}
+
 // The kernels of the next pass (bit p = PART p of zf_trial_kernel), and the shadow control block moved past that pass
 // on the assumption that every fresh trial is accepted and nothing terminates but max_iter - true for whole chunks
 // in the regime a line search settles in.  The shape rule is the kernel's own (zf_trial_kernel, zf_fresh_len).
-// All kernels (7) when nothing is known, the last chunk saw a rejection, x is sharded, or ZF_SPECULATE=0.
+// All kernels when nothing is known, the last chunk saw a rejection, the exchange is host-driven, or ZF_SPECULATE=0.
 static int zf_predict_parts(zf_solver* s) {
-    static const bool off = [] { const char* e = getenv("ZF_SPECULATE"); return e && atoi(e) == 0; }();
-    if (off || s->sub <= 1 || !s->shadow_valid || s->careful || s->desc.world != 1 || s->comm ||
-        s->desc.kind != ZF_PROBLEM_DIAG_QUAD_L1)
+    const bool off = !s->speculate;   // (ZF_SPECULATE=0 when the solver was created)
+    // (x sharded: only with the library's communicator, whose decide step checks that every rank's packs are those
+    //  of this step - all ranks predict from identical control blocks; a host-driven exchange launches everything)
+    if (off || s->sub <= 1 || !s->shadow_valid || s->careful || (s->desc.world != 1 && !s->comm) ||
+        s->desc.kind != ZF_PROBLEM_DIAG_QUAD_L1 || zf_fin_kernel_mode())
         return 15;
     zf_control& c = s->shadow;
     if (c.status != ZF_RUNNING) return 15;   // (expected to be finished; if the device is not - a chain broke - any shape may be due)
@@ -524,7 +545,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         a.p1 = d.c;
         // (ZF_FIN_KERNEL=1: the round-2 sequence - plain rows, a separate zf_finalize_kernel launch - for A/B
         //  measurements on one box; its sums are added in another order, so knife-edge decisions may differ)
-        static const bool fin_kernel = [] { const char* e = getenv("ZF_FIN_KERNEL"); return e && atoi(e) != 0; }();
+        const bool fin_kernel = zf_fin_kernel_mode();
         if (!dry && !fin_kernel) {
             // the pass finalises itself (zf_pass_tail): packs, and - unsharded - the decide pass, in the same launch
             a.fin_mode = 1;
@@ -540,7 +561,12 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             s->pass_seq = s->pass_seq >= 0x7ffffff0 ? 1 : s->pass_seq + 1;
             a.pass_seq = s->pass_seq;
         }
-        s->part_mask = (dry || !decide_in_launch) ? 15 : zf_predict_parts(s);
+        s->part_mask = (dry || !(decide_in_launch || s->comm)) ? 15 : zf_predict_parts(s);
+        if (!dry) {
+            const int shapes = s->part_mask & (s->sub >= 16 ? 15 : s->sub > 1 ? 3 : 1);
+            s->steps_issued += 1;
+            s->kernels_issued += __builtin_popcount(shapes);
+        }
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
         zf_launch_trial_t<true>(s, a);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
@@ -860,6 +886,9 @@ extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const doubl
     c.sub_iters = s->sub;
     c.pass_seq = 0;   // (step numbers are this solver's own)
     if (c.status == ZF_MAXITER && c.nit < c.max_iter) c.status = ZF_RUNNING;   // a larger max_iter continues (:539)
+    // (packs of passes from before the restore must not pass for packs of the restored state: zf_pack_stamp)
+    if (s->pack_all)
+        ZF_HIP(hipMemsetAsync(s->pack_all, 0, sizeof(double) * ZF_PACK_LEN * s->sub * d.world, s->stream));
     ZF_HIP(hipMemcpyAsync(s->ctl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));   // `c` is a stack object
     if (d.kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
@@ -946,8 +975,10 @@ extern "C" int zf_solver_enqueue_trial(zf_solver* s) {
 
 extern "C" int zf_solver_enqueue_decide(zf_solver* s) {
     ZF_REQUIRE(s && s->initialised, "zf_solver_enqueue_decide: solver not initialised");
+    // (separable problems finalise in the trial launch and stamp their packs: zf_pack_stamp)
+    const int stamped = (s->desc.kind == ZF_PROBLEM_DIAG_QUAD_L1 && !zf_fin_kernel_mode()) ? 1 : 0;
     hipLaunchKernelGGL(zf_decide_kernel, dim3(1), dim3(64), 0, s->stream, s->ctl, s->pack_all, s->trace,
-                       s->beta_ring, s->sub);
+                       s->beta_ring, s->sub, stamped);
     ZF_HIP(hipGetLastError());
     return ZF_OK;
 }
@@ -968,6 +999,14 @@ extern "C" int zf_solver_set_history(zf_solver* s, double* hist_dev, int64_t cap
     s->hist = hist_dev;
     s->hist_cap = cap_slots;
     s->hist_stride = stride;
+    return ZF_OK;
+}
+
+extern "C" int zf_solver_launch_counts(zf_solver* s, int64_t* out, int64_t count) {
+    ZF_REQUIRE(s && out, "zf_solver_launch_counts: null argument");
+    ZF_REQUIRE(count >= 2, "zf_solver_launch_counts: the output holds fewer than 2 values");
+    out[0] = s->steps_issued;
+    out[1] = s->kernels_issued;
     return ZF_OK;
 }
 

@@ -266,6 +266,12 @@ class DeviceSolver:
         _lib.check(self.lib.zf_solver_pass_stats(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
         return (out[0], int(out[1])), (out[2], int(out[3]))
 
+    def launch_counts(self):
+        """(trial steps issued, shape-specific trial kernels launched for them) since the solver was created."""
+        out = np.zeros(2, dtype=np.int64)
+        _lib.check(self.lib.zf_solver_launch_counts(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
+        return int(out[0]), int(out[1])
+
     def pass_stats_ex(self):
         """pass_stats() plus (fresh trials, replayed iterations) the other passes carried in total."""
         out = np.zeros(6)
