@@ -36,7 +36,7 @@ for sub in ("fetch", "write", "clock"):
     per_dispatch = collections.defaultdict(dict)
     for r in rows(sub):
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        if dur < 100_000:
+        if dur < max(20_000, n // 1000):
             continue   # a launch that found another shape (or the solve finished) and exited
         key = (part_of(r["Kernel_Name"]), r["Dispatch_Id"])
         per_dispatch[key][r["Counter_Name"]] = float(r["Counter_Value"])

@@ -7,7 +7,8 @@
 Reads DIR/**/*kernel_trace.csv, orders the launches by start time and prints one JSON object: per kernel
 class (trial kernel busy / idle, finalize, decide, everything else) the launches, mean duration and mean
 GAP in front of it (end of the previous kernel -> its start), and the accounting of the span between the
-first and the last busy trial launch: kernel time by class, idle gaps, span per busy pass."""
+first and the last busy trial launch: kernel time by class, idle gaps, span per busy pass; and the time between
+consecutive busy passes of one solve (end of one trial kernel -> start of the next, everything in between included)."""
 import csv
 import glob
 import json
@@ -66,6 +67,21 @@ for c, a in sorted(acc.items()):
                          "mean_gap_before_us": a["gap_ns"] / a["launches"] / 1e3}
     out["kernel_us_per_pass"][c] = a["dur_ns"] / passes / 1e3
     out["gap_us_per_pass"][c] = a["gap_ns"] / passes / 1e3
+# inside a solve: what lies between two consecutive busy passes with nothing but the solver's own small kernels
+# (idle shape kernels, refresh-beta, set-max-iter) between them - no re-initialisation, no foreign kernels
+inner, prev_busy_end, clean = [], None, True
+for s_, e_, n_ in rows[lo:hi + 1]:
+    c = cls(n_, e_ - s_)
+    if c == "trial_busy":
+        if prev_busy_end is not None and clean:
+            inner.append((s_ - prev_busy_end) / 1e3)
+        prev_busy_end, clean = e_, True
+    elif c in ("other", "zf_init", "zf_eval_kernel"):
+        clean = False
+if inner:
+    inner.sort()
+    out["between_consecutive_busy_passes_us"] = {"pairs": len(inner), "median": inner[len(inner) // 2],
+                                                 "p10": inner[len(inner) // 10], "p90": inner[len(inner) * 9 // 10]}
 out["kernel_us_per_pass_total"] = sum(out["kernel_us_per_pass"].values())
 out["gap_us_per_pass_total"] = sum(out["gap_us_per_pass"].values())
 print(json.dumps(out, indent=1))
