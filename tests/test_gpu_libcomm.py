@@ -95,6 +95,54 @@ def test_two_rank_rccl_communicator_in_the_library(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
 
 
+_FROM_GROUP = r"""
+import os, sys, warnings
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["ZF_ROOT"])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from zfista_amd.comm import LibComm
+expect_comm = os.environ.get("ZF_RCCL_LIB") is None
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    comm = LibComm.from_group(None)
+    again = LibComm.from_group(None)          # cached verdict, no second collective round
+assert again is comm
+if expect_comm:
+    assert comm is not None and (comm.rank, comm.world) == (0, 1) and not w
+    a = torch.arange(8, dtype=torch.float64, device="cuda")
+    b = torch.zeros(8, dtype=torch.float64, device="cuda")
+    comm.all_gather(a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+else:
+    assert comm is None and len(w) == 1 and "torch.distributed all-gathers" in str(w[0].message), [str(x.message) for x in w]
+dist.barrier(); dist.destroy_process_group()
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("rccl", ["present", "missing"])
+def test_communicator_from_an_nccl_process_group_is_all_or_nothing(tmp_path, rccl):
+    """`LibComm.from_group` on a (1-rank) nccl process group: unique id by object broadcast, ncclCommInitRank, and an
+    all-reduce of "did every rank get one".  With a librccl that cannot be loaded (ZF_RCCL_LIB names a file that does
+    not exist) every rank gets None and a RuntimeWarning - the callers then exchange through torch.distributed -
+    instead of an exception on some ranks and a hang on the others."""
+    import socket
+
+    script = tmp_path / "from_group.py"
+    script.write_text(_FROM_GROUP)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ZF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.pop("ZF_RCCL_LIB", None)
+    if rccl == "missing":
+        env["ZF_RCCL_LIB"] = str(tmp_path / "no_such_librccl.so")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("kind", ["diag", "diag_backtrack_history", "lasso", "lasso_rows"])
 def test_library_multi_rank_step_sequence_with_thread_ranks(kind, world):

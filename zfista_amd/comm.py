@@ -68,11 +68,39 @@ class LibComm:
         key = (id(pg), rank, world)
         hit = _CACHE.get(key)
         if hit is not None and hit[1] is pg:
-            return hit[0]
-        box = [cls.new_unique_id() if rank == 0 else None]
+            return hit[0]   # (None: the group has no library communicator - decided once, by all ranks)
+        err, uid = None, None
+        if rank == 0:
+            try:
+                uid = cls.new_unique_id()
+            except Exception as exc:   # noqa: BLE001 - the other ranks wait in the broadcast below: tell them
+                err = exc
+        box = [uid]
         src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
         dist.broadcast_object_list(box, src=src, group=group)
-        comm = cls(rank, world, box[0])
+        # ncclCommInitRank is collective; so is the verdict on it: if any rank could not create its communicator
+        # (librccl not loadable, an init error) EVERY rank gives its own up and the caller's exchanges go through
+        # torch.distributed on all ranks alike - never one rank on one sequence and the rest on the other
+        import torch
+
+        comm = None
+        if box[0] is not None:
+            try:
+                comm = cls(rank, world, box[0])
+            except Exception as exc:   # noqa: BLE001 - reported below, on every rank
+                err = exc
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+                comm = None
+            import warnings
+
+            warnings.warn("zfista_amd: the library's RCCL communicator could not be created on every rank"
+                          + (f" (this rank: {err})" if err is not None else "")
+                          + "; all ranks use torch.distributed all-gathers for the per-pass exchange", RuntimeWarning,
+                          stacklevel=2)
         _CACHE[key] = (comm, pg)
         return comm
 

@@ -39,11 +39,17 @@ char g_rccl_err[256] = "";
 
 // (once per process, whatever thread gets here first: rank threads of a local group may race to it)
 void rccl_load_once() {
+    // ZF_RCCL_LIB names the one library to use (a pinned RCCL build; tests: a path that does not exist)
+    const char* pinned = getenv("ZF_RCCL_LIB");
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
-    for (const char* n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+    if (pinned && *pinned) {
+        h = dlopen(pinned, RTLD_NOW | RTLD_GLOBAL);
+    } else {
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
     }
     if (!h) {
         snprintf(g_rccl_err, sizeof(g_rccl_err), "zf_comm: cannot load librccl (%s)", dlerror());

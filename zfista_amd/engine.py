@@ -115,9 +115,10 @@ class DeviceSolver:
             except (RuntimeError, ValueError, TypeError, AttributeError):
                 is_nccl = False
             if is_nccl:
-                # collective (an object broadcast + ncclCommInitRank): a failure must surface on the rank it happens
-                # on - swallowing it would leave this rank on the torch.distributed sequence while the others
-                # issue RCCL all-gathers inside zf_solver_enqueue_steps: a hang instead of an error
+                # collective (an object broadcast + ncclCommInitRank + an all-reduce of "did it work"): either every
+                # rank gets a communicator or none does (None: the torch.distributed sequence below, with a warning) -
+                # one rank on one sequence and the others issuing RCCL all-gathers inside zf_solver_enqueue_steps
+                # would be a hang
                 self.comm = LibComm.from_group(group)
         if self.comm is not None:
             _lib.check(self.lib.zf_solver_set_comm(self.handle, self.comm.handle), "zf_solver_set_comm")
