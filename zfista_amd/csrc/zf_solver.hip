@@ -7,6 +7,7 @@
 // buffer rotation happen in a one-workgroup decide kernel, so there is no host
 // round trip inside a chunk of steps.
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <new>
@@ -143,8 +144,10 @@ struct zf_solver {
     unsigned* fin_cnt = nullptr;  // arrival counters: of the finalize workgroups / of the in-kernel finalisation (zf_pass_tail)
     double* grp_part = nullptr;   // ZF_NPART x S x ZF_FIN_GROUPS group rows of the in-kernel finalisation
     bool nt = true;               // nontemporal policy for once-touched streams
-    zf_control* ctl = nullptr;
-    double* trace = nullptr;      // ZF_RING * ZF_TRACE_COLS
+    char* ctl_trace = nullptr;    // one allocation: the control block (ZF_CTL_SLOT bytes) and the trace ring behind it
+    char* mail = nullptr;         // pinned host mirror of ctl_trace: what a poll copies into
+    zf_control* ctl = nullptr;    // = ctl_trace
+    double* trace = nullptr;      // = ctl_trace + ZF_CTL_SLOT: ZF_RING * ZF_TRACE_COLS
     double* beta_ring = nullptr;  // ZF_RING
     double* pack_local = nullptr; // ZF_PACK_LEN
     double* pack_all = nullptr;   // world * ZF_PACK_LEN
@@ -200,14 +203,16 @@ struct zf_solver {
     int64_t hist_cap = 0, hist_stride = 0;
 };
 constexpr int ZF_PASS_LOG = 4096;
+constexpr size_t ZF_CTL_SLOT = (sizeof(zf_control) + 255) / 256 * 256;   // bytes in front of the trace ring (zf_solver::ctl_trace)
 
 static int zf_solver_free_all(zf_solver* s) {
-    void* ptrs[] = {s->row_part, s->ls_cnt, s->pass_log, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->xbuf, s->partials, s->ctl, s->trace, s->beta_ring,
+    void* ptrs[] = {s->row_part, s->ls_cnt, s->pass_log, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
                     s->own_svec ? s->s_part : nullptr, s->own_svec ? s->s_all : nullptr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->mail) (void)hipHostFree(s->mail);
     for (auto& e : s->ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -291,8 +296,12 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     ZF_TRY(hipMalloc(&s->fin_cnt, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2)));
     ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2), s->stream));
     ZF_TRY(hipMalloc(&s->grp_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_GROUPS));
-    ZF_TRY(hipMalloc(&s->ctl, sizeof(zf_control)));
-    ZF_TRY(hipMalloc(&s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS));
+    // the control block and the trace ring side by side, and a pinned host mirror of both: a poll is ONE DMA into
+    // pinned memory (two copies into the caller's pageable arrays cost 34 us on an idle stream, this costs a third)
+    ZF_TRY(hipMalloc(&s->ctl_trace, ZF_CTL_SLOT + sizeof(double) * ZF_RING * ZF_TRACE_COLS));
+    s->ctl = reinterpret_cast<zf_control*>(s->ctl_trace);
+    s->trace = reinterpret_cast<double*>(s->ctl_trace + ZF_CTL_SLOT);
+    ZF_TRY(hipHostMalloc(&s->mail, ZF_CTL_SLOT + sizeof(double) * ZF_RING * ZF_TRACE_COLS, hipHostMallocDefault));
     ZF_TRY(hipMalloc(&s->beta_ring, sizeof(double) * ZF_RING));
     ZF_TRY(hipMalloc(&s->pack_local, sizeof(double) * ZF_PACK_LEN * s->sub));
     ZF_TRY(hipMalloc(&s->pack_all, sizeof(double) * ZF_PACK_LEN * s->sub * desc->world));
@@ -1216,11 +1225,12 @@ extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_by
                "zf_solver_poll: ctl_bytes is smaller than zf_sizeof_control() (host built against another ABI version?)");
     ZF_REQUIRE(!trace_host || trace_bytes >= (int64_t)(sizeof(double) * ZF_RING * ZF_TRACE_COLS),
                "zf_solver_poll: trace_bytes is smaller than ZF_RING * ZF_TRACE_COLS doubles");
-    ZF_HIP(hipMemcpyAsync(ctl_host, s->ctl, sizeof(zf_control), hipMemcpyDeviceToHost, s->stream));
-    if (trace_host)
-        ZF_HIP(hipMemcpyAsync(trace_host, s->trace, sizeof(double) * ZF_RING * ZF_TRACE_COLS,
-                              hipMemcpyDeviceToHost, s->stream));
+    const size_t trace_len = sizeof(double) * ZF_RING * ZF_TRACE_COLS;
+    ZF_HIP(hipMemcpyAsync(s->mail, s->ctl_trace, trace_host ? ZF_CTL_SLOT + trace_len : sizeof(zf_control),
+                          hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
+    memcpy(ctl_host, s->mail, sizeof(zf_control));
+    if (trace_host) memcpy(trace_host, s->mail + ZF_CTL_SLOT, trace_len);
     {   // what the host now knows about the device: the basis of the next chunk's predictions
         const int64_t rej = ctl_host->total_trials - ctl_host->nit;
         s->careful = s->shadow_valid ? (rej != s->polled_rejections) : (rej != 0);
