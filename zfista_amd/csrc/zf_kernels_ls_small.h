@@ -45,6 +45,7 @@ struct zf_ls_small_args {
     int64_t hist_cap, hist_stride;
     int* pass_log;         // timing only (else NULL): slot pass_slot receives 1 when the step kernel ran a trial
     int pass_slot;
+    int pass_tag;          // (launch number & 0x7fff) << 16
 };
 
 template <bool NESTEROV, bool BOX>
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_ls_small_step_kernel(zf_ls_small_
     const zf_control* ctl = P.ctl;
     if (ctl->status != ZF_RUNNING) return;
     const int tid = threadIdx.x;
-    if (P.pass_log && blockIdx.x == 0 && tid == 0) P.pass_log[P.pass_slot] = 1;   // (one trial, nothing replayed)
+    if (P.pass_log && blockIdx.x == 0 && tid == 0) P.pass_log[P.pass_slot] = P.pass_tag | 1;   // (one trial, nothing replayed)
     const int cur = ctl->cur, prev = ctl->prev;
     const double beta = NESTEROV ? ctl->beta_next : 0.0;
     const double lr = ctl->lr;

@@ -225,8 +225,9 @@ struct zf_step_args {
     int64_t n;
     int tiles_per_wg;         // interleaved tiles per workgroup (1 .. ZF_MAX_TILES_PER_WG)
     double* blk_part;         // (S * ZF_NPART) x gridDim.x per-workgroup partials, quantity-major
-    int* pass_log;            // timing only (else NULL): slot pass_slot receives (lag << 8) | fresh trials
+    int* pass_log;            // timing only (else NULL): slot pass_slot receives pass_tag | (lag << 8) | fresh trials
     int pass_slot;
+    int pass_tag;             // (launch number & 0x7fff) << 16: tells this launch's entry from one an earlier launch left in the slot
     double* hist;             // HIST kernels: ring of hist_cap iterates (n doubles each); the iterate of
     int64_t hist_cap;         //   iteration k goes to slot k % hist_cap, written by the trial that computes it
     int64_t hist_stride;      // doubles between slots (>= n, 512-B aligned)
@@ -923,13 +924,13 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     // rings are sized by that)
     if (A.fin_mode != 0 && A.decide && A.ctl->pass_seq == A.pass_seq) return;
     if constexpr (S == 1) {
-        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = 1;
+        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | 1;
         zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, 1);
     } else {
         const int lag = A.ctl->lag;
         const int nf = zf_fresh_len(A.ctl);   // fresh trials of this chain (0: materialise only)
         if (zf_pass_part(S, lag, nf) != PART) return;
-        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = (lag << 8) | nf;
+        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | (lag << 8) | nf;
         if constexpr (PART == 0) {
             zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, S, stage);
         } else if constexpr (PART == 3) {

@@ -179,8 +179,7 @@ struct zf_solver {
     double ms_total = 0.0;
     int64_t ms_count = 0;
     // the shape of every timed pass, written by the kernel itself (the host cannot know it at launch)
-    int* pass_log = nullptr;              // ZF_PASS_LOG slots (device)
-    std::vector<int> pass_log_host;
+    int* pass_log = nullptr;              // ZF_PASS_LOG slots (device; inside ctl_trace, behind the trace ring)
     int64_t launches = 0;                 // timed launches so far (slot = launches % ZF_PASS_LOG)
     int64_t first_uncollected = 0;
     double ms_full = 0.0, ms_part = 0.0;  // S-trial chains without replay / everything else
@@ -204,9 +203,11 @@ struct zf_solver {
 };
 constexpr int ZF_PASS_LOG = 4096;
 constexpr size_t ZF_CTL_SLOT = (sizeof(zf_control) + 255) / 256 * 256;   // bytes in front of the trace ring (zf_solver::ctl_trace)
+constexpr size_t ZF_TRACE_BYTES = sizeof(double) * ZF_RING * ZF_TRACE_COLS;
+constexpr size_t ZF_MAIL_BYTES = ZF_CTL_SLOT + ZF_TRACE_BYTES + sizeof(int) * ZF_PASS_LOG;
 
 static int zf_solver_free_all(zf_solver* s) {
-    void* ptrs[] = {s->row_part, s->ls_cnt, s->pass_log, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
+    void* ptrs[] = {s->row_part, s->ls_cnt, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
                     s->own_svec ? s->s_part : nullptr, s->own_svec ? s->s_all : nullptr};
@@ -298,10 +299,13 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     ZF_TRY(hipMalloc(&s->grp_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_GROUPS));
     // the control block and the trace ring side by side, and a pinned host mirror of both: a poll is ONE DMA into
     // pinned memory (two copies into the caller's pageable arrays cost 34 us on an idle stream, this costs a third)
-    ZF_TRY(hipMalloc(&s->ctl_trace, ZF_CTL_SLOT + sizeof(double) * ZF_RING * ZF_TRACE_COLS));
+    //  - and, behind them, the log of pass shapes the kernels keep when timing is on)
+    ZF_TRY(hipMalloc(&s->ctl_trace, ZF_MAIL_BYTES));
     s->ctl = reinterpret_cast<zf_control*>(s->ctl_trace);
     s->trace = reinterpret_cast<double*>(s->ctl_trace + ZF_CTL_SLOT);
-    ZF_TRY(hipHostMalloc(&s->mail, ZF_CTL_SLOT + sizeof(double) * ZF_RING * ZF_TRACE_COLS, hipHostMallocDefault));
+    s->pass_log = reinterpret_cast<int*>(s->ctl_trace + ZF_CTL_SLOT + ZF_TRACE_BYTES);
+    ZF_TRY(hipMemsetAsync(s->pass_log, 0xff, sizeof(int) * ZF_PASS_LOG, s->stream));   // (no launch carries tag 0x7fff + negative sign)
+    ZF_TRY(hipHostMalloc(&s->mail, ZF_MAIL_BYTES, hipHostMallocDefault));
     ZF_TRY(hipMalloc(&s->beta_ring, sizeof(double) * ZF_RING));
     ZF_TRY(hipMalloc(&s->pack_local, sizeof(double) * ZF_PACK_LEN * s->sub));
     ZF_TRY(hipMalloc(&s->pack_all, sizeof(double) * ZF_PACK_LEN * s->sub * desc->world));
@@ -469,6 +473,7 @@ static void zf_fill_step_args(const zf_solver* s, zf_step_args& a) {
     a.tiles_per_wg = s->tiles;
     a.blk_part = s->blk_part;
     a.pass_log = nullptr;
+    a.pass_tag = 0;
     a.pass_slot = 0;
     a.hist = s->hist;
     a.hist_cap = s->hist_cap > 0 ? s->hist_cap : 1;
@@ -529,13 +534,9 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
     zf_fill_step_args(s, a);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing && !dry) {
-        if (!s->pass_log) {
-            ZF_HIP(hipMalloc(&s->pass_log, sizeof(int) * ZF_PASS_LOG));
-            ZF_HIP(hipMemsetAsync(s->pass_log, 0xff, sizeof(int) * ZF_PASS_LOG, s->stream));
-            s->pass_log_host.assign(ZF_PASS_LOG, -1);
-        }
         a.pass_log = s->pass_log;
         a.pass_slot = (int)(s->launches % ZF_PASS_LOG);
+        a.pass_tag = (int)(s->launches & 0x7fff) << 16;
         s->launches += 1;
     }
     if (s->timing) {
@@ -608,6 +609,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         P.hist_stride = s->hist_stride;
         P.pass_log = a.pass_log;
         P.pass_slot = a.pass_slot;
+        P.pass_tag = a.pass_tag;
         const bool nest = s->opt.nesterov != 0;
         dim3 gs(P.grid_step), gr((unsigned)((d.m_rows + ZF_WAVES - 1) / ZF_WAVES)), b(ZF_BLOCK);
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
@@ -1185,19 +1187,27 @@ extern "C" int zf_solver_set_pack_buffers(zf_solver* s, double* pack_local_dev, 
     return ZF_OK;
 }
 
-static int zf_collect_timing(zf_solver* s) {
-    const bool have_log = s->pass_log && s->ev_used > 0 && s->ev_used <= (size_t)ZF_PASS_LOG &&
+// log_in_mail: the caller (a poll) has just copied the log into the pinned mirror, with the control block and the trace
+static int zf_collect_timing(zf_solver* s, bool log_in_mail = false) {
+    if (!log_in_mail && s->ev_used > 0) {
+        const size_t off = ZF_CTL_SLOT + ZF_TRACE_BYTES;
+        ZF_HIP(hipMemcpyAsync(s->mail + off, s->ctl_trace + off, sizeof(int) * ZF_PASS_LOG, hipMemcpyDeviceToHost, s->stream));
+        ZF_HIP(hipStreamSynchronize(s->stream));
+    }
+    const bool have_log = s->ev_used > 0 && s->ev_used <= (size_t)ZF_PASS_LOG &&
                           s->launches - s->first_uncollected == (int64_t)s->ev_used;
-    if (have_log)
-        ZF_HIP(hipMemcpy(s->pass_log_host.data(), s->pass_log, sizeof(int) * ZF_PASS_LOG, hipMemcpyDeviceToHost));
+    const int* log = reinterpret_cast<const int*>(s->mail + ZF_CTL_SLOT + ZF_TRACE_BYTES);
     for (size_t k = 0; k < s->ev_used; ++k) {
         float ms = 0.f;
         ZF_HIP(hipEventElapsedTime(&ms, s->ev_pool[k].first, s->ev_pool[k].second));
         s->ms_total += ms;
         s->ms_count += 1;
         if (have_log) {
-            const int shape = s->pass_log_host[(s->first_uncollected + (int64_t)k) % ZF_PASS_LOG];
-            if (shape < 0) continue;   // the launch found the solve finished and exited
+            const int64_t launch = s->first_uncollected + (int64_t)k;
+            const int entry = log[launch % ZF_PASS_LOG];
+            // the launch found the solve finished and exited: the slot still holds what an earlier launch wrote
+            if (entry < 0 || (entry >> 16) != (int)(launch & 0x7fff)) continue;
+            const int shape = entry & 0xffff;
             if ((shape >> 8) == 0 && (shape & 0xff) == s->sub) {
                 s->ms_full += ms;
                 s->n_full += 1;
@@ -1208,9 +1218,6 @@ static int zf_collect_timing(zf_solver* s) {
                 s->lag_part += shape >> 8;
             }
         }
-    }
-    if (have_log) {   // re-arm the slots just read
-        ZF_HIP(hipMemsetAsync(s->pass_log, 0xff, sizeof(int) * ZF_PASS_LOG, s->stream));
     }
     s->first_uncollected = s->launches;
     s->ev_used = 0;
@@ -1225,9 +1232,10 @@ extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_by
                "zf_solver_poll: ctl_bytes is smaller than zf_sizeof_control() (host built against another ABI version?)");
     ZF_REQUIRE(!trace_host || trace_bytes >= (int64_t)(sizeof(double) * ZF_RING * ZF_TRACE_COLS),
                "zf_solver_poll: trace_bytes is smaller than ZF_RING * ZF_TRACE_COLS doubles");
-    const size_t trace_len = sizeof(double) * ZF_RING * ZF_TRACE_COLS;
-    ZF_HIP(hipMemcpyAsync(s->mail, s->ctl_trace, trace_host ? ZF_CTL_SLOT + trace_len : sizeof(zf_control),
-                          hipMemcpyDeviceToHost, s->stream));
+    const size_t trace_len = ZF_TRACE_BYTES;
+    const bool with_log = s->ev_used > 0;   // (events were recorded: the kernels logged their pass shapes)
+    const size_t want = with_log ? ZF_MAIL_BYTES : trace_host ? ZF_CTL_SLOT + trace_len : sizeof(zf_control);
+    ZF_HIP(hipMemcpyAsync(s->mail, s->ctl_trace, want, hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
     memcpy(ctl_host, s->mail, sizeof(zf_control));
     if (trace_host) memcpy(trace_host, s->mail + ZF_CTL_SLOT, trace_len);
@@ -1238,7 +1246,7 @@ extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_by
         s->shadow = *ctl_host;
         s->shadow_valid = true;
     }
-    return zf_collect_timing(s);
+    return zf_collect_timing(s, with_log);
 }
 
 extern "C" int zf_solver_x_dev(zf_solver* s, const double** x_dev) {
