@@ -436,3 +436,78 @@ def test_a_sharded_pass_launches_only_the_kernel_of_its_shape(world):
         # finished, as the host expected - then it launches every shape, in case the device is NOT finished
         assert np.all(rows[:, _lib.TR_TRIALS] == 1), "the test wants a solve without rejections"
         assert counts[-1] == (6, 5 + 4), counts
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_after_rejections_a_pass_launches_the_two_shapes_it_can_need(world):
+    """Once a poll has seen rejections the host no longer knows which shape the next pass has - but far from max_iter
+    it is the full chain or the short / replaying body, so only those two kernels are launched (near max_iter: all).
+    A solve that starts with lr too large (the first line search backtracks) and runs into the noise floor of the
+    acceptance test (rejections from iteration ~60 on at this size), polled every 2 passes, against the same solve
+    with every kernel launched every time (ZF_SPECULATE=0): identical rows and iterates, fewer launches."""
+    import threading
+
+    import torch
+
+    from oracle import problems_ref as P
+    from zfista_amd import _lib
+    from zfista_amd.comm import LibComm
+    from zfista_amd.problems import DiagQuadL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    n, K = 2 * 60000 + 18, 260
+    d, c, lam = P.make_pdiag(n, seed=3)
+    opts = dict(lr=4.0, tol=0.0, tol_internal=1e-12, max_iter=K, max_backtrack_iter=100, decay_rate=0.5,
+                nesterov=True, nesterov_ratio=(0, 0.25), deprecated=False, sub_iters=16)
+    dd, cc = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    x0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+
+    def solve(prob, x0):
+        run = NativeRun(prob, x0, opts)
+        rows = []
+        while run.status == _lib.ZF_RUNNING:
+            rows.append(run.advance(2))
+        x, nit, counts = run.solver.get_x(), int(run.solver.ctl.nit), run.solver.launch_counts()
+        run.solver.close()
+        return np.concatenate(rows), x, nit, counts
+
+    def ranks():
+        comms = LibComm.local_group(world, cap_doubles=4096) if world > 1 else [LibComm(0, 1, LibComm.new_unique_id())]
+        out, errs = [None] * world, []
+
+        def rank_main(r):
+            try:
+                lo, hi = r * n // world, (r + 1) * n // world
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    out[r] = solve(DiagQuadL1(dd[lo:hi].clone(), cc[lo:hi].clone(), lam, group=comms[r]), x0[lo:hi].clone())
+                    torch.cuda.current_stream().synchronize()
+            except Exception as exc:   # pragma: no cover - reported below
+                errs.append(exc)
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errs, errs
+        assert all(o is not None for o in out), "a rank thread did not finish"
+        for c_ in comms:
+            c_.close()
+        return out
+
+    os.environ["ZF_SPECULATE"] = "0"
+    try:
+        everything = ranks()
+    finally:
+        del os.environ["ZF_SPECULATE"]
+    predicted = ranks()
+    for r in range(world):
+        rows_e, x_e, nit_e, (steps_e, kernels_e) = everything[r]
+        rows_p, x_p, nit_p, (steps_p, kernels_p) = predicted[r]
+        assert nit_e == nit_p == K
+        assert np.any(rows_e[:, _lib.TR_TRIALS] > 1), "the test wants rejections"
+        assert np.array_equal(rows_e, rows_p) and np.array_equal(x_e, x_p)
+        assert kernels_e == 4 * steps_e
+        # mispredicted steps are no-ops that cost a step each: a few, and far fewer kernels all the same
+        assert steps_e <= steps_p <= steps_e + 8, (steps_e, steps_p)
+        assert kernels_p <= 0.7 * kernels_e, (kernels_p, kernels_e)

@@ -195,7 +195,8 @@ struct zf_solver {
     int pass_seq = 0;                     // step counter (zf_step_args.pass_seq)
     zf_control shadow;                    // the control block as the host expects it after the passes enqueued so far
     bool shadow_valid = false;            // false until the next poll (after init / restore / flush / set_max_iter ...)
-    bool careful = false;                 // the last chunk saw rejections: launch every kernel of a pass
+    bool careful = false;                 // the last chunk saw rejections: launch every kernel a pass may need
+    int64_t steps_since_poll = 0;         // trial steps issued since the shadow was read
     int64_t polled_rejections = 0;
     // streaming return_all: caller-owned ring of iterates in HBM (zf_solver_set_history)
     double* hist = nullptr;
@@ -502,17 +503,26 @@ static bool zf_fin_kernel_mode() {
 // The kernels of the next pass (bit p = PART p of zf_trial_kernel), and the shadow control block moved past that pass
 // on the assumption that every fresh trial is accepted and nothing terminates but max_iter - true for whole chunks
 // in the regime a line search settles in.  The shape rule is the kernel's own (zf_trial_kernel, zf_fresh_len).
-// All kernels when nothing is known, the last chunk saw a rejection, the exchange is host-driven, or ZF_SPECULATE=0.
+// All kernels when nothing is known, the exchange is host-driven, or ZF_SPECULATE=0; after a chunk that saw a rejection
+// the two a pass can need far from max_iter, all of them near it.
 static int zf_predict_parts(zf_solver* s) {
     const bool off = !s->speculate;   // (ZF_SPECULATE=0 when the solver was created)
     // (x sharded: only with the library's communicator, whose decide step checks that every rank's packs are those
     //  of this step - all ranks predict from identical control blocks; a host-driven exchange launches everything)
-    if (off || s->sub <= 1 || !s->shadow_valid || s->careful || (s->desc.world != 1 && !s->comm) ||
+    if (off || s->sub <= 1 || !s->shadow_valid || (s->desc.world != 1 && !s->comm) ||
         s->desc.kind != ZF_PROBLEM_DIAG_QUAD_L1 || zf_fin_kernel_mode())
         return 15;
     zf_control& c = s->shadow;
     if (c.status != ZF_RUNNING) return 15;   // (expected to be finished; if the device is not - a chain broke - any shape may be due)
     const int S = s->sub;
+    if (s->careful) {
+        // Chains have been breaking: what the device will need is not known - but far from max_iter it is one of
+        // two shapes.  The device has accepted at most S iterations per step since the poll, so at least `left`
+        // remain; with left >= 2 S a pass with nothing lagging is a full chain (zf_fresh_len: PART 0) and a pass
+        // behind lagging iterations, or one that only materialises, has at most S / 2 fresh trials (PART 1).
+        const int64_t left = c.max_iter - c.nit - (int64_t)S * s->steps_since_poll;
+        return left >= 2 * (int64_t)S ? 3 : 15;
+    }
     const int lag = c.lag;
     const int nf = zf_fresh_len(&c);
     const int part = zf_pass_part(S, lag, nf);
@@ -573,6 +583,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         }
         s->part_mask = (dry || !(decide_in_launch || s->comm)) ? 15 : zf_predict_parts(s);
         if (!dry) {
+            s->steps_since_poll += 1;
             const int shapes = s->part_mask & (s->sub >= 16 ? 15 : s->sub > 1 ? 3 : 1);
             s->steps_issued += 1;
             s->kernels_issued += __builtin_popcount(shapes);
@@ -1245,6 +1256,7 @@ extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_by
         s->polled_rejections = rej;
         s->shadow = *ctl_host;
         s->shadow_valid = true;
+        s->steps_since_poll = 0;
     }
     return zf_collect_timing(s, with_log);
 }
