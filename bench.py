@@ -325,10 +325,13 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
             run.set_max_iter(nit0 + K)
             sync_all()
             t0 = time.perf_counter()
+            trials0 = int(run.solver.ctl.total_trials) - run.nit_seen
             while run.status == _lib.ZF_RUNNING:
-                # exactly the passes the remaining iterations need if no chain breaks; a rejected trial
-                # (lr halves, :305) costs further rounds
-                run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S)
+                # the passes the remaining iterations need if no chain breaks; a rejected trial (lr halves, :305)
+                # costs further passes: once this block has seen rejections, two spare passes ride along with every
+                # round (a pass enqueued behind the end of the solve exits at once) instead of a poll round trip each
+                spare = 2 if int(run.solver.ctl.total_trials) - run.nit_seen > trials0 else 0
+                run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S + spare)
                 run.collect()
             sync_all()
             dt = time.perf_counter() - t0

@@ -49,7 +49,9 @@ def run_native(prob, x0, opts, K, W):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     while run.status == _lib.ZF_RUNNING:
-        run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S)
+        # (as bench.py: two spare passes per round once the block has seen rejections)
+        spare = 2 if int(run.solver.ctl.total_trials) - run.nit_seen > trials0 - nit0 else 0
+        run.enqueue_only((K - (run.nit_seen - nit0) + S - 1) // S + spare)
         run.collect()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
