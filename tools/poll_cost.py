@@ -36,5 +36,11 @@ for n in (10**5, 10**7, 10**5):
             best = min(best, time.perf_counter() - t0)
         return best
     r1, r8 = rt(1), rt(8)
-    print(f"n={n:.0e} idle poll {t_poll*1e6:.1f} us, idle synchronize {t_sync*1e6:.1f} us, 1 pass + poll {r1*1e6:.1f} us, 8 passes + poll {r8*1e6:.1f} us -> per pass {(r8-r1)/7*1e6:.1f} us, fixed {(r1-(r8-r1)/7)*1e6:.1f} us")
+    # what the HOST spends enqueuing a pass (returns before the device has run it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run.enqueue_only(16)
+    t_enq = (time.perf_counter() - t0) / 16
+    run.collect()
+    print(f"n={n:.0e} idle poll {t_poll*1e6:.1f} us, idle synchronize {t_sync*1e6:.1f} us, 1 pass + poll {r1*1e6:.1f} us, 8 passes + poll {r8*1e6:.1f} us -> per pass {(r8-r1)/7*1e6:.1f} us, fixed {(r1-(r8-r1)/7)*1e6:.1f} us; host time to enqueue a pass {t_enq*1e6:.1f} us")
     run.solver.close()
