@@ -604,7 +604,13 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     const int64_t full_tiles = n2 / ZF_TILE_UNITS;
     const int64_t G = gridDim.x;
     // UB units are loaded, then computed, at a time
-    constexpr int UB = (S >= 16) ? ZF_S16_UB : (S >= 8) ? ZF_S8_UB : ZF_TILE_U;
+#ifndef ZF_M1_UB
+#define ZF_M1_UB ZF_TILE_U   // units per load batch of the replay + 8 fresh trials body: the whole tile
+#endif
+    // (the replay + 8 body is not software-pipelined - pipelined it spills - so it waits for every batch it loads:
+    //  a whole tile per batch, 8 independent recursions per replay step, halves the waits: 1.36 -> 1.30 ms per
+    //  such pass at n = 1e8, same box; the same for the body of shorter fresh chains costs clean tails 2.7 %)
+    constexpr int UB = (S >= 16) ? ZF_S16_UB : (S >= 8) ? ((MODE == 1 && S == 8 && !HIST) ? ZF_M1_UB : ZF_S8_UB) : ZF_TILE_U;
     auto load_batch = [&](int64_t first_unit, zf_d2 (&a)[UB], zf_d2 (&o)[UB], zf_d2 (&q)[UB], zf_d2 (&cc)[UB]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
