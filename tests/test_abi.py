@@ -70,7 +70,10 @@ def test_short_output_buffers_are_refused():
     assert bytes(small) == bytes(176) and not trace.any()
     # zf_solver_poll: 176 "caller" bytes at the head of a guard region that must stay untouched
     guard = (C.c_byte * 1024)()
-    dummy = (C.c_byte * 64)()          # a non-null handle; never dereferenced: the checks come first
+    # a non-null "handle": a patterned region larger than any solver object - the checks must come before anything is
+    # read or WRITTEN through it (a write would land here instead of in somebody's heap, and is asserted on below)
+    dummy = (C.c_ubyte * (1 << 20))()
+    C.memset(dummy, 0xA5, len(dummy))
     rc = raw(lib.zf_solver_poll, [P, P, I, P, I], C.addressof(dummy), C.addressof(guard), 176, None, 0)
     assert rc == -2 and b"ctl_bytes" in lib.zf_last_error()
     ctl = _lib.Control()
@@ -85,6 +88,7 @@ def test_short_output_buffers_are_refused():
     out = np.zeros(6)
     rc = raw(lib.zf_solver_pass_stats_ex, [P, P, I], C.addressof(dummy), _lib.ptr(out), 4)
     assert rc == -2 and not out.any()
+    assert (np.frombuffer(dummy, dtype=np.uint8) == 0xA5).all(), "an entry point wrote through the handle before checking its arguments"
 
 
 def test_product_fails_loudly_without_gpu():

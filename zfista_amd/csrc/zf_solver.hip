@@ -877,7 +877,7 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
 extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev,
                                  const zf_control* saved, int64_t saved_bytes) {
     ZF_REQUIRE(s && xk_dev && xprev_dev && saved, "zf_solver_restore: null argument");
-    s->shadow_valid = false;   // (the control block changes behind the host's back: predict again after the next poll)
+    // (nothing is read or written through `s` before the caller's sizes have been checked)
     ZF_REQUIRE(saved_bytes == (int64_t)sizeof(zf_control),
                "zf_solver_restore: saved_bytes differs from zf_sizeof_control() (a control block of another ABI version)");
     const zf_problem_desc& d = s->desc;
@@ -885,6 +885,7 @@ extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const doubl
                "zf_solver_restore: sharded least squares is not supported");
     ZF_REQUIRE(saved->nit >= 0 && saved->lr > 0.0, "zf_solver_restore: implausible control block");
     const int64_t n = d.n;
+    s->shadow_valid = false;   // (the control block changes behind the host's back: predict again after the next poll)
     ZF_HIP(hipMemcpyAsync(s->xb[0], xk_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream));
     ZF_HIP(hipMemcpyAsync(s->xb[s->ring - 1], xprev_dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream));
     zf_control c = *saved;
