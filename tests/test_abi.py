@@ -88,6 +88,13 @@ def test_short_output_buffers_are_refused():
     out = np.zeros(6)
     rc = raw(lib.zf_solver_pass_stats_ex, [P, P, I], C.addressof(dummy), _lib.ptr(out), 4)
     assert rc == -2 and not out.any()
+    rc = raw(lib.zf_solver_pass_stats, [P, P, I], C.addressof(dummy), _lib.ptr(out), 3)
+    assert rc == -2 and not out.any()
+    iout = np.zeros(6, dtype=np.int64)
+    rc = raw(lib.zf_solver_launch_counts, [P, P, I], C.addressof(dummy), _lib.ptr(iout), 1)
+    assert rc == -2 and not iout.any()
+    rc = raw(lib.zf_mo_solve_stats, [P, P, I], C.addressof(dummy), _lib.ptr(iout), 5)
+    assert rc == -2 and not iout.any()
     assert (np.frombuffer(dummy, dtype=np.uint8) == 0xA5).all(), "an entry point wrote through the handle before checking its arguments"
 
 
