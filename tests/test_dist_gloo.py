@@ -8,7 +8,6 @@ concatenated iterates equal the single-process oracle on the full vector
 (bit-exact: the element recursion never sees a reduced sum), and the scalar
 traces agree to 1e-12."""
 import os
-import socket
 import sys
 import warnings
 
@@ -19,13 +18,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def _init_gloo(dist, rank, world, outdir):
+    """File rendezvous in the test's own tmp_path: no port is picked, so none can be taken by another
+    process (or by a sibling rank's retrying connect) before rank 0 listens on it."""
+    dist.init_process_group("gloo", init_method=f"file://{outdir}/rdzv", rank=rank, world_size=world)
 
 
-def _worker(rank, world, port, n, kw, outdir):
+def _worker(rank, world, n, kw, outdir):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -35,7 +34,7 @@ def _worker(rank, world, port, n, kw, outdir):
     from oracle import problems_ref as P
     from zfista_amd.proximal_gradient import _solve_native
 
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    _init_gloo(dist, rank, world, outdir)
     d, c, lam = P.make_pdiag(n, seed=1)
     lo, hi = rank * n // world, (rank + 1) * n // world
     prob = FakeProblem(d[lo:hi], c[lo:hi], lam, group=dist.group.WORLD, world=world, rank=rank)
@@ -62,7 +61,7 @@ def test_sharded_pdiag_world2(tmp_path, kw):
     from oracle import cpu_ref, problems_ref as P
 
     n, world = 10007, 2
-    mp.spawn(_worker, args=(world, _free_port(), n, kw, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, n, kw, str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     d, c, lam = P.make_pdiag(n, seed=1)
     with warnings.catch_warnings():
@@ -78,7 +77,7 @@ def test_sharded_pdiag_world2(tmp_path, kw):
     np.testing.assert_allclose(r[0]["allfuns"], exp.allfuns, rtol=1e-12)
 
 
-def _worker_chain(rank, world, port, n, kw, sub, outdir):
+def _worker_chain(rank, world, n, kw, sub, outdir):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -89,7 +88,7 @@ def _worker_chain(rank, world, port, n, kw, sub, outdir):
     from zfista_amd import _lib
     from zfista_amd.proximal_gradient import NativeRun
 
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    _init_gloo(dist, rank, world, outdir)
     d, c, lam = P.make_pdiag(n, seed=1)
     lo, hi = rank * n // world, (rank + 1) * n // world
     prob = FakeProblem(d[lo:hi], c[lo:hi], lam, group=dist.group.WORLD, world=world, rank=rank)
@@ -122,7 +121,7 @@ def test_sharded_pdiag_world2_chained_passes(tmp_path, kw, sub):
     from zfista_amd import _lib
 
     n, world = 10007, 2
-    mp.spawn(_worker_chain, args=(world, _free_port(), n, kw, sub, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_chain, args=(world, n, kw, sub, str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     d, c, lam = P.make_pdiag(n, seed=1)
     with warnings.catch_warnings():
@@ -138,7 +137,7 @@ def test_sharded_pdiag_world2_chained_passes(tmp_path, kw, sub):
     assert int(r[0]["passes"]) < exp.nit   # fewer exchanges than iterations
 
 
-def _worker_totals(rank, world, port, outdir):
+def _worker_totals(rank, world, outdir):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -146,7 +145,7 @@ def _worker_totals(rank, world, port, outdir):
 
     from zfista_amd.multiobjective import combine_totals
 
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    _init_gloo(dist, rank, world, outdir)
     vals = np.array([0.1 * (rank + 1), 1e16 if rank == 0 else 1.0, -3.0 + rank, float(rank)])
     got_sum = combine_totals(vals, -1, dist.group.WORLD)
     got_max = combine_totals(vals, 2, dist.group.WORLD)
@@ -161,7 +160,7 @@ def test_multiobjective_totals_exchange_world3(tmp_path):
     import torch.multiprocessing as mp
 
     world = 3
-    mp.spawn(_worker_totals, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_totals, args=(world, str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"t{k}.npz") for k in range(world)]
     exp_sum = np.array([(0.1 + 0.2) + 0.30000000000000004, (1e16 + 1.0) + 1.0, (-3.0 + -2.0) + -1.0, (0.0 + 1.0) + 2.0])
     for k in range(world):

@@ -66,14 +66,10 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     """The N > 1 flow of bench.py end to end - one process per rank, sharded solver, per-pass pack
     exchange, barrier-bracketed timing, max over ranks, one JSON line from rank 0 - rehearsed with
     two ranks on this one GPU (ZF_BENCH_BACKEND=gloo; the driver's runs use RCCL, one GPU per rank)."""
-    import socket
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, ZF_BENCH_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+    # --standalone: the agent's own store (bound to port 0 and kept open) is the rendezvous - no picked port
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+                          "--nnodes=1", "--nproc-per-node", "2", os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--elements", "2000000", "--steps", "24", "--warmup", "8",
                           "--min-seconds", "0.05"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)

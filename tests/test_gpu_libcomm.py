@@ -78,19 +78,16 @@ print("rank", rank, "ok")
 
 
 def test_two_rank_rccl_communicator_in_the_library(tmp_path):
-    import socket
-
     import torch
 
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL places one rank per device)")
     script = tmp_path / "two_ranks.py"
     script.write_text(_TWO_RANKS)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+    # --standalone: the agent listens on a port the kernel gives it (bind 0, kept open) and the ranks reuse the
+    # agent's store - no port number is ever picked, closed and hoped to be still free
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+                          "--nnodes=1", "--nproc-per-node", "2", str(script)],
                          capture_output=True, text=True, timeout=600, env=dict(os.environ, ZF_ROOT=ROOT))
     assert out.returncode == 0, out.stderr[-3000:]
 
@@ -100,7 +97,8 @@ import os, sys, warnings
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["ZF_ROOT"])
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dist.init_process_group("nccl", init_method="file://" + os.environ["ZF_RDZV_FILE"], rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
 from zfista_amd.comm import LibComm
 expect_comm = os.environ.get("ZF_RCCL_LIB") is None
 with warnings.catch_warnings(record=True) as w:
@@ -128,14 +126,9 @@ def test_communicator_from_an_nccl_process_group_is_all_or_nothing(tmp_path, rcc
     all-reduce of "did every rank get one".  With a librccl that cannot be loaded (ZF_RCCL_LIB names a file that does
     not exist) every rank gets None and a RuntimeWarning - the callers then exchange through torch.distributed -
     instead of an exception on some ranks and a hang on the others."""
-    import socket
-
     script = tmp_path / "from_group.py"
     script.write_text(_FROM_GROUP)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, ZF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env = dict(os.environ, ZF_ROOT=ROOT, ZF_RDZV_FILE=str(tmp_path / "rdzv"))     # file rendezvous: no port
     env.pop("ZF_RCCL_LIB", None)
     if rccl == "missing":
         env["ZF_RCCL_LIB"] = str(tmp_path / "no_such_librccl.so")

@@ -4,7 +4,6 @@ rank by tools/check_sharded_mo_rccl.py and ``ZF_FORCE_SPLIT=1 torchrun ... bench
 the in-process lockstep tests of test_gpu_sharded.py: here the exchange is a real collective between
 processes and every rank drives its own solver through the public entry point."""
 import os
-import socket
 import sys
 import warnings
 
@@ -17,13 +16,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _worker(rank, world, port, case, outdir):
+def _worker(rank, world, case, outdir):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -35,7 +28,8 @@ def _worker(rank, world, port, case, outdir):
     from zfista_amd.problems import DiagQuadL1, LeastSquaresL1
 
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # file rendezvous: no port is picked, so none can be taken by somebody else before rank 0 listens on it
+    dist.init_process_group("gloo", init_method=f"file://{outdir}/rdzv", rank=rank, world_size=world)
     warnings.simplefilter("ignore")
     if case == "lasso_rows":   # rows of A and b split over the ranks, x replicated: A_p^T r_p is exchanged
         A, b, lam = P.make_plasso(96, 301, seed=3, n_informative=12)
@@ -69,7 +63,7 @@ def test_sharded_solve_in_separate_processes(case, world, tmp_path):
 
     from oracle import cpu_ref, problems_ref as P
 
-    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, case, str(tmp_path)), nprocs=world, join=True)
     r = [np.load(tmp_path / f"r{k}.npz") for k in range(world)]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
