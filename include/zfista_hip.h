@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZF_ABI_VERSION 4
+#define ZF_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------ */
 #define ZF_OK 0
@@ -173,6 +173,22 @@ int zf_comm_destroy(zf_comm* c);
  * barrier and stream events.  cap_doubles bounds the per-rank count of an all-gather. */
 int zf_comm_create_local_group(zf_comm** out_world, int32_t world, int64_t cap_doubles);
 int zf_comm_info(zf_comm* c, int32_t* rank, int32_t* world);
+/* What the communicator says about itself (ABI 5): nccl_* come from RCCL's own queries of the ncclComm_t
+ * (ncclCommCount / ncclCommUserRank / ncclCommCuDevice; -1 for the in-process stand-in), not from what the caller
+ * passed to zf_comm_create; `library` is the file the RCCL symbols were resolved from.  out_bytes = capacity of *out
+ * (a short buffer is refused before anything is written). */
+typedef struct zf_comm_desc {
+    int32_t rank, world;      /* as given at creation */
+    int32_t kind;             /* 0: RCCL communicator, 1: in-process thread-rank group */
+    int32_t nccl_count;       /* ranks RCCL reports for this communicator */
+    int32_t nccl_user_rank;
+    int32_t nccl_device;
+    int32_t rccl_version;     /* ncclGetVersion (0: not available) */
+    int32_t reserved;
+    int64_t all_gathers;      /* zf_comm_all_gather calls issued on this communicator so far */
+    char library[256];
+} zf_comm_desc;
+int zf_comm_describe(zf_comm* c, zf_comm_desc* out, int64_t out_bytes);
 /* recv (world x count doubles, rank-major) <- send (count doubles) of every rank; stream-ordered */
 int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream);
 
@@ -283,6 +299,9 @@ int zf_solver_launch_counts(zf_solver* s, int64_t* out, int64_t count /* >= 2 */
 int zf_solver_pass_stats(zf_solver* s, double* out, int64_t count /* >= 4 */);
 /* the same window plus out[4] = fresh trials and out[5] = replayed iterations the other passes carried */
 int zf_solver_pass_stats_ex(zf_solver* s, double* out, int64_t count /* >= 6 */);
+/* sharded solves, timing on (ABI 5): out[0] = mean ms, out[1] = count of the per-pass pack exchanges since the last
+ * call, each timed on this rank's stream from "my packs are ready" to "the gathered packs are here" */
+int zf_solver_exchange_stats(zf_solver* s, double* out, int64_t count /* >= 2 */);
 int zf_solver_set_timing(zf_solver* s, int32_t enabled);
 
 /* ---- vector kernels for opaque (Python) callbacks ------------------------

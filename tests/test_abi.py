@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in zfista_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.zf_abi_version() == 4
+    assert lib.zf_abi_version() == 5
 
 
 def test_struct_mirrors():

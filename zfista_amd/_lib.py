@@ -72,6 +72,16 @@ class Options(C.Structure):
     ]
 
 
+class CommDesc(C.Structure):
+    """Mirror of ``zf_comm_desc``."""
+
+    _fields_ = [
+        ("rank", C.c_int32), ("world", C.c_int32), ("kind", C.c_int32), ("nccl_count", C.c_int32),
+        ("nccl_user_rank", C.c_int32), ("nccl_device", C.c_int32), ("rccl_version", C.c_int32), ("reserved", C.c_int32),
+        ("all_gathers", C.c_int64), ("library", C.c_char * 256),
+    ]
+
+
 _P = C.c_void_p
 _D = C.POINTER(C.c_double)
 # name -> (restype, argtypes); every symbol include/zfista_hip.h declares
@@ -93,6 +103,7 @@ SIGNATURES = {
     "zf_comm_destroy": (C.c_int, [_P]),
     "zf_comm_create_local_group": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int64]),
     "zf_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "zf_comm_describe": (C.c_int, [_P, C.POINTER(CommDesc), C.c_int64]),
     "zf_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "zf_solver_set_comm": (C.c_int, [_P, _P]),
     "zf_solver_enqueue_init_all": (C.c_int, [_P, _P]),
@@ -125,6 +136,7 @@ SIGNATURES = {
     "zf_solver_set_timing": (C.c_int, [_P, C.c_int32]),
     "zf_solver_pass_stats": (C.c_int, [_P, _P, C.c_int64]),
     "zf_solver_pass_stats_ex": (C.c_int, [_P, _P, C.c_int64]),
+    "zf_solver_exchange_stats": (C.c_int, [_P, _P, C.c_int64]),
     "zf_solver_launch_counts": (C.c_int, [_P, _P, C.c_int64]),
     "zf_host_grad_step": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64]),
     "zf_host_model_terms": (C.c_int, [_P, _P, _P, C.c_int64, _P]),

@@ -112,6 +112,18 @@ class LibComm:
         _lib.check(self.lib.zf_comm_all_gather(self.handle, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
                                                send.numel(), C.c_void_p(st)), "zf_comm_all_gather")
 
+    def describe(self) -> dict:
+        """What the communicator says about itself (``zf_comm_describe``): the ranks RCCL reports, the library file the
+        RCCL symbols came from, its version, the all-gathers issued so far."""
+        d = _lib.CommDesc()
+        _lib.check(self.lib.zf_comm_describe(self.handle, C.byref(d), C.sizeof(d)), "zf_comm_describe")
+        return {"via": "zf_comm (RCCL inside libzfista_hip.so)" if d.kind == 0 else "zf_comm in-process thread-rank group (no RCCL)",
+                "world": int(d.world), "rank": int(d.rank),
+                "rank_count_seen": int(d.nccl_count) if d.kind == 0 else int(d.world),
+                "rccl_user_rank": int(d.nccl_user_rank), "rccl_device": int(d.nccl_device),
+                "rccl_version": int(d.rccl_version), "library": d.library.decode(errors="replace"),
+                "all_gathers_issued": int(d.all_gathers)}
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.zf_comm_destroy(self.handle)

@@ -31,6 +31,12 @@ struct rccl_api {
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    // what the communicator says about itself (zf_comm_describe): optional symbols
+    int (*CommCount)(nccl_comm_t, int*) = nullptr;
+    int (*CommUserRank)(nccl_comm_t, int*) = nullptr;
+    int (*CommCuDevice)(nccl_comm_t, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    char path[256] = "";
 };
 rccl_api g_rccl;
 
@@ -64,6 +70,12 @@ void rccl_load_once() {
         snprintf(g_rccl_err, sizeof(g_rccl_err), "zf_comm: librccl lacks an expected symbol");
         return;
     }
+    g_rccl.CommCount = (int (*)(nccl_comm_t, int*))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (int (*)(nccl_comm_t, int*))dlsym(h, "ncclCommUserRank");
+    g_rccl.CommCuDevice = (int (*)(nccl_comm_t, int*))dlsym(h, "ncclCommCuDevice");
+    g_rccl.GetVersion = (int (*)(int*))dlsym(h, "ncclGetVersion");
+    Dl_info info;
+    if (dladdr((void*)g_rccl.AllGather, &info) && info.dli_fname) snprintf(g_rccl.path, sizeof(g_rccl.path), "%s", info.dli_fname);
     g_rccl.handle = h;
 }
 int rccl_load() {
@@ -90,6 +102,7 @@ struct zf_local_group {
     double* staging = nullptr;        // [2][world][cap]
     hipEvent_t* ev = nullptr;         // [2][world]
     pthread_barrier_t barrier;
+    int failed[2] = {0, 0};           // per parity: some rank could not contribute to the call in flight
     int refs = 0;
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
 };
@@ -99,6 +112,7 @@ struct zf_comm {
     int rank = 0, world = 1;
     zf_local_group* local = nullptr;  // non-NULL: the in-process stand-in
     unsigned calls = 0;
+    int64_t gathers = 0;              // all-gathers issued on this communicator (zf_comm_describe)
 };
 
 // 128 bytes that rank 0 creates and every rank of the communicator must receive (over any host
@@ -206,6 +220,31 @@ extern "C" int zf_comm_info(zf_comm* c, int32_t* rank, int32_t* world) {
     return ZF_OK;
 }
 
+// What the communicator says about itself: the ranks RCCL reports (ncclCommCount / ncclCommUserRank /
+// ncclCommCuDevice - not what the caller passed in), the library the symbols came from, its version, and how many
+// all-gathers have gone through it.  A benchmark line built from this shows what RCCL saw.
+extern "C" int zf_comm_describe(zf_comm* c, zf_comm_desc* out, int64_t out_bytes) {
+    ZF_REQUIRE(out && out_bytes >= (int64_t)sizeof(zf_comm_desc), "zf_comm_describe: out_bytes is smaller than sizeof(zf_comm_desc)");
+    ZF_REQUIRE(c, "zf_comm_describe: null communicator");
+    memset(out, 0, sizeof(*out));
+    out->rank = c->rank;
+    out->world = c->world;
+    out->kind = c->local ? 1 : 0;
+    out->nccl_count = out->nccl_user_rank = out->nccl_device = -1;
+    out->all_gathers = c->gathers;
+    if (c->comm) {
+        int v = 0;
+        if (g_rccl.CommCount && g_rccl.CommCount(c->comm, &v) == 0) out->nccl_count = v;
+        if (g_rccl.CommUserRank && g_rccl.CommUserRank(c->comm, &v) == 0) out->nccl_user_rank = v;
+        if (g_rccl.CommCuDevice && g_rccl.CommCuDevice(c->comm, &v) == 0) out->nccl_device = v;
+        if (g_rccl.GetVersion && g_rccl.GetVersion(&v) == 0) out->rccl_version = v;
+        snprintf(out->library, sizeof(out->library), "%s", g_rccl.path);
+    } else {
+        snprintf(out->library, sizeof(out->library), "in-process thread-rank group (no RCCL)");
+    }
+    return ZF_OK;
+}
+
 // recv (world x count doubles, rank-major) <- send (count doubles) of every rank, on `stream`
 extern "C" int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream) {
     ZF_REQUIRE(c && send_dev && recv_dev && count >= 0, "zf_comm_all_gather: bad argument");
@@ -219,21 +258,32 @@ extern "C" int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* re
         const int par = (int)(c->calls++ & 1u);
         double* stage = g->staging + (int64_t)par * g->world * g->cap;
         hipStream_t st = (hipStream_t)stream;
+        c->gathers += 1;
         if (fits) {
             e = hipMemcpyAsync(stage + (int64_t)c->rank * count, send_dev, sizeof(double) * count, hipMemcpyDeviceToDevice, st);
             if (e == hipSuccess) e = hipEventRecord(g->ev[par * g->world + c->rank], st);
         }
+        // a rank that could not contribute says so BEFORE the first barrier; every rank reads the flag after it: nobody
+        // copies out a staging area that holds an older value (and a never re-recorded event) for the failing rank's
+        // slice and goes on with stale scalars while only the failing rank reports an error
+        if (!fits || e != hipSuccess) __atomic_store_n(&g->failed[par], 1, __ATOMIC_RELEASE);
         pthread_barrier_wait(&g->barrier);   // every rank's copy-in is enqueued and its event recorded
-        if (fits && e == hipSuccess) {
+        const bool group_failed = __atomic_load_n(&g->failed[par], __ATOMIC_ACQUIRE) != 0;
+        if (fits && e == hipSuccess && !group_failed) {
             for (int r = 0; r < g->world && e == hipSuccess; ++r) e = hipStreamWaitEvent(st, g->ev[par * g->world + r], 0);
             if (e == hipSuccess)
                 e = hipMemcpyAsync(recv_dev, stage, sizeof(double) * count * g->world, hipMemcpyDeviceToDevice, st);
         }
         pthread_barrier_wait(&g->barrier);   // nobody re-records an event of this parity before all waits are enqueued
+        // (re-armed for the call after next, which every rank starts only after this barrier; the flag of the OTHER
+        //  parity is the one the next call uses)
+        if (group_failed && c->rank == 0) __atomic_store_n(&g->failed[par], 0, __ATOMIC_RELEASE);
         if (!fits) return zf_fail(ZF_ERR_ARG, "zf_comm_all_gather: count exceeds the local group's staging capacity%s");
         if (e != hipSuccess) return zf_fail(ZF_ERR_HIP, "zf_comm_all_gather (local group): %s", hipGetErrorString(e));
+        if (group_failed) return zf_fail(ZF_ERR_STATE, "zf_comm_all_gather (local group): another rank of the group failed in this exchange%s");
         return ZF_OK;
     }
+    c->gathers += 1;
     return rccl_check(g_rccl.AllGather(send_dev, recv_dev, (size_t)count, /*ncclDouble*/ 8, c->comm, (hipStream_t)stream),
                       "ncclAllGather");
 }

@@ -178,6 +178,11 @@ struct zf_solver {
     size_t ev_used = 0;
     double ms_total = 0.0;
     int64_t ms_count = 0;
+    // the per-pass exchange of a sharded solve (zf_gather_packs), bracketed the same way when timing is on
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> xev_pool;
+    size_t xev_used = 0;
+    double xms_total = 0.0;
+    int64_t xms_count = 0;
     // the shape of every timed pass, written by the kernel itself (the host cannot know it at launch)
     int* pass_log = nullptr;              // ZF_PASS_LOG slots (device; inside ctl_trace, behind the trace ring)
     int64_t launches = 0;                 // timed launches so far (slot = launches % ZF_PASS_LOG)
@@ -216,6 +221,10 @@ static int zf_solver_free_all(zf_solver* s) {
         if (p) (void)hipFree(p);
     if (s->mail) (void)hipHostFree(s->mail);
     for (auto& e : s->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    for (auto& e : s->xev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
@@ -1082,7 +1091,20 @@ extern "C" int zf_solver_set_comm(zf_solver* s, zf_comm* comm) {
 }
 
 static int zf_gather_packs(zf_solver* s, int64_t packs) {
-    return zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, s->stream);
+    if (!s->timing) return zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, s->stream);
+    // timed: from "this rank's packs are ready" to "the gathered packs are here" on this rank's stream - the
+    // collective itself plus the wait for the slowest rank (zf_solver_exchange_stats)
+    if (s->xev_used == s->xev_pool.size()) {
+        hipEvent_t x, y;
+        ZF_HIP(hipEventCreate(&x));
+        ZF_HIP(hipEventCreate(&y));
+        s->xev_pool.emplace_back(x, y);
+    }
+    const auto& ev = s->xev_pool[s->xev_used++];
+    ZF_HIP(hipEventRecord(ev.first, s->stream));
+    const int rc = zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, s->stream);
+    ZF_HIP(hipEventRecord(ev.second, s->stream));
+    return rc;
 }
 static int zf_gather_svec(zf_solver* s, bool at_init = false) {
     if (s->desc.kind != ZF_PROBLEM_LEAST_SQUARES_L1 || s->desc.world == 1) return ZF_OK;
@@ -1233,6 +1255,29 @@ static int zf_collect_timing(zf_solver* s, bool log_in_mail = false) {
     }
     s->first_uncollected = s->launches;
     s->ev_used = 0;
+    for (size_t k = 0; k < s->xev_used; ++k) {
+        float ms = 0.f;
+        ZF_HIP(hipEventElapsedTime(&ms, s->xev_pool[k].first, s->xev_pool[k].second));
+        s->xms_total += ms;
+        s->xms_count += 1;
+    }
+    s->xev_used = 0;
+    return ZF_OK;
+}
+
+// Sharded solves with timing on: out[0] = mean ms, out[1] = count of the per-pass pack exchanges since the last
+// call - each measured on this rank's stream from "my packs are ready" to "the gathered packs are here" (the
+// collective and the wait for the slowest rank).  Resets its window.
+extern "C" int zf_solver_exchange_stats(zf_solver* s, double* out, int64_t count) {
+    ZF_REQUIRE(out && count >= 2, "zf_solver_exchange_stats: needs a buffer of >= 2 doubles");
+    ZF_REQUIRE(s, "zf_solver_exchange_stats: null solver");
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    int rc = zf_collect_timing(s);
+    if (rc) return rc;
+    out[0] = s->xms_count ? s->xms_total / (double)s->xms_count : 0.0;
+    out[1] = (double)s->xms_count;
+    s->xms_total = 0.0;
+    s->xms_count = 0;
     return ZF_OK;
 }
 

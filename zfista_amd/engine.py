@@ -279,6 +279,12 @@ class DeviceSolver:
         _lib.check(self.lib.zf_solver_pass_stats_ex(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
         return (out[0], int(out[1])), (out[2], int(out[3])), (int(out[4]), int(out[5]))
 
+    def exchange_stats(self):
+        """(mean ms, count) of the per-pass pack exchanges the library issued since the last call (timing on)."""
+        out = np.zeros(2)
+        _lib.check(self.lib.zf_solver_exchange_stats(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
+        return out[0], int(out[1])
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.zf_solver_destroy(self.handle)
