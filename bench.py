@@ -345,6 +345,7 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 m["part_n"] += pn
                 m["part_fresh"] += pf
                 m["part_lag"] += pl
+            note_comm(run)
             dt = max_over_ranks(dt)
             m["blocks"].append(dt)
             m["timed"] += dt
@@ -354,6 +355,22 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 break
             run = NativeRun(prob, x0, o, timing=timing)   # the same workload again, on a warmer device
         return m
+
+    comm_seen = {}
+
+    def note_comm(run):
+        """What carried the per-pass exchange of this run (rank 0 reports it: config.rccl)."""
+        sv = run.solver
+        if getattr(sv, "comm", None) is not None:
+            comm_seen.update(sv.comm.describe())
+            if timing:
+                ms, cnt = sv.exchange_stats()
+                comm_seen["exchange_ms_per_pass"] = (comm_seen.get("exchange_ms_per_pass", 0.0) * comm_seen.get("exchanges_timed", 0)
+                                                     + ms * cnt) / max(comm_seen.get("exchanges_timed", 0) + cnt, 1)
+                comm_seen["exchanges_timed"] = comm_seen.get("exchanges_timed", 0) + cnt
+        elif getattr(sv, "split", False):
+            comm_seen.update({"via": "torch.distributed fallback (host-driven trial / all-gather / decide per pass)",
+                              "world": sv.world, "rank": sv.rank, "rank_count_seen": sv.world, "library": None})
 
     M = measure(K, W, args.min_seconds, args.max_blocks)
     S, blocks, timed, tiles = M["S"], M["blocks"], M["timed"], M["tiles"]
@@ -413,6 +430,11 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 "tiles_per_workgroup": tiles,
                 "iterations_per_sec_by_regime": regimes,
                 "thread_ranks": thread_ranks or None,
+                # what carried the per-pass exchange, as the communicator itself reports it (zf_comm_describe: RCCL's own
+                # ncclCommCount / ncclCommUserRank / ncclCommCuDevice, the librccl file, its version) and what one exchange
+                # cost on rank 0's stream (HIP events: my packs ready -> gathered packs here); None on one GPU without one
+                "rccl": comm_seen or None,
+                "overrides": _lib.env_overrides(),
                 "parallelism": (f"DRY RUN: x sharded over {world} rank threads on ONE GPU (in-process communicator group of the "
                                 "library); the N > 1 step sequence, not a scaling measurement") if thread_ranks else
                                f"x sharded over {world} GPU(s); per-pass scalar pack all-gather (RCCL inside the library)"

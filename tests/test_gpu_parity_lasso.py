@@ -255,3 +255,32 @@ def test_generic_path_golden_toy(golden):
             assert res.nit == int(G(f"{tag}.nit")), tag
             np.testing.assert_allclose(np.concatenate(res.allvecs), G(f"{tag}.vecs").ravel(), rtol=TOL, atol=1e-15)
             np.testing.assert_allclose(res.allerrs, G(f"{tag}.allerrs"), rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(nesterov=True), dict(return_all=True), dict(nesterov=True, max_iter=7),
+                                dict(lr=8.0, nesterov=True)])
+def test_generic_path_calls_the_callbacks_as_often_as_the_reference(kw):
+    """Opaque callbacks are called where and as often as the reference calls them (proximal_gradient.py:140-142,
+    :279, :295, :466, :472, :523, :547): the same counting closures through the oracle (pinned to the imported
+    reference, G1) and through the product must count the same - g(x0) before the loop only with return_all."""
+    from oracle import cpu_ref
+    from zfista_amd import minimize_proximal_gradient
+
+    def counted():
+        f, g, jac_f, prox = _toy(0.1)
+        n = dict(f=0, g=0, jac_f=0, prox=0)
+
+        def wrap(name, fn):
+            def inner(*a):
+                n[name] += 1
+                return fn(*a)
+            return inner
+        return n, (wrap("f", f), wrap("g", g), wrap("jac_f", jac_f), wrap("prox", prox))
+
+    n_ref, cb_ref = counted()
+    n_got, cb_got = counted()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*cb_ref, np.array([0.3]), **kw)
+        res = minimize_proximal_gradient(*cb_got, np.array([0.3]), **kw)
+    assert res.nit == exp.nit and n_got == n_ref, (n_got, n_ref)

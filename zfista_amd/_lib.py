@@ -251,5 +251,18 @@ def require_gpu():
     return lib
 
 
+# Every ZF_* environment variable product code reads.  Each changes which kernels run, their launch geometry or a
+# numerics path - results that were produced under one say so (``OptimizeResult.overrides``, bench.py's
+# ``config.overrides``): numerics never change silently with the environment.
+ENV_SWITCHES = ("ZF_FIN_KERNEL", "ZF_SPECULATE", "ZF_NT", "ZF_LS_SMALL", "ZF_GEMV_MFMA", "ZF_TILES_PER_WG", "ZF_SUB_ITERS",
+                "ZF_COMM", "ZF_MO_COMM", "ZF_MO_LAUNCH_AHEAD", "ZF_MO_SPIN_LIMIT", "ZF_RCCL_LIB", "ZF_DUAL_SOLVER",
+                "ZF_FORCE_SPLIT", "ZF_LIB_PATH", "ZF_PERSIST", "ZF_BENCH_BACKEND")
+
+
+def env_overrides() -> dict:
+    """{name: value} of every ZF_* switch set in this process's environment (empty: the defaults ran)."""
+    return {k: os.environ[k] for k in ENV_SWITCHES if k in os.environ}
+
+
 def ptr(a: np.ndarray) -> int:
     return a.ctypes.data

@@ -626,19 +626,24 @@ def solve_native(problem, x0, o):
     t_state = None
     betas = []
     nit_done = trials_done = 0
+    w_last = None
     if (lazy_f_y and not o["return_all"] and o["max_iter"] >= 1
             and os.environ.get("ZF_MO_LAUNCH_AHEAD", "1") != "0"):
         out = _solve_native_ahead(eng, o, m, F_old, res, t0)
         if isinstance(out, _HandOver):
             # a device trial gave up in the middle of the solve: the loop below continues from the state it
             # left - x_k, x_{k-1}, y in the engine, the line search of iteration nit_done + 1 under way
-            nit_done, trials_done, lr, F_old, t_state, betas = out
+            nit_done, trials_done, lr, F_old, t_state, betas, w_last = out
         elif out is not None:
             return out
         else:
             eng.set_x0(x0)              # (no device trial for this problem: the loop below, from the start)
             eng.set_fused(lazy_f_y)
     w0 = np.ones(m) / m
+    if o["warm_start"] and w_last is not None:
+        # handed over in the middle of a solve: the reference goes on from the weights of the last trial (:286-288) -
+        # the one just rejected inside this line search, else the one the previous iteration was accepted with
+        w0 = np.asarray(w_last, dtype=np.float64)
     allvecs = allfuns = allerrs = None
     if o["return_all"]:
         allvecs, allfuns, allerrs = [x0], [f0 + g0], []
@@ -718,8 +723,9 @@ def solve_native(problem, x0, o):
 
 
 class _HandOver(tuple):
-    """(nit_done, trials_done, lr, F(x_k), t_state, betas): where _solve_native_ahead left a solve whose device
-    trial gave up; solve_native's sequential loop continues from it."""
+    """(nit_done, trials_done, lr, F(x_k), t_state, betas, last weights): where _solve_native_ahead left a solve whose
+    device trial gave up; solve_native's sequential loop continues from it (the weights of the last completed trial
+    are what a ``warm_start`` search starts from)."""
 
 
 def _solve_native_ahead(eng, o, m, F_old, res, t0):
@@ -754,6 +760,7 @@ def _solve_native_ahead(eng, o, m, F_old, res, t0):
     status = _lib.ZF_MAXITER
     nit = 0
     F_k = F_old
+    w_last = None
     for nit in range(1, o["max_iter"] + 1):
         trials = 0
         ahead = None
@@ -777,7 +784,7 @@ def _solve_native_ahead(eng, o, m, F_old, res, t0):
                     if o["nesterov"]:
                         betas.append(ahead[1])
                 eng.device_timed_out(ticket)
-                return _HandOver((nit - 1, trials - 1, lr, F_k, t_state, betas))
+                return _HandOver((nit - 1, trials - 1, lr, F_k, t_state, betas, w_last))
             if out is None or isinstance(out[0], str):
                 # the search did not run on the device (non-finite dual values, e.g. F(x_0) = inf outside the
                 # box): its record says "not accepted", so a trial launched ahead found its gate closed
@@ -788,6 +795,7 @@ def _solve_native_ahead(eng, o, m, F_old, res, t0):
                     return None                               # from the start: the caller's loop (host search)
                 raise RuntimeError("the device-side trial was not attempted in the middle of a solve")
             weight, dual_fun, nit_int, err, f_x, g_x, f_y, accepted = out
+            w_last = weight
             fun = -dual_fun                                   # (:207)
             F_new = f_x + g_x                                 # (:295) formed and tested on the device
             if accepted:

@@ -149,6 +149,11 @@ def minimize_proximal_gradient(
         res, status = _solve_generic(f, g, jac_f, prox_wsum_g, x0, opts)
     if from_env:
         res["dual_solver"] = f"{dual_solver} (from the environment: ZF_DUAL_SOLVER)"
+    overrides = _lib.env_overrides()
+    if overrides:
+        # run-time switches that select other kernels, launch geometries or numerics paths: a result produced under
+        # one says so (an extra field; absent when the defaults ran)
+        res["overrides"] = overrides
     if status == _lib.ZF_MAXITER:
         warn(res.message, stacklevel=2)   # :543
     return res
@@ -638,9 +643,11 @@ class _GenericOps:
         self.m = 1
 
     def start(self, x0):
-        f0 = self.f(x0)
+        f0 = self.f(x0)                                         # :466
         self.m = _objectives(f0)
-        return f0 + self.g(x0)
+        # g(x0) is called before the loop only for the record (:472); every line search re-evaluates F(x_k) (:279), so
+        # nothing else needs the value - a callback that counts its calls sees exactly the reference's
+        return f0 + self.g(x0) if self.o["return_all"] else None
 
     def begin(self, x_old, y, F_old):
         return _LineSearch(self.f(x_old) + self.g(x_old))      # :279
