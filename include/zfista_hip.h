@@ -225,7 +225,13 @@ int zf_solver_enqueue_init_commit(zf_solver* s);
 /* momentum factors beta_j for accepted-iteration indices first..first+count-1 (:531-533) */
 int zf_solver_set_beta(zf_solver* s, int64_t first, const double* beta_host, int64_t count);
 /* world == 1: enqueue `steps` complete steps (trial+finalize+decide), no host sync; a step accepts
- * between 0 and sub_iters iterations, so poll before the device can be ZF_RING iterations ahead */
+ * between 0 and sub_iters iterations, so poll before the device can be ZF_RING iterations ahead.
+ * CONTRACT: a step runs the pass the host EXPECTS from the control block of its last zf_solver_poll (advanced on
+ * the assumption that every trial since was accepted).  When the device takes another turn - a trial rejected, a
+ * termination inside a chain - the steps already enqueued behind it may be no-ops (no kernel finds its shape, the
+ * control block stays as it is) until the next zf_solver_poll: N steps advance the solve by AT MOST N passes, and
+ * only the first step after a poll is guaranteed to run.  Behind a chunk that saw rejections the library launches a
+ * fallback kernel with every step, so such chunks lose no passes.  ZF_SPECULATE=0 launches every shape always. */
 int zf_solver_enqueue_steps(zf_solver* s, int64_t steps);
 /* after initialisation: fix the launch geometry (interleaved tiles per workgroup) of the trial
  * kernel.  It is a function of n only - never of a timing measurement, the chain length or the
@@ -288,10 +294,13 @@ int zf_solver_get_x_prev(zf_solver* s, double* x_host, int64_t count /* >= n */)
 int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev, const zf_control* saved,
                       int64_t saved_bytes /* == zf_sizeof_control(): a block of another layout is refused */);
 int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches);
-/* since creation: out[0] = trial steps issued, out[1] = shape-specific trial kernels launched for them.  A chained
- * pass has up to four shapes (full chain, short, long, mid) and needs one; the host launches only the one it
- * expects once a poll has shown it the control block and the last chunk had no rejection - unsharded, and
- * sharded through the library's communicator - otherwise all of them (the others exit at once). */
+/* since creation: out[0] = trial steps issued, out[1] = trial kernels launched for them; with count >= 4 (ABI 5) also
+ * out[2] = launches of the persistent multi-pass kernel, out[3] = steps those launches covered.  A chained pass has
+ * one of several shapes (full chain, short, general, a mid chain of 9 .. 15 trials) and needs one kernel; the host
+ * launches the one it expects once a poll has shown it the control block - unsharded, and sharded through the
+ * library's communicator; behind a chunk that saw rejections the general body rides along as the complement of the
+ * expected kernel (on small grids: alone); with nothing known, the three kernels that between them run every shape.
+ * On grids the device holds at once, consecutive full chains share ONE launch (zf_persist_kernel; ZF_PERSIST=0: off). */
 int zf_solver_launch_counts(zf_solver* s, int64_t* out, int64_t count /* >= 2 */);
 /* the same window split by the shape of the pass, which the kernel logs itself: out[0], out[1] = mean
  * ms and count of full chains (sub_iters fresh trials, nothing replayed); out[2], out[3] = every other

@@ -357,7 +357,7 @@ def test_kernel_timing_of_a_row_sharded_solver_with_thread_ranks():
 
 @pytest.mark.parametrize("world", [1, 3])
 def test_a_sharded_pass_launches_only_the_kernel_of_its_shape(world):
-    """A chained pass has four shape-specific kernels and needs one.  Once a poll has shown the host the control
+    """A chained pass has several shape-specific kernels and needs one.  Once a poll has shown the host the control
     block it launches only the one it expects - through the library's communicator too: every rank predicts from the
     same control block, the packs carry a stamp of the state they were computed from (zf_pack_stamp) and the decide
     step ignores gathered packs of any other state.  Checked here: the launch counts, and bitwise agreement with
@@ -420,21 +420,21 @@ def test_a_sharded_pass_launches_only_the_kernel_of_its_shape(world):
     finally:
         del os.environ["ZF_SPECULATE"]
     for rows, x, nit, counts in everything:
-        assert nit == K and counts[-1] == (6, 24), counts
+        assert nit == K and counts[-1] == (6, 18), counts   # (the three kernels that between them run every shape)
     by_chunk = sharded(2)          # polled every two passes
     for r, (rows, x, nit, counts) in enumerate(by_chunk):
         assert nit == K
         assert np.array_equal(rows, everything[r][0]) and np.array_equal(x, everything[r][1])
         # 3 full chains + 10 + 10 = 5 passes in 3 chunks of 2 steps: one kernel each; the 6th step finds the solve
-        # finished, as the host expected - then it launches every shape, in case the device is NOT finished
+        # finished, as the host expected - then it launches the general body on any shape, in case the device is NOT
         assert np.all(rows[:, _lib.TR_TRIALS] == 1), "the test wants a solve without rejections"
-        assert counts[-1] == (6, 5 + 4), counts
+        assert counts[-1] == (6, 5 + 1), counts
 
 
 @pytest.mark.parametrize("world", [1, 2])
 def test_after_rejections_a_pass_launches_the_two_shapes_it_can_need(world):
-    """Once a poll has seen rejections the host no longer knows which shape the next pass has - but far from max_iter
-    it is the full chain or the short / replaying body, so only those two kernels are launched (near max_iter: all).
+    """Once a poll has seen rejections the host no longer knows which shape the passes behind the first have: the
+    general body runs them whatever their shape (on this small grid alone; on large ones beside the expected kernel).
     A solve that starts with lr too large (the first line search backtracks) and runs into the noise floor of the
     acceptance test (rejections from iteration ~60 on at this size), polled every 2 passes, against the same solve
     with every kernel launched every time (ZF_SPECULATE=0): identical rows and iterates, fewer launches."""
@@ -500,7 +500,7 @@ def test_after_rejections_a_pass_launches_the_two_shapes_it_can_need(world):
         assert nit_e == nit_p == K
         assert np.any(rows_e[:, _lib.TR_TRIALS] > 1), "the test wants rejections"
         assert np.array_equal(rows_e, rows_p) and np.array_equal(x_e, x_p)
-        assert kernels_e == 4 * steps_e
+        assert kernels_e == 3 * steps_e
         # mispredicted steps are no-ops that cost a step each: a few, and far fewer kernels all the same
         assert steps_e <= steps_p <= steps_e + 8, (steps_e, steps_p)
         assert kernels_p <= 0.7 * kernels_e, (kernels_p, kernels_e)

@@ -27,6 +27,15 @@ struct zf_elem_acc {
     double fy, dot, ss, l1, fx, mx;
 };
 
+// threadIdx.x; OPAQUE: through a volatile asm, so that what is computed from it is not loop-invariant to the compiler.
+// Inside the pass loop of zf_persist_kernel LICM hoisted every address and index derived from the thread id out of the
+// loop and kept them alive across the chain: 315 VGPRs (one wave per SIMD) against 240 for the same body per launch.
+template <bool OPAQUE> __device__ __forceinline__ unsigned zf_tid() {
+    unsigned t = threadIdx.x;
+    if (OPAQUE) asm volatile("" : "+v"(t));
+    return t;
+}
+
 // --- element bodies --------------------------------------------------------
 // The ITERATE arithmetic (y, grad, v, x+) is NumPy's, operation by operation, never contracted:
 // x+ is bit-identical to the reference expression.  The six REDUCTIONS feed only the scalar
@@ -177,10 +186,14 @@ typedef __attribute__((address_space(3))) void* zf_lds_ptr;
 #ifndef ZF_GLDS_STAGES
 #define ZF_GLDS_STAGES 3   // LDS stages of the DMA pipeline: units in flight ahead of the one being computed + 1
 #endif
+#ifndef ZF_MID_REG_MAX
+#define ZF_MID_REG_MAX 10   // mid chains (PART 3) of up to this many trials load into registers (software-pipelined), longer ones by DMA
+#endif
 // SP = packs per pass of the solver (S <= SP): the 8-trial bodies use the DMA path only inside a 16-chain solver
 template <int S, int MODE, bool HIST, bool GRAD_INLINE, int SP = S> constexpr bool zf_uses_glds() {
     if (HIST || !GRAD_INLINE || ZF_S16_GLDS == 0) return false;
     if (S >= 16) return true;
+    if (MODE == 0 && SP >= 16 && S > ZF_MID_REG_MAX) return true;   // the longer mid chains (zf_pass_part: PART 3)
     return ZF_S8_GLDS != 0 && S == 8 && SP >= 16;
 }
 constexpr int ZF_GLDS_STREAMS = 4;                                   // x_k, x_{k-1}, d, c
@@ -197,18 +210,34 @@ constexpr int zf_chain_h(int S) {
     while (h < 4 && S % (2 << h) == 0) ++h;
     return h;
 }
-// trials of the branch-free MID chain: the driver-sized tail before max_iter (S < left <= 2 x this: two passes of this many)
-constexpr int ZF_MID_CHAIN = 10;
-// Which shape-specific kernel runs a pass of `nf` fresh trials behind `lag` lagging iterations (S = chain length of
-// the solver): 0 the full chain; 3 (S = 16) exactly ZF_MID_CHAIN fresh trials, nothing replayed; 2 (S = 16) other
-// chains of more than S / 2; 1 everything else.  Shared by the kernels and the host's prediction.
+// Branch-free MID chains (S = 16 solvers): a pass of L fresh trials with nothing lagging, ZF_MID_MIN <= L <= ZF_MID_MAX - the
+// lengths a tail shared by two passes takes before max_iter (zf_fresh_len: S < left < 2 S iterations -> two passes of
+// about left / 2), and the tail of fewer than S iterations itself.  One kernel per length (PART 3, template
+// parameter L): the registers of a chain are 12 L running sums, so each length gets the load pipeline it has room for -
+// software-pipelined register loads up to ZF_MID_REG_MAX trials, loads through LDS by DMA (no VGPR destination) above.
+// Round 3 had this body for L = 10 only - the shape of the driver's K = 20 blocks - and sent 9, 11 .. 15 through the
+// general body (a wave-uniform branch per trial: 23.8 instead of 20.7 VALU instructions per element and trial).
+constexpr int ZF_MID_MIN = 9;
+constexpr int ZF_MID_MAX = 15;
+// Which shape-specific kernel the HOST launches for a pass of `nf` fresh trials behind `lag` lagging iterations (S =
+// chain length of the solver) when it knows the shape: 0 the full chain; 3 (S = 16) a mid chain of exactly nf trials,
+// nothing replayed; 2 (S = 16) other chains of more than S / 2 fresh trials; 1 everything else.
 ZF_HD inline int zf_pass_part(int S, int lag, int nf) {
     if (lag == 0 && nf == S) return 0;
 #ifndef ZF_MID_CHAIN_OFF   // (A/B builds: the general body takes these passes)
-    if (S >= 16 && lag == 0 && nf == ZF_MID_CHAIN) return 3;
+    if (S >= 16 && lag == 0 && nf >= ZF_MID_MIN && nf <= ZF_MID_MAX) return 3;
 #endif
     if (S >= 16 && nf > S / 2) return 2;
     return 1;
+}
+// Whether the kernel PART (mid chains: of length L) runs a pass of that shape.  The general body (PART 2) also runs
+// what a mid chain could: when the host does not know the shape it launches parts 0, 1, 2 and no mid chain; when it
+// does, exactly one kernel - a pass is never claimed by two kernels of one step.
+ZF_HD inline bool zf_pass_claims(int PART, int L, int S, int lag, int nf) {
+    if (PART == 0) return lag == 0 && nf == S;
+    if (PART == 3) return lag == 0 && nf == L;
+    const bool longer = S >= 16 && nf > S / 2 && !(lag == 0 && nf == S);
+    return PART == 2 ? longer : !longer && !(lag == 0 && nf == S);
 }
 #ifndef ZF_S16_UB
 #define ZF_S16_UB 1   // units per load batch of the 16-trial chain (192 VGPRs of running sums leave room for one)
@@ -244,7 +273,14 @@ struct zf_step_args {
     int decide;               // unsharded x: decide here; sharded: the packs are gathered first (zf_decide_kernel)
     double* trace;
     int pass_seq;             // number of this step (> 0): written to ctl->pass_seq by the pass that decides in-kernel
+    // the general body (PART 2) as a FALLBACK: it runs every shape that the kernel PART fb_part (mid chains: of fb_len
+    // trials) launched beside it does not run; fb_part < 0: every shape.  (zf_predict_parts)
+    int fb_on, fb_part, fb_len;
 };
+
+// pass_log entry (low 16 bits; the high 16 are the launch tag): fresh trials | lagging iterations << 5 | passes << 10
+// (passes: 0 for a per-pass kernel = one pass; the persistent kernel counts the passes its launch ran)
+ZF_HD inline int zf_log_shape(int lag, int nf, int passes) { return (nf & 31) | ((lag & 31) << 5) | ((passes & 63) << 10); }
 
 struct zf_finalize_args {
     const double* blk_part;   // (S * ZF_NPART) x nblocks (written by the trial kernel)
@@ -403,14 +439,14 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 // and the fin_ng <= 64 group rows: 2 - 3 us, against a separate finalize launch of 15 - 26 us behind a kernel
 // boundary (round 2).  Every other workgroup has taken its ticket - has read the control block for the last time -
 // before the one that writes it gets there.
-template <int SP>
+template <int SP, bool OPAQUE_TID = false>
 __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double v) {
     constexpr int NQ = SP * ZF_NPART;
     __shared__ int s_role;
     __shared__ double s_tot[NQ];
     __shared__ double s_pack[ZF_MAX_SUB_ITERS * ZF_PACK_LEN];
     __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
-    const int t = threadIdx.x, G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int t = (int)zf_tid<OPAQUE_TID>(), G = (int)gridDim.x, b = (int)blockIdx.x;
     const int gsz = A.fin_gsz, ng = A.fin_ng;
     const bool grouped = gsz > 1;
     const bool is_max = (t % ZF_NPART == ZF_NPART - 1);
@@ -511,6 +547,34 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     }
 }
 
+// What a pass reads of the control block before its first vector load.  The per-pass kernels fill it with plain
+// (scalar) loads - the block was written by an earlier launch; the persistent multi-pass kernel (zf_persist_kernel)
+// from its own copy of the block, fetched past the caches after every in-kernel decide.
+// a wave-uniform 64-bit value into scalar registers
+__device__ __forceinline__ unsigned long long zf_uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double zf_uniform_f64(double v) {
+    return __longlong_as_double((long long)zf_uniform_u64((unsigned long long)__double_as_longlong(v)));
+}
+struct zf_pass_head {
+    int cur, prev, ring;
+    double lr, beta_next;
+    int64_t nit;
+};
+__device__ __forceinline__ zf_pass_head zf_head_of(const zf_control* c) {
+    zf_pass_head h;
+    h.cur = c->cur;
+    h.prev = c->prev;
+    h.ring = c->ring_size;
+    h.lr = c->lr;
+    h.beta_next = c->beta_next;
+    h.nit = c->nit;
+    return h;
+}
+
 // GRAD_INLINE: true  -> separable quadratic, gradient computed from d, c
 //              false -> gradient vector read from HBM (least squares; S = 1 only)
 // NT: nontemporal policy for the once-touched streams (p0, p1 loads, x+ stores)
@@ -534,22 +598,24 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
 // slot that the retry overwrites; replayed trials wrote theirs when they were fresh.
 // SP: packs per pass of the solver (rows of partials written, S <= SP: a 16-chain solver runs its short
 // passes through the 8-trial bodies and leaves the packs of trials 8 .. 15 zero)
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST, int SP = S>
-__device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds, const int lag, const int nf,
-                                              zf_d2* stage = nullptr) {
+// Returns the workgroup's row: thread t < 6 S holds quantity t % 6 of fresh trial t / 6 (0 for the other threads).
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST, int SP = S, bool OPAQUE_TID = false>
+__device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* lds, const zf_pass_head& HD, const int lag,
+                                                const int nf, zf_d2* stage = nullptr) {
     constexpr bool FULL = (MODE == 0);          // nothing replayed, S fresh trials
+    const unsigned tidx = zf_tid<OPAQUE_TID>();   // threadIdx.x (opaque per call inside the persistent kernel's pass loop)
     constexpr bool FRESH_FULL = (MODE <= 1);    // S fresh trials
-    const int cur = A.ctl->cur;
-    const int prev = A.ctl->prev;
-    const int ring = A.ctl->ring_size;
-    const double lr = A.ctl->lr;
+    const int cur = HD.cur;
+    const int prev = HD.prev;
+    const int ring = HD.ring;
+    const double lr = HD.lr;
     const int ntr = FULL ? S : (FRESH_FULL ? lag + S : lag + nf);   // chain length: iterates x_{b+1} .. x_{b+ntr} from (x_b, x_{b-1})
     double beta[S];
-    const int64_t nit = A.ctl->nit;
+    const int64_t nit = HD.nit;
     const int64_t base = nit - lag;        // iteration count the stored iterates belong to
     // momentum factor of the trial that produces iteration i + 1: ring[i % ZF_RING]; that of the
     // first trial of the pass was resolved into the control block by the previous decide step
-    beta[0] = NESTEROV ? ((FULL || lag == 0) ? A.ctl->beta_next : A.beta_ring[nit % ZF_RING]) : 0.0;
+    beta[0] = NESTEROV ? ((FULL || lag == 0) ? HD.beta_next : A.beta_ring[nit % ZF_RING]) : 0.0;
 #pragma unroll
     for (int j = 1; j < S; ++j) beta[j] = NESTEROV ? A.beta_ring[(nit + j) % ZF_RING] : 0.0;
     const double tau = A.lam * lr;   // oracle: soft_threshold(x, lam * weight)
@@ -660,10 +726,10 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
         for (int t = 0; t < A.tiles_per_wg; ++t)
             if ((int64_t)t * G + blockIdx.x < full_tiles) my_tiles = t + 1;
         const int total = my_tiles * ZF_TILE_U;
-        const int wave = threadIdx.x >> 6;
+        const int wave = tidx >> 6;
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(zf_lds_ptr)stage + wave * 1024u);
         auto unit_of = [&](int k) -> int64_t {
-            return ((int64_t)(k / ZF_TILE_U) * G + blockIdx.x) * ZF_TILE_UNITS + (k % ZF_TILE_U) * ZF_BLOCK + threadIdx.x;
+            return ((int64_t)(k / ZF_TILE_U) * G + blockIdx.x) * ZF_TILE_UNITS + (k % ZF_TILE_U) * ZF_BLOCK + tidx;
         };
         auto issue = [&](int k) {
             const int64_t i = unit_of(k);
@@ -699,7 +765,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
             auto trip = [&](int k, auto more_c, auto ahead_c) {
                 constexpr bool MORE = decltype(more_c)::value;
                 constexpr int AHEAD = decltype(ahead_c)::value;
-                const zf_d2* sp = stage + st * ZF_GLDS_STAGE_UNITS + threadIdx.x;
+                const zf_d2* sp = stage + st * ZF_GLDS_STAGE_UNITS + tidx;
                 st = (st + 1 == NST) ? 0 : st + 1;
                 const zf_d2 a = sp[0];
                 const zf_d2 o = NESTEROV ? sp[ZF_BLOCK] : a;
@@ -743,7 +809,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
                 static_assert(NST <= 3, "the run-time waits are written for 2 or 3 stages");
 #pragma unroll 1
                 for (; k < total; ++k) {
-                    const zf_d2* sp = stage + st * ZF_GLDS_STAGE_UNITS + threadIdx.x;
+                    const zf_d2* sp = stage + st * ZF_GLDS_STAGE_UNITS + tidx;
                     st = (st + 1 == NST) ? 0 : st + 1;
                     const zf_d2 a = sp[0];
                     const zf_d2 o = NESTEROV ? sp[ZF_BLOCK] : a;
@@ -794,7 +860,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
             if (tile >= full_tiles) break;
 #pragma unroll 1
             for (int u0 = 0; u0 < ZF_TILE_U; u0 += UB) {
-                const int64_t base_u = tile * ZF_TILE_UNITS + threadIdx.x + (int64_t)u0 * ZF_BLOCK;
+                const int64_t base_u = tile * ZF_TILE_UNITS + tidx + (int64_t)u0 * ZF_BLOCK;
                 zf_d2 a[UB], o[UB], q[UB], cc[UB];
                 load_batch(base_u, a, o, q, cc);
                 compute_batch(base_u, a, o, q, cc);
@@ -811,14 +877,14 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
             if ((int64_t)t * G + blockIdx.x < full_tiles) my_tiles = t + 1;
         if (my_tiles > 0) {
             zf_d2 a0[UB], o0[UB], q0[UB], c0[UB], a1[UB], o1[UB], q1[UB], c1[UB];
-            int64_t base_u = (int64_t)blockIdx.x * ZF_TILE_UNITS + threadIdx.x;
+            int64_t base_u = (int64_t)blockIdx.x * ZF_TILE_UNITS + tidx;
             load_batch(base_u, a0, o0, q0, c0);
             // (the last tile is peeled: a conditional prefetch inside the loop made the register
             //  allocator keep both buffers of both paths alive - 512 VGPRs and scratch)
             for (int t = 0; t + 1 < my_tiles; ++t) {
                 load_batch(base_u + UB * ZF_BLOCK, a1, o1, q1, c1);
                 compute_batch(base_u, a0, o0, q0, c0);
-                const int64_t next_u = ((int64_t)(t + 1) * G + blockIdx.x) * ZF_TILE_UNITS + threadIdx.x;
+                const int64_t next_u = ((int64_t)(t + 1) * G + blockIdx.x) * ZF_TILE_UNITS + tidx;
                 load_batch(next_u, a0, o0, q0, c0);
                 compute_batch(base_u + UB * ZF_BLOCK, a1, o1, q1, c1);
                 base_u = next_u;
@@ -832,7 +898,7 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     // element, after its own tiles, by the workgroup next in the round-robin
     const int64_t rem0 = full_tiles * ZF_TILE_UNITS * 2;
     if (rem0 < n && blockIdx.x == full_tiles % G) {
-        for (int64_t e = rem0 + threadIdx.x; e < n; e += ZF_BLOCK) {
+        for (int64_t e = rem0 + tidx; e < n; e += ZF_BLOCK) {
             double a = xk[e], o = NESTEROV ? xo[e] : a;
             const double q = p0[e], cc = GRAD_INLINE ? p1[e] : q;
             if constexpr (!FULL && GRAD_INLINE) {
@@ -864,64 +930,85 @@ __device__ __forceinline__ void zf_trial_body(const zf_step_args& A, double* lds
     // workgroup partials of every fresh trial of the chain: rows j * ZF_NPART + k.  All 6 S wave
     // reductions run as ONE transposing butterfly (zf_wave_reduce_multi: same pairing, hence the
     // same bits, as a butterfly per quantity), then the four wave totals are added in wave order.
-    constexpr int H = zf_chain_h(S);
+    // (an odd chain length is reduced as the next even one with a trial of zeros: without a factor of two the
+    //  butterfly transposes nothing and keeps all 6 S values alive through six levels - 316 VGPRs for S = 13)
+    constexpr int RS = S + (S > 1 ? (S & 1) : 0);
+    constexpr int H = zf_chain_h(RS);
     constexpr int NQ = S * ZF_NPART;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double sums[5 * S], maxs[S];
+    const int lane = tidx & 63, wave = tidx >> 6;
+    double sums[5 * RS], maxs[RS];
 #pragma unroll
-    for (int j = 0; j < S; ++j) {
-        sums[j * 5 + 0] = acc[j].fy;
-        sums[j * 5 + 1] = acc[j].dot;
-        sums[j * 5 + 2] = acc[j].ss;
-        sums[j * 5 + 3] = acc[j].l1;
-        sums[j * 5 + 4] = acc[j].fx;
-        maxs[j] = acc[j].mx;
+    for (int j = 0; j < RS; ++j) {
+        if (j < S) {
+            sums[j * 5 + 0] = acc[j].fy;
+            sums[j * 5 + 1] = acc[j].dot;
+            sums[j * 5 + 2] = acc[j].ss;
+            sums[j * 5 + 3] = acc[j].l1;
+            sums[j * 5 + 4] = acc[j].fx;
+            maxs[j] = acc[j].mx;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sums[j * 5 + k] = 0.0;
+            maxs[j] = 0.0;
+        }
     }
-    zf_wave_reduce_multi<5 * S, H, false>(sums, lane);
-    zf_wave_reduce_multi<S, H, true>(maxs, lane);
-    if ((lane & ((64 >> H) - 1)) == 0) {   // (S >> H trials per lane group: one when S is a power of two)
+    zf_wave_reduce_multi<5 * RS, H, false>(sums, lane);
+    zf_wave_reduce_multi<RS, H, true>(maxs, lane);
+    if ((lane & ((64 >> H) - 1)) == 0) {   // (RS >> H trials per lane group: one when RS is a power of two)
 #pragma unroll
-        for (int q = 0; q < ((5 * S) >> H); ++q) {
-            const int idx = zf_wave_reduce_multi_index<5 * S, H>(q, lane);
-            lds[wave * NQ + (idx / 5) * ZF_NPART + idx % 5] = sums[q];
+        for (int q = 0; q < ((5 * RS) >> H); ++q) {
+            const int idx = zf_wave_reduce_multi_index<5 * RS, H>(q, lane);
+            if (idx / 5 < S) lds[wave * NQ + (idx / 5) * ZF_NPART + idx % 5] = sums[q];
         }
 #pragma unroll
-        for (int q = 0; q < (S >> H); ++q)
-            lds[wave * NQ + zf_wave_reduce_multi_index<S, H>(q, lane) * ZF_NPART + 5] = maxs[q];
+        for (int q = 0; q < (RS >> H); ++q) {
+            const int tr = zf_wave_reduce_multi_index<RS, H>(q, lane);
+            if (tr < S) lds[wave * NQ + tr * ZF_NPART + 5] = maxs[q];
+        }
     }
     __syncthreads();
     double v = 0.0;   // (rows of trials S .. SP - 1: no such trial in this pass)
-    if (threadIdx.x < NQ) {
-        const int t = threadIdx.x;
+    if (tidx < NQ) {
+        const int t = tidx;
         v = lds[t];
 #pragma unroll
         for (int w = 1; w < ZF_WAVES; ++w) v = (t % ZF_NPART == 5) ? fmax(v, lds[w * NQ + t]) : v + lds[w * NQ + t];
     }
-    if (A.fin_mode == 0) {   // a zf_finalize_kernel launch follows
+    return v;
+}
+
+// what a per-pass kernel does with its row: stored plainly for the zf_finalize_kernel launch that follows (least
+// squares), or finalised - and decided - inside this launch (zf_pass_tail)
+template <int SP>
+__device__ __forceinline__ void zf_pass_finish(const zf_step_args& A, const double v) {
+    if (A.fin_mode == 0) {
         if (threadIdx.x < SP * ZF_NPART) A.blk_part[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
         return;
     }
     zf_pass_tail<SP>(A, v);
 }
 
-// PART (chains only, S > 1): a pass is launched as TWO kernels (S = 16: THREE), each of which exits at
-// once unless the pass has its shape -
+// PART (chains only, S > 1): the bodies of a pass live in separate kernels, each of which exits at once unless the
+// pass has its shape (zf_pass_claims) -
 //   0: the full chain (nothing replayed, S fresh trials: the hot, branch-free body);
 //   1: every other shape (replays, shorter chains, materialise-only) - for S = 16: of up to 8 fresh
 //      trials, through the 8-trial bodies (pack rows of trials 8 .. 15 written as zeros);
-//   2: S = 16 only: 9 .. 15 fresh trials (the shared tail before max_iter, zf_fresh_len) through the
-//      general 16-trial body - a wave-uniform branch per trial, LDS-DMA loads;
-//   3: S = 16 only: exactly ZF_MID_CHAIN = 10 fresh trials and nothing replayed - a branch-free 10-chain.
+//   2: S = 16 only: 9 .. 15 fresh trials behind any number of lagging iterations through the general 16-trial body - a
+//      wave-uniform branch per trial, LDS-DMA loads;
+//   3: S = 16 only: exactly L fresh trials and nothing replayed - a branch-free mid chain (ZF_MID_MIN .. ZF_MID_MAX).
 // One kernel holding all bodies needs the registers of the largest plus what the compiler hoists across
 // the branches (S = 16: 274 VGPRs for parts 0 + 1, ~400 for parts 1 + 2 - one wave per SIMD instead of two;
-// S = 8: 207 instead of 190); every further launch costs a kernel boundary (~1.5-4 us) per pass.
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false, int PART = 0>
+// S = 8: 207 instead of 190); every further launch costs a kernel boundary (~1.5-4 us) per pass - so the host
+// launches the ONE kernel it predicts (zf_predict_parts) and all of 0, 1, 2 only when it cannot know.
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false, int PART = 0, int L = 0>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
     static_assert(PART <= 1 || S >= 16, "the third and fourth kernels exist for chains of 16 only");
+    static_assert(PART != 3 || (L >= ZF_MID_MIN && L <= ZF_MID_MAX), "mid chains: ZF_MID_MIN .. ZF_MID_MAX trials");
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
-    constexpr bool GLDS = PART == 3 ? false : PART != 1 ? zf_uses_glds<S, PART == 0 ? 0 : 2, HIST, GRAD_INLINE>()
-                                                         : (S >= 16 && zf_uses_glds<S / 2, 1, HIST, GRAD_INLINE, S>());
+    constexpr bool GLDS = PART == 3 ? zf_uses_glds<(PART == 3 ? L : S), 0, HIST, GRAD_INLINE, S>()
+                          : PART != 1 ? zf_uses_glds<S, PART == 0 ? 0 : 2, HIST, GRAD_INLINE>()
+                                      : (S >= 16 && zf_uses_glds<S / 2, 1, HIST, GRAD_INLINE, S>());
     __shared__ zf_d2 stage[GLDS ? ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS : 1];   // the stages of the LDS-DMA pipeline (16 KiB each)
     // wave-uniform control reads (scalar loads); written by the previous step's decide
     if (A.ctl->status != ZF_RUNNING) return;
@@ -929,35 +1016,132 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     // the next pass, which belongs to the next step (one step = at most one pass: the trace / momentum / history
     // rings are sized by that)
     if (A.fin_mode != 0 && A.decide && A.ctl->pass_seq == A.pass_seq) return;
+    const zf_pass_head HD = zf_head_of(A.ctl);
     if constexpr (S == 1) {
-        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | 1;
-        zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, 1);
+        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(0, 1, 0);
+        zf_pass_finish<S>(A, zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, HD, 0, 1));
     } else {
         const int lag = A.ctl->lag;
         const int nf = zf_fresh_len(A.ctl);   // fresh trials of this chain (0: materialise only)
-        if (zf_pass_part(S, lag, nf) != PART) return;
-        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | (lag << 8) | nf;
+        if constexpr (PART == 2) {
+            if (A.fb_on ? (A.fb_part >= 0 && zf_pass_claims(A.fb_part, A.fb_len, S, lag, nf)) : !zf_pass_claims(2, 0, S, lag, nf)) return;
+        } else {
+            if (!zf_pass_claims(PART, L, S, lag, nf)) return;
+        }
+        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(lag, nf, 0);
+        double v;
         if constexpr (PART == 0) {
-            zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, 0, S, stage);
+            v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, HD, 0, S, stage);
         } else if constexpr (PART == 3) {
-            // the branch-free chain of ZF_MID_CHAIN trials through the register-load pipeline of the short chains:
-            // the HBM-bound passes of a tail shared by two passes (the driver's K = 20 blocks: 10 + 10)
-            zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, ZF_MID_CHAIN, 0, HIST, S>(A, lds, 0, ZF_MID_CHAIN);
+            // a branch-free chain of L trials: the passes of a tail shared by two passes (the driver's K = 20 blocks:
+            // 10 + 10) and the tail itself
+            v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, L, 0, HIST, S>(A, lds, HD, 0, L, stage);
         } else if constexpr (PART == 2) {
             // (nf is laundered through readfirstlane: knowing nf > S / 2 the compiler made the first
             //  trials unconditional, scheduled across them and needed 379 VGPRs instead of 227; an empty
             //  asm as the barrier gave 260)
             const int nf_opaque = __builtin_amdgcn_readfirstlane(nf);
-            zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, lag, nf_opaque, stage);
+            v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, HD, lag, nf_opaque, stage);
         } else if constexpr (S >= 16) {
             constexpr int SS = S / 2;
-            if (lag == 0 && nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 0, HIST, S>(A, lds, 0, SS, stage);
-            else if (nf == SS) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 1, HIST, S>(A, lds, lag, SS, stage);
-            else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 2, HIST, S>(A, lds, lag, nf, stage);
+            if (lag == 0 && nf == SS) v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 0, HIST, S>(A, lds, HD, 0, SS, stage);
+            else if (nf == SS) v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 1, HIST, S>(A, lds, HD, lag, SS, stage);
+            else v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 2, HIST, S>(A, lds, HD, lag, nf, stage);
         } else {
-            if (nf == S) zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1, HIST>(A, lds, lag, S);
-            else zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, lag, nf);
+            if (nf == S) v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1, HIST>(A, lds, HD, lag, S);
+            else v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, HD, lag, nf);
         }
+        zf_pass_finish<S>(A, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Several passes in ONE launch (grids whose workgroups are all resident at once: n up to ~2.5e7).
+// A per-pass launch costs what lies between two dependent kernels of a stream (8 - 10 us) and the ramp of its one
+// round of workgroups; at n = 1e7 that is a quarter of a 0.15 ms pass, at n <= 1e6 most of it.  This kernel runs up
+// to `npass` FULL-CHAIN passes back to back: every workgroup keeps its tiles, the last arriver of a pass decides it as
+// zf_pass_tail always does, and instead of ending the launch it publishes the new control block; the others wait for
+// its sequence number and go on.  It leaves - before touching anything - as soon as the next pass is not a full chain
+// (a chain broke, the tail before max_iter, a final status): the per-pass kernels the host enqueues behind it take over,
+// so it needs no other body than the hot one (all bodies in one kernel: 274+ VGPRs, one wave per SIMD).
+//
+// Memory model.  The L2s of the 8 XCDs are not coherent with each other and a launch is no longer a boundary, so
+// inside this kernel the control block is only ever read and written PAST the caches: every workgroup fetches its own
+// copy (52 words, one agent-scope load per lane) at the start of a pass; the deciding wave runs zf_decide_pass on its
+// copy in LDS and publishes it word by word, the word that carries pass_seq last, behind a counted wait.  The
+// iterates a workgroup reads in pass p + 1 are those it wrote itself in pass p (same tiles, same CU, same L2); its
+// L1 is invalidated after every wait (acquire).  Rows and tickets were write-through / atomic already.  Every wait is
+// bounded (spin_limit polls): if the grid is not co-resident after all - another process took CUs - the waiting
+// workgroups leave; the control block is only ever advanced by a complete pass, so what the host finds at its next
+// poll is a consistent state and the per-pass path goes on from it.
+// Bit-identical to per-pass launches: same geometry, same sums in the same order, same decide code.
+// Registers: the chain needs 240 VGPRs per launch and, inside the pass loop, 274 - one wave per SIMD - although nothing
+// of a pass outlives it but a few addresses.  amdgpu_waves_per_eu(2, 2) holds the allocator to 256: it then parks ~25
+// pass-loop invariants in scratch, stored once per launch and loaded once per PASS, outside the tile loops
+// (tests/test_abi.py checks exactly that: a bounded private segment, no scratch instruction at loop depth >= 2).
+template <bool NESTEROV, bool BOX, bool NT>
+__global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void zf_persist_kernel(zf_step_args A, int npass, unsigned spin_limit) {
+    constexpr int S = ZF_MAX_SUB;
+    constexpr int CW = (int)(sizeof(zf_control) / 8);
+    constexpr int SEQ_WORD = (int)(offsetof(zf_control, pass_seq) / 8);   // (shares its word with pend_status)
+    static_assert(sizeof(zf_control) % 8 == 0 && CW <= 64, "one lane per word of the control block");
+    static_assert(S == 16, "the persistent kernel holds the 16-trial full chain");
+    __shared__ double lds[ZF_WAVES * S * ZF_NPART];
+    __shared__ zf_d2 stage[ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS];
+    __shared__ zf_control s_ctl;
+    __shared__ int s_go;
+    unsigned long long* gw = reinterpret_cast<unsigned long long*>(A.ctl_rw);
+    unsigned long long* lw = reinterpret_cast<unsigned long long*>(&s_ctl);
+#pragma unroll 1
+    for (int p = 0; p < npass; ++p) {
+        const int seq = A.pass_seq + p;
+        if (threadIdx.x < CW) lw[threadIdx.x] = __hip_atomic_load(gw + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ctl.status != ZF_RUNNING || s_ctl.lag != 0 || zf_fresh_len(&s_ctl) != S) return;   // (the same for every workgroup)
+        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(0, S, p + 1);
+        // (the copy lives in LDS: what the body takes from it is wave-uniform, and is moved to scalar registers - left
+        //  in vector registers, lr, nit and the sixteen momentum factors loaded through them cost the chain its second
+        //  wave per SIMD)
+        zf_pass_head HD;
+        HD.cur = __builtin_amdgcn_readfirstlane(s_ctl.cur);
+        HD.prev = __builtin_amdgcn_readfirstlane(s_ctl.prev);
+        HD.ring = __builtin_amdgcn_readfirstlane(s_ctl.ring_size);
+        HD.lr = zf_uniform_f64(s_ctl.lr);
+        HD.beta_next = zf_uniform_f64(s_ctl.beta_next);
+        HD.nit = (int64_t)zf_uniform_u64((unsigned long long)s_ctl.nit);
+        const double v = zf_trial_body<true, NESTEROV, BOX, NT, S, 0, false, S, true>(A, lds, HD, 0, S, stage);
+        zf_step_args T = A;           // this pass: decided on the workgroup's own copy of the block
+        T.ctl_rw = &s_ctl;
+        T.ctl = &s_ctl;
+        T.pass_seq = seq;
+        T.decide = 1;
+        zf_pass_tail<S, true>(T, v);
+        __syncthreads();
+        if (s_ctl.pass_seq == seq) {
+            // this workgroup decided the pass (zf_pass_tail left its number in the copy): publish the block
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x;
+                if (lane < CW && lane != SEQ_WORD)
+                    __hip_atomic_store(gw + lane, lw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(gw + SEQ_WORD, lw[SEQ_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (threadIdx.x == 0) s_go = 1;
+        } else if (threadIdx.x == 0) {
+            const int* seq_ptr = &A.ctl_rw->pass_seq;
+            int ok = 0;
+            for (unsigned k = 0; k < spin_limit; ++k) {
+                if (__hip_atomic_load(seq_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) {
+                    ok = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_go = ok;
+        }
+        __syncthreads();
+        if (!s_go) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }
 

@@ -19,6 +19,7 @@
 #include "zf_kernels_gemv.h"
 #include "zf_kernels_ls_small.h"
 #include "zf_kernels_step.h"
+#include "zf_trial_launch.h"
 
 thread_local char zf_errbuf[512] = "";
 
@@ -194,7 +195,14 @@ struct zf_solver {
     // Which shape-specific kernel a pass needs is decided on the device; the host PREDICTS it from the control
     // block of its last poll (zf_predict_parts) and launches only that one.  A wrong prediction costs passes that
     // do nothing (no kernel finds its shape, the control block stays as it is), never a wrong result.
-    int part_mask = 15;
+    int part_mask = 7;                    // ZF_K_* bits (ZF_K_ALL until a prediction says otherwise)
+    int mid_len = 0;                      // ZF_K_MID: trials of the mid chain
+    int fb_part = -1, fb_len = 0;         // ZF_K_FALLBACK: the general body runs what this kernel does not (-1: everything)
+    // several full-chain passes per launch (zf_persist_kernel): grids the device holds at once
+    int persist_cap = -1;                 // co-resident workgroups of the persistent kernel (-1: not asked yet)
+    bool persist = true;                  // ZF_PERSIST=0 at creation: always one launch per pass
+    unsigned persist_spin = 1u << 20;     // polls a workgroup waits for a pass to be decided before it gives up
+    int64_t persist_launches = 0, persist_passes = 0;
     bool speculate = true;                // ZF_SPECULATE=0 at creation: always launch every shape
     int64_t steps_issued = 0, kernels_issued = 0;   // trial steps and the shape kernels launched for them (zf_solver_launch_counts)
     int pass_seq = 0;                     // step counter (zf_step_args.pass_seq)
@@ -259,6 +267,8 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     s->desc = *desc;
     s->opt = *opt;
     if (const char* e = getenv("ZF_SPECULATE")) s->speculate = atoi(e) != 0;
+    if (const char* e = getenv("ZF_PERSIST")) s->persist = atoi(e) != 0;
+    if (const char* e = getenv("ZF_PERSIST_SPIN_LIMIT")) s->persist_spin = (unsigned)strtoul(e, nullptr, 10);
     s->stream = reinterpret_cast<hipStream_t>(stream);
     s->box = !(desc->box_lo == -INFINITY && desc->box_hi == INFINITY);
     const int64_t n = desc->n;
@@ -371,59 +381,49 @@ extern "C" int zf_solver_destroy(zf_solver* s) {
 }
 
 // ---- launches ---------------------------------------------------------------
-// one pass = the full-chain kernel + (chains only) the kernel for every other shape (chains of 16: two,
-// for short and for long chains); each exits at once when the pass has not its shape (zf_trial_kernel, PART)
-template <bool GI, bool NEST, bool BOX, bool NT, int S, bool HIST>
-static void zf_launch_trial_parts(zf_solver* s, const zf_step_args& a) {
-    dim3 g(s->grid), b(ZF_BLOCK);
-    const int mask = s->part_mask;   // which of the shape-specific kernels this pass launches (zf_predict_parts)
-    if (mask & 1) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 0>), g, b, 0, s->stream, a);
-    if constexpr (S > 1)
-        if (mask & 2) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 1>), g, b, 0, s->stream, a);
-    if constexpr (S >= 16) {
-        if (mask & 4) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 2>), g, b, 0, s->stream, a);
-        if (mask & 8) hipLaunchKernelGGL((zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, 3>), g, b, 0, s->stream, a);
-    }
-}
+// Bits of zf_solver::part_mask: which shape-specific kernels a step launches (zf_trial_kernel, PART).  Each exits at
+// once unless the pass has its shape (zf_pass_claims).
+enum {
+    ZF_K_FULL = 1,       // PART 0: the full chain
+    ZF_K_SHORT = 2,      // PART 1: up to S / 2 fresh trials behind the lagging iterations, materialise-only passes
+    ZF_K_GENERAL = 4,    // PART 2 (S = 16): the general body on the shapes of its own (more than S / 2 fresh trials)
+    ZF_K_MID = 8,        // PART 3 (S = 16): the branch-free mid chain of s->mid_len trials
+    ZF_K_FALLBACK = 16,  // PART 2 as the fallback: every shape the kernel named by s->fb_part / fb_len does NOT run (-1: every shape)
+    ZF_K_ALL = ZF_K_FULL | ZF_K_SHORT | ZF_K_GENERAL,   // nothing is known: between them these three run every shape
+};
 
-// history-recording variants (nontemporal policy only: the history is write-once)
-template <bool GI, int S>
-static void zf_launch_trial_hist(zf_solver* s, const zf_step_args& a) {
-    const bool nest = s->opt.nesterov != 0;
-    if (nest && s->box) zf_launch_trial_parts<GI, true, true, true, S, true>(s, a);
-    else if (nest) zf_launch_trial_parts<GI, true, false, true, S, true>(s, a);
-    else if (s->box) zf_launch_trial_parts<GI, false, true, true, S, true>(s, a);
-    else zf_launch_trial_parts<GI, false, false, true, S, true>(s, a);
-}
-
-template <bool GI, bool NT, int S>
-static void zf_launch_trial_t3(zf_solver* s, const zf_step_args& a) {
-    const bool nest = s->opt.nesterov != 0;
-    if (nest && s->box) zf_launch_trial_parts<GI, true, true, NT, S, false>(s, a);
-    else if (nest) zf_launch_trial_parts<GI, true, false, NT, S, false>(s, a);
-    else if (s->box) zf_launch_trial_parts<GI, false, true, NT, S, false>(s, a);
-    else zf_launch_trial_parts<GI, false, false, NT, S, false>(s, a);
-}
-template <bool GI, bool NT>
-static void zf_launch_trial_t2(zf_solver* s, const zf_step_args& a) {
-    if constexpr (GI) {   // temporal blocking needs the gradient inline (separable f)
-        if (s->sub == 16) return zf_launch_trial_t3<GI, NT, 16>(s, a);
-        if (s->sub == 8) return zf_launch_trial_t3<GI, NT, 8>(s, a);
-        if (s->sub == 4) return zf_launch_trial_t3<GI, NT, 4>(s, a);
-        if (s->sub == 2) return zf_launch_trial_t3<GI, NT, 2>(s, a);
+static void zf_launch_trial_kernels(zf_solver* s, const zf_step_args& a, bool grad_inline) {
+    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+    const int mask = s->part_mask;
+    const int grid = s->grid;
+    hipStream_t st = s->stream;
+    if (!grad_inline) {   // least squares: one trial per pass
+        if (s->hist) zf_launch_hist(v, false, 1, 0, grid, st, a);
+        else zf_launch_vec(v, grid, st, a);
+        return;
     }
-    zf_launch_trial_t3<GI, NT, 1>(s, a);
-}
-template <bool GI>
-static void zf_launch_trial_t(zf_solver* s, const zf_step_args& a) {
     if (s->hist) {   // (zf_solver_set_history allowed only chain lengths 1 and 8)
-        if constexpr (GI) {
-            if (s->sub == 8) return zf_launch_trial_hist<GI, 8>(s, a);
-        }
-        return zf_launch_trial_hist<GI, 1>(s, a);
+        const int S = s->sub == 8 ? 8 : 1;
+        if (mask & ZF_K_FULL) zf_launch_hist(v, true, S, 0, grid, st, a);
+        if (S > 1 && (mask & ZF_K_SHORT)) zf_launch_hist(v, true, S, 1, grid, st, a);
+        return;
     }
-    if (s->nt) zf_launch_trial_t2<GI, true>(s, a);
-    else zf_launch_trial_t2<GI, false>(s, a);
+    if (s->sub >= 16) {
+        if (mask & ZF_K_FULL) zf_launch_s16_full(v, grid, st, a);
+        if (mask & ZF_K_SHORT) zf_launch_s16_short(v, grid, st, a);
+        if (mask & ZF_K_MID) zf_launch_s16_mid(v, s->mid_len, grid, st, a);   // (zf_predict_parts checked that it exists)
+        if (mask & ZF_K_GENERAL) zf_launch_s16_general(v, grid, st, a);
+        if (mask & ZF_K_FALLBACK) {
+            zf_step_args f = a;
+            f.fb_on = 1;
+            f.fb_part = s->fb_part;
+            f.fb_len = s->fb_len;
+            zf_launch_s16_general(v, grid, st, f);
+        }
+        return;
+    }
+    if (mask & ZF_K_FULL) zf_launch_chain(v, s->sub, 0, grid, st, a);
+    if (s->sub > 1 && (mask & ZF_K_SHORT)) zf_launch_chain(v, s->sub, 1, grid, st, a);
 }
 
 // second launch of a step: partials -> pack (+ decide when x is unsharded)
@@ -509,42 +509,90 @@ static bool zf_fin_kernel_mode() {
     return on;
 }
 
-// The kernels of the next pass (bit p = PART p of zf_trial_kernel), and the shadow control block moved past that pass
-// on the assumption that every fresh trial is accepted and nothing terminates but max_iter - true for whole chunks
-// in the regime a line search settles in.  The shape rule is the kernel's own (zf_trial_kernel, zf_fresh_len).
-// All kernels when nothing is known, the exchange is host-driven, or ZF_SPECULATE=0; after a chunk that saw a rejection
-// the two a pass can need far from max_iter, all of them near it.
+// grids of at most this many workgroups are latency-bound: a second (idle) launch per pass costs more than a slower body
+constexpr int ZF_SMALL_GRID = 512;
+
+// move the shadow control block past a pass on the assumption that every fresh trial is accepted and nothing
+// terminates but max_iter - true for whole chunks in the regime a line search settles in
+static void zf_shadow_advance(zf_control& c) {
+    if (c.pend_status != 0) {
+        c.lag = 0;
+        if (c.pend_status > 0) c.status = c.pend_status;
+        c.pend_status = 0;
+        return;
+    }
+    c.nit += zf_fresh_len(&c);
+    c.lag = 0;
+    if (c.nit >= c.max_iter) c.status = ZF_MAXITER;
+}
+
+// The kernels of the next step (ZF_K_* bits; s->mid_len, s->fb_part, s->fb_len beside them), and the shadow control
+// block moved past that pass.  The shape rule is the kernel's own (zf_pass_part, zf_fresh_len).
+// * nothing known (no poll yet, a host-driven exchange, ZF_SPECULATE=0): the three kernels that between them run every shape;
+// * the shadow is what the device holds, or what it holds if no chain broke since the poll: the ONE kernel of that shape;
+// * the last chunk saw rejections ("careful"): the first step after the poll is still exact; behind it the optimistic
+//   prediction plus the general body as its complement (whatever shape the pass has, exactly one of the two runs it)
+//   - on small grids, where an idle launch costs more than the general body loses, the general body alone;
+// * the shadow says the solve is over (and the device may not be: a chain broke): the general body on any shape.
+// A wrong prediction costs passes that do nothing (no kernel finds its shape, the control block stays as it is) until
+// the next poll - never a wrong result.
 static int zf_predict_parts(zf_solver* s) {
     const bool off = !s->speculate;   // (ZF_SPECULATE=0 when the solver was created)
     // (x sharded: only with the library's communicator, whose decide step checks that every rank's packs are those
     //  of this step - all ranks predict from identical control blocks; a host-driven exchange launches everything)
     if (off || s->sub <= 1 || !s->shadow_valid || (s->desc.world != 1 && !s->comm) ||
         s->desc.kind != ZF_PROBLEM_DIAG_QUAD_L1 || zf_fin_kernel_mode())
-        return 15;
+        return ZF_K_ALL;
     zf_control& c = s->shadow;
-    if (c.status != ZF_RUNNING) return 15;   // (expected to be finished; if the device is not - a chain broke - any shape may be due)
     const int S = s->sub;
-    if (s->careful) {
-        // Chains have been breaking: what the device will need is not known - but far from max_iter it is one of
-        // two shapes.  The device has accepted at most S iterations per step since the poll, so at least `left`
-        // remain; with left >= 2 S a pass with nothing lagging is a full chain (zf_fresh_len: PART 0) and a pass
-        // behind lagging iterations, or one that only materialises, has at most S / 2 fresh trials (PART 1).
-        const int64_t left = c.max_iter - c.nit - (int64_t)S * s->steps_since_poll;
-        return left >= 2 * (int64_t)S ? 3 : 15;
+    const bool s16 = S >= 16;
+    if (c.status != ZF_RUNNING) {
+        if (!s16) return ZF_K_ALL;
+        s->fb_part = -1;
+        return ZF_K_FALLBACK;
     }
     const int lag = c.lag;
     const int nf = zf_fresh_len(&c);
-    const int part = zf_pass_part(S, lag, nf);
-    if (c.pend_status != 0) {
-        c.lag = 0;
-        if (c.pend_status > 0) c.status = c.pend_status;
-        c.pend_status = 0;
-    } else {
-        c.nit += nf;
-        c.lag = 0;
-        if (c.nit >= c.max_iter) c.status = ZF_MAXITER;
+    int part = zf_pass_part(S, lag, nf);
+    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+    if (part == 3 && !zf_have_s16_mid(v, nf)) part = 2;
+    int mask = part == 3 ? ZF_K_MID : (1 << part);
+    s->mid_len = nf;
+    if (s->careful && s->steps_since_poll > 0) {
+        if (!s16) {
+            mask = ZF_K_ALL;
+        } else if (s->grid <= ZF_SMALL_GRID) {
+            s->fb_part = -1;
+            mask = ZF_K_FALLBACK;
+        } else {
+            s->fb_part = part;
+            s->fb_len = nf;
+            mask |= ZF_K_FALLBACK;
+        }
     }
-    return 1 << part;
+    zf_shadow_advance(c);
+    return mask;
+}
+
+// How many of the next `max_steps` steps can run as ONE launch of the persistent kernel: consecutive full chains by
+// the shadow's account, on a grid the device holds at once.  < 2: launch per pass.
+static int zf_persist_run(zf_solver* s, int64_t max_steps) {
+    if (!s->persist || !s->speculate || s->careful || !s->shadow_valid || s->sub < 16 || s->hist || s->comm ||
+        s->desc.world != 1 || s->desc.kind != ZF_PROBLEM_DIAG_QUAD_L1 || zf_fin_kernel_mode() || max_steps < 2)
+        return 0;
+    if (s->persist_cap < 0) {
+        const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+        s->persist_cap = zf_persist_capacity(v);
+    }
+    if (s->grid > s->persist_cap) return 0;
+    zf_control c = s->shadow;
+    int run = 0;
+    while (run < max_steps && run < 60 && c.status == ZF_RUNNING && c.lag == 0 && c.pend_status == 0 &&
+           zf_fresh_len(&c) == s->sub) {
+        zf_shadow_advance(c);
+        run += 1;
+    }
+    return run;
 }
 
 static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false) {
@@ -590,17 +638,17 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             s->pass_seq = s->pass_seq >= 0x7ffffff0 ? 1 : s->pass_seq + 1;
             a.pass_seq = s->pass_seq;
         }
-        s->part_mask = (dry || !(decide_in_launch || s->comm)) ? 15 : zf_predict_parts(s);
+        s->part_mask = (dry || !(decide_in_launch || s->comm)) ? ZF_K_ALL : zf_predict_parts(s);
         if (!dry) {
             s->steps_since_poll += 1;
-            const int shapes = s->part_mask & (s->sub >= 16 ? 15 : s->sub > 1 ? 3 : 1);
+            const int shapes = s->part_mask & (s->sub >= 16 ? 31 : s->sub > 1 ? 3 : 1);
             s->steps_issued += 1;
             s->kernels_issued += __builtin_popcount(shapes);
         }
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
-        zf_launch_trial_t<true>(s, a);
+        zf_launch_trial_kernels(s, a, true);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
-        s->part_mask = 15;
+        s->part_mask = ZF_K_ALL;
         if (!dry && fin_kernel) zf_launch_finalize(s, d.world == 1 && decide_in_launch);
     } else if (s->ls_small && !dry && decide_in_launch) {
         // cache-resident A: the whole trial in two launches (zf_kernels_ls_small.h)
@@ -680,7 +728,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         a.p0 = s->grad;
         a.p1 = nullptr;
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
-        zf_launch_trial_t<false>(s, a);
+        zf_launch_trial_kernels(s, a, false);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
         // (3) s+ = A x+ ; f(x+).  Sharded x (column blocks): this rank's A_p x_p+ goes to
         // s_part; the caller gathers the parts and zf_solver_enqueue_trial_finish() adds them.
@@ -705,6 +753,57 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
     return ZF_OK;
 }
 
+// `run` >= 2 consecutive full-chain passes (zf_persist_run) as ONE launch of the persistent kernel; the shadow control
+// block moves past all of them.  One event pair and one log slot for the launch: the kernel logs how many passes it ran.
+static int zf_launch_persist(zf_solver* s, int run) {
+    const zf_problem_desc& d = s->desc;
+    zf_step_args a;
+    zf_fill_step_args(s, a);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s->timing) {
+        a.pass_log = s->pass_log;
+        a.pass_slot = (int)(s->launches % ZF_PASS_LOG);
+        a.pass_tag = (int)(s->launches & 0x7fff) << 16;
+        s->launches += 1;
+        if (s->ev_used == s->ev_pool.size()) {
+            hipEvent_t x, y;
+            ZF_HIP(hipEventCreate(&x));
+            ZF_HIP(hipEventCreate(&y));
+            s->ev_pool.emplace_back(x, y);
+        }
+        e0 = s->ev_pool[s->ev_used].first;
+        e1 = s->ev_pool[s->ev_used].second;
+        s->ev_used++;
+    }
+    a.p0 = d.d;
+    a.p1 = d.c;
+    a.fin_mode = 1;
+    zf_fin_groups(s->grid, &a.fin_gsz, &a.fin_ng);
+    a.grp_part = s->grp_part;
+    a.fin_cnt = s->fin_cnt;
+    a.fin_scale_f = 0.5;
+    a.fin_scale_g = d.lam;
+    a.pack = s->pack_local;
+    a.ctl_rw = s->ctl;
+    a.decide = 1;
+    a.trace = s->trace;
+    if (s->pass_seq >= 0x7ffffff0 - run) s->pass_seq = 0;
+    a.pass_seq = s->pass_seq + 1;    // pass p of the launch is step pass_seq + 1 + p
+    s->pass_seq += run;
+    for (int k = 0; k < run; ++k) zf_shadow_advance(s->shadow);
+    s->steps_since_poll += run;
+    s->steps_issued += run;
+    s->kernels_issued += 1;
+    s->persist_launches += 1;
+    s->persist_passes += run;
+    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+    if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
+    zf_launch_s16_persist(v, s->grid, s->stream, a, run, s->persist_spin);
+    if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+    ZF_HIP(hipGetLastError());
+    return ZF_OK;
+}
+
 // sharded least squares, second half of a trial: s+ = sum over ranks of A_p x_p+ (rank
 // order), f(x+), local pack (f values contributed by rank 0 only: they are replicated)
 extern "C" int zf_solver_enqueue_trial_finish(zf_solver* s) {
@@ -724,7 +823,7 @@ extern "C" int zf_solver_enqueue_trial_finish(zf_solver* s) {
         zf_fill_step_args(s, a);
         a.p0 = s->grad;
         a.p1 = nullptr;
-        zf_launch_trial_t<false>(s, a);
+        zf_launch_trial_kernels(s, a, false);
         const int V = (n % 2 == 0) ? 2 : 1;
         zf_ring3 xr = {{s->xb[0], s->xb[1], s->xb[2]}};
         int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
@@ -1039,6 +1138,10 @@ extern "C" int zf_solver_launch_counts(zf_solver* s, int64_t* out, int64_t count
     ZF_REQUIRE(count >= 2, "zf_solver_launch_counts: the output holds fewer than 2 values");
     out[0] = s->steps_issued;
     out[1] = s->kernels_issued;
+    if (count >= 4) {   // (ABI 5) launches of the persistent multi-pass kernel and the steps they covered
+        out[2] = s->persist_launches;
+        out[3] = s->persist_passes;
+    }
     return ZF_OK;
 }
 
@@ -1140,6 +1243,13 @@ extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
     for (int64_t k = 0; k < steps; ++k) {
         int rc;
         if (!s->comm) {
+            // full chains ahead on a grid the device holds at once: several passes in one launch
+            const int run = zf_persist_run(s, steps - k);
+            if (run >= 2) {
+                if ((rc = zf_launch_persist(s, run))) return rc;
+                k += run - 1;
+                continue;
+            }
             if ((rc = zf_launch_trial(s, true))) return rc;
             continue;
         }
@@ -1166,7 +1276,7 @@ static void zf_set_tiles(zf_solver* s, int tiles) {
 // accept / reject decision - so it is a FUNCTION OF n ONLY (never of a timing measurement, the
 // chain length or the device found at run time): the same problem takes the same decisions in every
 // process, on every rank layout with equal shard sizes, for every S and after every restore.
-// Below 4096 tiles (64 MiB per stream) the launch is latency-bound: T = 1.  From there on the grid is a
+// Up to 512 tiles: T = 1.  From there on the grid is a
 // round or more deep and T follows the rounds: the chained kernels keep two workgroups per CU resident - 512
 // on the 256 CUs of an MI355X - and a workgroup costs its T tiles plus ~0.3 of a tile for its start and
 // epilogue (6 S wave reductions), so a pass takes  rounds(T) x (T + 0.3)  tile times with
@@ -1177,15 +1287,19 @@ static void zf_set_tiles(zf_solver* s, int tiles) {
 // (Round 1 picked T by timing; tools/tune_trial.hip keeps that experiment.)  ZF_TILES_PER_WG=<n>
 // overrides it for experiments and changes the rounding of the sums with it.
 static int zf_tiles_for(int64_t ntiles) {
-    if (ntiles < 4096) return 1;
     constexpr int64_t SLOTS = 512;
-    int best_t = 8;
+    if (ntiles <= SLOTS) return 1;
+    // (round 4) between one round of single-tile workgroups and 4096 tiles the same cost rule over T = 1 .. 8: whole
+    // rounds here too - n = 2e6 runs ONE round of 489 workgroups of 2 tiles instead of two rounds of single tiles - and
+    // a grid the device holds at once, which is what lets several passes share a launch (zf_persist_kernel)
+    const int t_lo = ntiles < 4096 ? 1 : 8, t_hi = ntiles < 4096 ? 8 : ZF_MAX_TILES_PER_WG;
+    int best_t = t_lo;
     double best_cost = 0.0;
-    for (int t = 8; t <= ZF_MAX_TILES_PER_WG; ++t) {
+    for (int t = t_lo; t <= t_hi; ++t) {
         const int64_t wgs = (ntiles + t - 1) / t;
         const int64_t rounds = (wgs + SLOTS - 1) / SLOTS;
         const double cost = (double)rounds * ((double)t + 0.3);
-        if (t == 8 || cost < best_cost - 1e-9) {
+        if (t == t_lo || cost < best_cost - 1e-9) {
             best_cost = cost;
             best_t = t;
         }
@@ -1241,15 +1355,17 @@ static int zf_collect_timing(zf_solver* s, bool log_in_mail = false) {
             const int entry = log[launch % ZF_PASS_LOG];
             // the launch found the solve finished and exited: the slot still holds what an earlier launch wrote
             if (entry < 0 || (entry >> 16) != (int)(launch & 0x7fff)) continue;
-            const int shape = entry & 0xffff;
-            if ((shape >> 8) == 0 && (shape & 0xff) == s->sub) {
+            const int shape = entry & 0xffff;   // zf_log_shape: fresh trials | lagging iterations << 5 | passes << 10
+            const int nf = shape & 31, lag = (shape >> 5) & 31, cnt = (shape >> 10) & 63;
+            if (lag == 0 && nf == s->sub) {
+                // (a persistent launch ran cnt full-chain passes back to back: its duration counts for all of them)
                 s->ms_full += ms;
-                s->n_full += 1;
+                s->n_full += cnt > 0 ? cnt : 1;
             } else {
                 s->ms_part += ms;
                 s->n_part += 1;
-                s->fresh_part += shape & 0xff;
-                s->lag_part += shape >> 8;
+                s->fresh_part += nf;
+                s->lag_part += lag;
             }
         }
     }

@@ -1,0 +1,44 @@
+// zf_trial_launch.h - host-side launchers of the shape-specific trial kernels.
+//
+// zf_trial_kernel has ~130 instantiations (chain length x shape x momentum x box x store policy x history); in one
+// translation unit they compiled for 2.5 minutes on one core.  Each group of kernels now lives in a translation unit
+// of its own (zf_trial_*.hip) behind one plain function; zf_solver.hip only dispatches.
+#pragma once
+#include "zf_kernels_step.h"
+
+struct zf_trial_sel {
+    bool nest, box, nt;
+};
+
+// chains of 16 (the default): the full chain (PART 0), the short bodies (PART 1), the general body (PART 2),
+// the branch-free mid chains (PART 3, `len` trials; false: no such kernel for this variant - the caller launches the
+// general body instead) and the persistent multi-pass kernel of the full chain
+void zf_launch_s16_full(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
+void zf_launch_s16_short(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
+void zf_launch_s16_general(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
+bool zf_launch_s16_mid(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a);
+bool zf_have_s16_mid(const zf_trial_sel& v, int len);
+void zf_launch_s16_persist(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a, int npass, unsigned spin_limit);
+// workgroups of the persistent kernel the device holds at once (0: could not be determined)
+int zf_persist_capacity(const zf_trial_sel& v);
+// chains of 8 / 4 / 2 (part 0: full chain, part 1: every other shape) and single trials (S = 1, part 0)
+void zf_launch_chain(const zf_trial_sel& v, int S, int part, int grid, hipStream_t st, const zf_step_args& a);
+// history-recording kernels (streaming return_all; nontemporal policy only): separable S = 8 / 1, gradient vector S = 1
+void zf_launch_hist(const zf_trial_sel& v, bool grad_inline, int S, int part, int grid, hipStream_t st, const zf_step_args& a);
+// gradient vector read from HBM (least squares), S = 1
+void zf_launch_vec(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
+
+// CALL(NEST, BOX, NT) for the variant `v`
+#define ZF_SEL_NBT(v, CALL)                                  \
+    do {                                                     \
+        if ((v).nest && (v).box && (v).nt) { CALL(true, true, true); }          \
+        else if ((v).nest && (v).box) { CALL(true, true, false); }              \
+        else if ((v).nest && (v).nt) { CALL(true, false, true); }               \
+        else if ((v).nest) { CALL(true, false, false); }                        \
+        else if ((v).box && (v).nt) { CALL(false, true, true); }                \
+        else if ((v).box) { CALL(false, true, false); }                         \
+        else if ((v).nt) { CALL(false, false, true); }                          \
+        else { CALL(false, false, false); }                                     \
+    } while (0)
+#define ZF_LAUNCH_TRIAL(GI, N, B, T, S, HIST, PART, L) \
+    hipLaunchKernelGGL((zf_trial_kernel<GI, N, B, T, S, HIST, PART, L>), dim3(grid), dim3(ZF_BLOCK), 0, st, a)

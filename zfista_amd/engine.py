@@ -273,6 +273,12 @@ class DeviceSolver:
         _lib.check(self.lib.zf_solver_launch_counts(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
         return int(out[0]), int(out[1])
 
+    def persist_counts(self):
+        """(launches of the persistent multi-pass kernel, steps those launches covered) since the solver was created."""
+        out = np.zeros(4, dtype=np.int64)
+        _lib.check(self.lib.zf_solver_launch_counts(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
+        return int(out[2]), int(out[3])
+
     def pass_stats_ex(self):
         """pass_stats() plus (fresh trials, replayed iterations) the other passes carried in total."""
         out = np.zeros(6)
