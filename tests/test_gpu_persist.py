@@ -1,9 +1,11 @@
-"""GPU: several passes per launch (zf_persist_kernel) and the branch-free mid chains (PART 3, 9 .. 15 trials).
+"""GPU: several passes per launch (zf_persist_kernel, opt-in: ZF_PERSIST=1) and the branch-free mid chains (PART 3, 9 ..
+15 trials).
 
-On grids the device holds at once (n up to ~2.5e7) consecutive full-chain passes share ONE launch: the last arriver of
-a pass decides it and publishes the control block past the caches, the other workgroups wait for its sequence number.
-Everything a per-pass launch produces - trace rows, iterates, lr / trial sequences, statuses - must come out bit for bit
-the same (ZF_PERSIST=0 switches the persistent kernel off), whatever ends a launch early: a rejected trial, a
+On grids the device holds at once (n up to ~2.5e7) consecutive full-chain passes can share ONE launch: the last arriver
+of a pass decides it and publishes what the next pass needs past the caches, the other workgroups wait for its sequence
+number.  Measured (profiles/r04_persist_*): the in-kernel barrier costs what the kernel boundary costs, so the
+persistent kernel is OFF by default - but it is kept correct: everything a per-pass launch produces - trace rows,
+iterates, lr / trial sequences, statuses - must come out bit for bit the same, whatever ends a launch early: a rejected trial, a
 termination in the middle of a chain, the tail before max_iter.  The tail lengths 9 .. 15 each have a kernel of their
 own; S = 16 must equal S = 1 for every max_iter that produces them."""
 import numpy as np
@@ -62,10 +64,10 @@ def test_persistent_passes_equal_per_pass_launches(case, monkeypatch):
     n, opts = PERSIST_CASES[case]
     prob = _pdiag(n, seed=2 + case)
     x0 = np.zeros(n)
-    monkeypatch.setenv("ZF_PERSIST", "0")
+    monkeypatch.delenv("ZF_PERSIST", raising=False)
     ref = _run(prob, x0, opts)
     assert ref["persist"] == (0, 0)
-    monkeypatch.delenv("ZF_PERSIST")
+    monkeypatch.setenv("ZF_PERSIST", "1")
     for chunk in (64, 5, 2):
         got = _run(prob, x0, opts, chunk=chunk)
         _same(got, ref)
@@ -75,7 +77,8 @@ def test_persistent_passes_equal_per_pass_launches(case, monkeypatch):
     _same(one, ref)
 
 
-def test_persistent_kernel_is_not_used_beyond_the_resident_grid():
+def test_persistent_kernel_is_not_used_beyond_the_resident_grid(monkeypatch):
+    monkeypatch.setenv("ZF_PERSIST", "1")
     n = 30_000_000     # two rounds of workgroups: not co-resident
     r = _run(_pdiag(n, seed=9), np.zeros(n), dict(lr=0.45, nesterov=True, tol=0.0, max_iter=48))
     assert r["persist"] == (0, 0) and r["nit"] == 48

@@ -276,6 +276,8 @@ struct zf_step_args {
     // the general body (PART 2) as a FALLBACK: it runs every shape that the kernel PART fb_part (mid chains: of fb_len
     // trials) launched beside it does not run; fb_part < 0: every shape.  (zf_predict_parts)
     int fb_on, fb_part, fb_len;
+    // the persistent kernel: pass descriptors, one 128-byte line per group of the finalisation (zf_pass_desc)
+    unsigned long long* pdesc;
 };
 
 // pass_log entry (low 16 bits; the high 16 are the launch tag): fresh trials | lagging iterations << 5 | passes << 10
@@ -439,7 +441,9 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 // and the fin_ng <= 64 group rows: 2 - 3 us, against a separate finalize launch of 15 - 26 us behind a kernel
 // boundary (round 2).  Every other workgroup has taken its ticket - has read the control block for the last time -
 // before the one that writes it gets there.
-template <int SP, bool OPAQUE_TID = false>
+// FETCH_CTL (the persistent kernel): the deciding wave first fetches the control block past the caches from A.ctl
+// (global) into A.ctl_rw (its workgroup's LDS copy) and decides on that copy.
+template <int SP, bool OPAQUE_TID = false, bool FETCH_CTL = false>
 __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double v) {
     constexpr int NQ = SP * ZF_NPART;
     __shared__ int s_role;
@@ -482,20 +486,31 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     // 32 rows: the rows are read write-through / sc1, every load misses the caches by design).
     auto sum_rows = [&](const double* rows, int count) -> double {   // rows: quantity t of row 0; rows are NQ apart
         double acc = 0.0, comp = 0.0;
+        auto add = [&](double p) {
+            if (is_max) {
+                acc = fmax(acc, p);
+            } else {
+                const double tsum = acc + p;
+                comp += (fabs(acc) >= fabs(p)) ? (acc - tsum) + p : (p - tsum) + acc;
+                acc = tsum;
+            }
+        };
+        if (count > 32 && count <= 64) {
+            // the <= 64 group rows of the last level: ALL in flight at once - one round trip to memory (~2 us on the
+            // critical path of every pass) instead of two; same additions in the same order
+            double p[64];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) p[u] = (u < count) ? zf_consume(rows + (int64_t)u * NQ) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 64; ++u) add(p[u]);
+            return is_max ? acc : acc + comp;
+        }
         for (int k0 = 0; k0 < count; k0 += 32) {
             double p[32];
 #pragma unroll
             for (int u = 0; u < 32; ++u) p[u] = (k0 + u < count) ? zf_consume(rows + (int64_t)(k0 + u) * NQ) : 0.0;
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                if (is_max) {
-                    acc = fmax(acc, p[u]);
-                } else {
-                    const double tsum = acc + p[u];
-                    comp += (fabs(acc) >= fabs(p[u])) ? (acc - tsum) + p[u] : (p[u] - tsum) + acc;
-                    acc = tsum;
-                }
-            }
+            for (int u = 0; u < 32; ++u) add(p[u]);
         }
         return is_max ? acc : acc + comp;
     };
@@ -540,6 +555,13 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
         }
     }
     if (A.decide) {
+        if constexpr (FETCH_CTL) {
+            constexpr int CW = (int)(sizeof(zf_control) / 8);
+            const unsigned long long* gw = reinterpret_cast<const unsigned long long*>(A.ctl);
+            unsigned long long* lw = reinterpret_cast<unsigned long long*>(A.ctl_rw);
+            if (t < CW) lw[t] = __hip_atomic_load(gw + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_wave_barrier();
+        }
         zf_decide_pass_wave(A.ctl_rw, s_pack, pk, A.trace, A.beta_ring, t, LSTR, s_pre);
         // this step has had its pass: the other shape kernels of the same step find the control block already
         // decided - describing the NEXT pass - and must not run it (zf_trial_kernel)
@@ -669,6 +691,9 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
     // of every stream (consecutive tiles per workgroup measured 4-8 % slower).
     const int64_t full_tiles = n2 / ZF_TILE_UNITS;
     const int64_t G = gridDim.x;
+    // (tile counts fit 32 bits - n < 2^42 - and gfx9 has no scalar 64-bit ordered compare: a 64-bit tile test
+    //  is a VALU compare whose scalar operands are first copied into vector registers)
+    const int full_tiles32 = (int)full_tiles, G32 = (int)gridDim.x, b32 = (int)blockIdx.x;
     // UB units are loaded, then computed, at a time
 #ifndef ZF_M1_UB
 #define ZF_M1_UB ZF_TILE_U   // units per load batch of the replay + 8 fresh trials body: the whole tile
@@ -724,7 +749,7 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
         constexpr int NL = NESTEROV ? 4 : 3;   // DMA instructions per unit
         int my_tiles = 0;
         for (int t = 0; t < A.tiles_per_wg; ++t)
-            if ((int64_t)t * G + blockIdx.x < full_tiles) my_tiles = t + 1;
+            if (t * G32 + b32 < full_tiles32) my_tiles = t + 1;
         const int total = my_tiles * ZF_TILE_U;
         const int wave = tidx >> 6;
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(zf_lds_ptr)stage + wave * 1024u);
@@ -874,7 +899,7 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
         static_assert(ZF_TILE_U == 2 * UB, "two batches per tile");
         int my_tiles = 0;
         for (int t = 0; t < A.tiles_per_wg; ++t)
-            if ((int64_t)t * G + blockIdx.x < full_tiles) my_tiles = t + 1;
+            if (t * G32 + b32 < full_tiles32) my_tiles = t + 1;
         if (my_tiles > 0) {
             zf_d2 a0[UB], o0[UB], q0[UB], c0[UB], a1[UB], o1[UB], q1[UB], c1[UB];
             int64_t base_u = (int64_t)blockIdx.x * ZF_TILE_UNITS + tidx;
@@ -897,7 +922,7 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
     // remainder of the vector (less than one tile, including an odd last element): element by
     // element, after its own tiles, by the workgroup next in the round-robin
     const int64_t rem0 = full_tiles * ZF_TILE_UNITS * 2;
-    if (rem0 < n && blockIdx.x == full_tiles % G) {
+    if (rem0 != n && b32 == full_tiles32 % G32) {
         for (int64_t e = rem0 + tidx; e < n; e += ZF_BLOCK) {
             double a = xk[e], o = NESTEROV ? xo[e] : a;
             const double q = p0[e], cc = GRAD_INLINE ? p1[e] : q;
@@ -1030,8 +1055,21 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
         }
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(lag, nf, 0);
         double v;
+#ifdef ZF_PERSIST_DEBUG   // (the same phase stamps as zf_persist_kernel, for the per-pass full chain: slot = pass_seq % 8)
+        long long* dbg = nullptr;
+        if constexpr (PART == 0 && !HIST) {
+            if (A.hist && threadIdx.x == 0) {
+                dbg = reinterpret_cast<long long*>(A.hist) + ((int64_t)(A.pass_seq % 8) * gridDim.x + blockIdx.x) * 8;
+                dbg[0] = wall_clock64();
+                dbg[6] = gridDim.x;
+            }
+        }
+#endif
         if constexpr (PART == 0) {
             v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, HD, 0, S, stage);
+#ifdef ZF_PERSIST_DEBUG
+            if (dbg) dbg[2] = wall_clock64();
+#endif
         } else if constexpr (PART == 3) {
             // a branch-free chain of L trials: the passes of a tail shared by two passes (the driver's K = 20 blocks:
             // 10 + 10) and the tail itself
@@ -1052,6 +1090,12 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
             else v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, HD, lag, nf);
         }
         zf_pass_finish<S>(A, v);
+#ifdef ZF_PERSIST_DEBUG
+        if constexpr (PART == 0 && !HIST) {
+            __syncthreads();
+            if (dbg) dbg[3] = wall_clock64();
+        }
+#endif
     }
 }
 
@@ -1079,69 +1123,119 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
 // of a pass outlives it but a few addresses.  amdgpu_waves_per_eu(2, 2) holds the allocator to 256: it then parks ~25
 // pass-loop invariants in scratch, stored once per launch and loaded once per PASS, outside the tile loops
 // (tests/test_abi.py checks exactly that: a bounded private segment, no scratch instruction at loop depth >= 2).
+// What the workgroups need of the control block to run the next pass: THREE words in one cache line, published by
+// the deciding wave; word 0 is written last and doubles as the barrier.  (Measured with the phase stamps of
+// tools/persist_phases.py: 489 workgroups fetching the 52 words of the block itself behind every barrier - 25 000
+// loads of four cache lines, all served by one memory channel - took 12 us per pass; one descriptor line per group of
+// workgroups took as long, because 62 scattered write-through stores leave the deciding wave one after the other.)
+//   [0] pass_seq | go << 32 | cur << 40 | prev << 44 | ring << 48     [1] lr     [2] nit
+// The momentum factor of the next trial is beta_ring[nit % ZF_RING] (zf_resolve_beta with nothing lagging).
+constexpr int ZF_PDESC_WORDS = 3;
 template <bool NESTEROV, bool BOX, bool NT>
 __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void zf_persist_kernel(zf_step_args A, int npass, unsigned spin_limit) {
     constexpr int S = ZF_MAX_SUB;
     constexpr int CW = (int)(sizeof(zf_control) / 8);
-    constexpr int SEQ_WORD = (int)(offsetof(zf_control, pass_seq) / 8);   // (shares its word with pend_status)
     static_assert(sizeof(zf_control) % 8 == 0 && CW <= 64, "one lane per word of the control block");
     static_assert(S == 16, "the persistent kernel holds the 16-trial full chain");
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
     __shared__ zf_d2 stage[ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS];
-    __shared__ zf_control s_ctl;
+    __shared__ zf_control s_ctl;                      // the deciding workgroup's copy of the control block
+    __shared__ unsigned long long s_desc[ZF_PDESC_WORDS];
     __shared__ int s_go;
     unsigned long long* gw = reinterpret_cast<unsigned long long*>(A.ctl_rw);
     unsigned long long* lw = reinterpret_cast<unsigned long long*>(&s_ctl);
+    unsigned long long* my_desc = A.pdesc;
+    if (threadIdx.x == 0) s_ctl.pass_seq = 0;
+    // the first pass reads the block as every per-pass kernel does (written by an earlier launch)
+    zf_pass_head HD = zf_head_of(A.ctl);
+    if (A.ctl->status != ZF_RUNNING || A.ctl->lag != 0 || zf_fresh_len(A.ctl) != S) return;
 #pragma unroll 1
     for (int p = 0; p < npass; ++p) {
         const int seq = A.pass_seq + p;
-        if (threadIdx.x < CW) lw[threadIdx.x] = __hip_atomic_load(gw + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (s_ctl.status != ZF_RUNNING || s_ctl.lag != 0 || zf_fresh_len(&s_ctl) != S) return;   // (the same for every workgroup)
+#ifdef ZF_PERSIST_DEBUG   // (timestamps of the phases of every pass and workgroup: tools/persist_phases.py)
+        long long* dbg = reinterpret_cast<long long*>(A.hist) + ((int64_t)p * gridDim.x + blockIdx.x) * 8;
+        if (A.hist && threadIdx.x == 0) {
+            dbg[0] = wall_clock64();
+            dbg[6] = gridDim.x;
+        }
+#endif
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(0, S, p + 1);
-        // (the copy lives in LDS: what the body takes from it is wave-uniform, and is moved to scalar registers - left
-        //  in vector registers, lr, nit and the sixteen momentum factors loaded through them cost the chain its second
-        //  wave per SIMD)
-        zf_pass_head HD;
-        HD.cur = __builtin_amdgcn_readfirstlane(s_ctl.cur);
-        HD.prev = __builtin_amdgcn_readfirstlane(s_ctl.prev);
-        HD.ring = __builtin_amdgcn_readfirstlane(s_ctl.ring_size);
-        HD.lr = zf_uniform_f64(s_ctl.lr);
-        HD.beta_next = zf_uniform_f64(s_ctl.beta_next);
-        HD.nit = (int64_t)zf_uniform_u64((unsigned long long)s_ctl.nit);
         const double v = zf_trial_body<true, NESTEROV, BOX, NT, S, 0, false, S, true>(A, lds, HD, 0, S, stage);
-        zf_step_args T = A;           // this pass: decided on the workgroup's own copy of the block
+#ifdef ZF_PERSIST_DEBUG
+        if (A.hist && threadIdx.x == 0) dbg[2] = wall_clock64();
+#endif
+        zf_step_args T = A;           // this pass: decided on the deciding workgroup's own copy of the block
+        T.ctl = A.ctl_rw;
         T.ctl_rw = &s_ctl;
-        T.ctl = &s_ctl;
         T.pass_seq = seq;
         T.decide = 1;
-        zf_pass_tail<S, true>(T, v);
+        zf_pass_tail<S, true, true>(T, v);
         __syncthreads();
+#ifdef ZF_PERSIST_DEBUG
+        if (A.hist && threadIdx.x == 0) {
+            dbg[3] = wall_clock64();
+            dbg[5] = (s_ctl.pass_seq == seq) ? 1 : 0;
+        }
+#endif
         if (s_ctl.pass_seq == seq) {
-            // this workgroup decided the pass (zf_pass_tail left its number in the copy): publish the block
+            // this workgroup decided the pass (zf_pass_tail left its number in the copy): publish the block for the
+            // host and for later launches, then one descriptor per group, its word 0 last
             if (threadIdx.x < 64) {
                 const int lane = threadIdx.x;
-                if (lane < CW && lane != SEQ_WORD)
-                    __hip_atomic_store(gw + lane, lw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < CW) __hip_atomic_store(gw + lane, lw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int go = (s_ctl.status == ZF_RUNNING && s_ctl.lag == 0 && zf_fresh_len(&s_ctl) == S) ? 1 : 0;
+                unsigned long long w[ZF_PDESC_WORDS];
+                w[0] = (unsigned long long)(unsigned)seq | ((unsigned long long)go << 32) | ((unsigned long long)(s_ctl.cur & 15) << 40) |
+                       ((unsigned long long)(s_ctl.prev & 15) << 44) | ((unsigned long long)(s_ctl.ring_size & 15) << 48);
+                w[1] = (unsigned long long)__double_as_longlong(s_ctl.lr);
+                w[2] = (unsigned long long)s_ctl.nit;
+                if (lane >= 1 && lane < ZF_PDESC_WORDS) __hip_atomic_store(A.pdesc + lane, w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(gw + SEQ_WORD, lw[SEQ_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    __hip_atomic_store(A.pdesc, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < ZF_PDESC_WORDS; ++k) s_desc[k] = w[k];
+                    s_go = 1;
+                }
             }
-            if (threadIdx.x == 0) s_go = 1;
         } else if (threadIdx.x == 0) {
-            const int* seq_ptr = &A.ctl_rw->pass_seq;
             int ok = 0;
             for (unsigned k = 0; k < spin_limit; ++k) {
-                if (__hip_atomic_load(seq_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) {
+                const unsigned long long w0 = __hip_atomic_load(my_desc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(unsigned)w0 == seq) {
+                    s_desc[0] = w0;
                     ok = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (ok) {
+#pragma unroll
+                for (int k = 1; k < ZF_PDESC_WORDS; ++k) s_desc[k] = __hip_atomic_load(my_desc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             s_go = ok;
         }
         __syncthreads();
-        if (!s_go) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#ifdef ZF_PERSIST_DEBUG
+        if (A.hist && threadIdx.x == 0) dbg[4] = wall_clock64();
+#endif
+        if (!s_go || ((s_desc[0] >> 32) & 1) == 0) return;   // gave up waiting / the next pass is not a full chain
+        // No agent-scope acquire here: its buffer_inv sc1 walks the L2, and 2000 waves issuing one behind every barrier
+        // cost 11 us per pass (phase stamps).  What this workgroup reads next and somebody else wrote - rows, tickets,
+        // the descriptor - is read past the caches anyway; the iterates it reads are those it stored itself, through
+        // the L1 it reads them from.  The L1 of this CU alone is dropped all the same (sc0: a CU-local operation).
+#ifndef ZF_PERSIST_NO_INV
+        asm volatile("buffer_inv sc0" ::: "memory");
+#endif
+        // (wave-uniform values out of LDS into scalar registers: left in vector registers, lr, nit and the sixteen
+        //  momentum factors loaded through them cost the chain its second wave per SIMD)
+        const unsigned cp = __builtin_amdgcn_readfirstlane((unsigned)(s_desc[0] >> 40));
+        HD.cur = (int)(cp & 15);
+        HD.prev = (int)((cp >> 4) & 15);
+        HD.ring = (int)((cp >> 8) & 15);
+        HD.lr = zf_uniform_f64(__longlong_as_double((long long)s_desc[1]));
+        HD.nit = (int64_t)zf_uniform_u64(s_desc[2]);
+        HD.beta_next = NESTEROV ? A.beta_ring[HD.nit % ZF_RING] : 0.0;
     }
 }
 

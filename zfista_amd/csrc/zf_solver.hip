@@ -144,6 +144,7 @@ struct zf_solver {
     double* slice_part = nullptr; // ZF_NPART x ZF_FIN_WGS
     unsigned* fin_cnt = nullptr;  // arrival counters: of the finalize workgroups / of the in-kernel finalisation (zf_pass_tail)
     double* grp_part = nullptr;   // ZF_NPART x S x ZF_FIN_GROUPS group rows of the in-kernel finalisation
+    unsigned long long* pdesc = nullptr;   // pass descriptors of the persistent kernel: one 128-byte line per group
     bool nt = true;               // nontemporal policy for once-touched streams
     char* ctl_trace = nullptr;    // one allocation: the control block (ZF_CTL_SLOT bytes) and the trace ring behind it
     char* mail = nullptr;         // pinned host mirror of ctl_trace: what a poll copies into
@@ -200,7 +201,8 @@ struct zf_solver {
     int fb_part = -1, fb_len = 0;         // ZF_K_FALLBACK: the general body runs what this kernel does not (-1: everything)
     // several full-chain passes per launch (zf_persist_kernel): grids the device holds at once
     int persist_cap = -1;                 // co-resident workgroups of the persistent kernel (-1: not asked yet)
-    bool persist = true;                  // ZF_PERSIST=0 at creation: always one launch per pass
+    bool persist = false;                 // ZF_PERSIST=1 at creation: consecutive full chains share a launch (measured: no gain)
+    bool mid_chains = true;               // ZF_MID_CHAINS=0 at creation: tails of 9 .. 15 trials through the general body (A/B)
     unsigned persist_spin = 1u << 20;     // polls a workgroup waits for a pass to be decided before it gives up
     int64_t persist_launches = 0, persist_passes = 0;
     bool speculate = true;                // ZF_SPECULATE=0 at creation: always launch every shape
@@ -221,7 +223,7 @@ constexpr size_t ZF_TRACE_BYTES = sizeof(double) * ZF_RING * ZF_TRACE_COLS;
 constexpr size_t ZF_MAIL_BYTES = ZF_CTL_SLOT + ZF_TRACE_BYTES + sizeof(int) * ZF_PASS_LOG;
 
 static int zf_solver_free_all(zf_solver* s) {
-    void* ptrs[] = {s->row_part, s->ls_cnt, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
+    void* ptrs[] = {s->row_part, s->ls_cnt, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->pdesc, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
                     s->own_svec ? s->s_part : nullptr, s->own_svec ? s->s_all : nullptr};
@@ -268,6 +270,7 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     s->opt = *opt;
     if (const char* e = getenv("ZF_SPECULATE")) s->speculate = atoi(e) != 0;
     if (const char* e = getenv("ZF_PERSIST")) s->persist = atoi(e) != 0;
+    if (const char* e = getenv("ZF_MID_CHAINS")) s->mid_chains = atoi(e) != 0;
     if (const char* e = getenv("ZF_PERSIST_SPIN_LIMIT")) s->persist_spin = (unsigned)strtoul(e, nullptr, 10);
     s->stream = reinterpret_cast<hipStream_t>(stream);
     s->box = !(desc->box_lo == -INFINITY && desc->box_hi == INFINITY);
@@ -317,6 +320,8 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     ZF_TRY(hipMalloc(&s->fin_cnt, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2)));
     ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2), s->stream));
     ZF_TRY(hipMalloc(&s->grp_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_GROUPS));
+    ZF_TRY(hipMalloc(&s->pdesc, sizeof(unsigned long long) * 16));
+    ZF_TRY(hipMemsetAsync(s->pdesc, 0, sizeof(unsigned long long) * 16, s->stream));
     // the control block and the trace ring side by side, and a pinned host mirror of both: a poll is ONE DMA into
     // pinned memory (two copies into the caller's pageable arrays cost 34 us on an idle stream, this costs a third)
     //  - and, behind them, the log of pass shapes the kernels keep when timing is on)
@@ -555,7 +560,7 @@ static int zf_predict_parts(zf_solver* s) {
     const int nf = zf_fresh_len(&c);
     int part = zf_pass_part(S, lag, nf);
     const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
-    if (part == 3 && !zf_have_s16_mid(v, nf)) part = 2;
+    if (part == 3 && (!s->mid_chains || !zf_have_s16_mid(v, nf))) part = 2;
     int mask = part == 3 ? ZF_K_MID : (1 << part);
     s->mid_len = nf;
     if (s->careful && s->steps_since_poll > 0) {
@@ -645,6 +650,11 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             s->steps_issued += 1;
             s->kernels_issued += __builtin_popcount(shapes);
         }
+#ifdef ZF_PERSIST_DEBUG
+        if (const char* e = getenv("ZF_PERSIST_DBG")) {
+            if (!s->hist) a.hist = reinterpret_cast<double*>(strtoull(e, nullptr, 0));
+        }
+#endif
         if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
         zf_launch_trial_kernels(s, a, true);
         if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
@@ -787,7 +797,11 @@ static int zf_launch_persist(zf_solver* s, int run) {
     a.ctl_rw = s->ctl;
     a.decide = 1;
     a.trace = s->trace;
-    if (s->pass_seq >= 0x7ffffff0 - run) s->pass_seq = 0;
+    if (s->pass_seq >= 0x7ffffff0 - run) {   // (step numbers start over: no descriptor of the old numbering may match a new one)
+        s->pass_seq = 0;
+        ZF_HIP(hipMemsetAsync(s->pdesc, 0, sizeof(unsigned long long) * 16, s->stream));
+    }
+    a.pdesc = s->pdesc;
     a.pass_seq = s->pass_seq + 1;    // pass p of the launch is step pass_seq + 1 + p
     s->pass_seq += run;
     for (int k = 0; k < run; ++k) zf_shadow_advance(s->shadow);
@@ -797,6 +811,9 @@ static int zf_launch_persist(zf_solver* s, int run) {
     s->persist_launches += 1;
     s->persist_passes += run;
     const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+#ifdef ZF_PERSIST_DEBUG
+    if (const char* e = getenv("ZF_PERSIST_DBG")) a.hist = reinterpret_cast<double*>(strtoull(e, nullptr, 0));
+#endif
     if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
     zf_launch_s16_persist(v, s->grid, s->stream, a, run, s->persist_spin);
     if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
