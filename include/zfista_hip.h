@@ -311,6 +311,9 @@ int zf_solver_pass_stats_ex(zf_solver* s, double* out, int64_t count /* >= 6 */)
 /* sharded solves, timing on (ABI 5): out[0] = mean ms, out[1] = count of the per-pass pack exchanges since the last
  * call, each timed on this rank's stream from "my packs are ready" to "the gathered packs are here" */
 int zf_solver_exchange_stats(zf_solver* s, double* out, int64_t count /* >= 2 */);
+/* timing on (ABI 5): one (shape, milliseconds) pair per launch that ran a pass since the last call, oldest first; shape =
+ * fresh trials | lagging iterations << 5 | passes of a persistent launch << 10; *count = pairs written (<= cap_pairs) */
+int zf_solver_pass_records(zf_solver* s, double* out, int64_t cap_pairs, int64_t* count);
 int zf_solver_set_timing(zf_solver* s, int32_t enabled);
 
 /* ---- vector kernels for opaque (Python) callbacks ------------------------

@@ -32,6 +32,7 @@ for rep in range(2):   # second repetition on a warm device is the one reported
         run.advance(64)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    records = run.solver.pass_records()
     (fm, fn), (pm, pn) = run.solver.pass_stats()
     ctl = run.solver.ctl
     S_used = run.sub_iters
@@ -42,4 +43,9 @@ for rep in range(2):   # second repetition on a warm device is the one reported
                kernel_time_over_ideal=(fm * fn + pm * pn) / max(fm * (-(-K // S_used)), 1e-30) - 1.0 if fn else None,
                seconds=dt, it_per_s=int(ctl.nit) / dt)
     run.solver.close()
+# kernel time by pass shape (lagging iterations replayed, fresh trials): count, mean ms
+by_shape = {}
+for lag, nf, cnt, ms in records:
+    by_shape.setdefault((lag, nf), []).append(ms)
+out["by_shape"] = [dict(lag=k[0], fresh=k[1], passes=len(v), mean_ms=sum(v) / len(v)) for k, v in sorted(by_shape.items())]
 print(json.dumps(out))

@@ -137,6 +137,7 @@ SIGNATURES = {
     "zf_solver_pass_stats": (C.c_int, [_P, _P, C.c_int64]),
     "zf_solver_pass_stats_ex": (C.c_int, [_P, _P, C.c_int64]),
     "zf_solver_exchange_stats": (C.c_int, [_P, _P, C.c_int64]),
+    "zf_solver_pass_records": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "zf_solver_launch_counts": (C.c_int, [_P, _P, C.c_int64]),
     "zf_host_grad_step": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64]),
     "zf_host_model_terms": (C.c_int, [_P, _P, _P, C.c_int64, _P]),

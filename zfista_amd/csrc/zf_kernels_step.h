@@ -194,6 +194,7 @@ template <int S, int MODE, bool HIST, bool GRAD_INLINE, int SP = S> constexpr bo
     if (HIST || !GRAD_INLINE || ZF_S16_GLDS == 0) return false;
     if (S >= 16) return true;
     if (MODE == 0 && SP >= 16 && S > ZF_MID_REG_MAX) return true;   // the longer mid chains (zf_pass_part: PART 3)
+    if (ZF_S8_GLDS == 2) return S == 8 && SP >= 16 && MODE == 1;   // (experiment: only the replay + 8 body)
     return ZF_S8_GLDS != 0 && S == 8 && SP >= 16;
 }
 constexpr int ZF_GLDS_STREAMS = 4;                                   // x_k, x_{k-1}, d, c
@@ -581,6 +582,13 @@ __device__ __forceinline__ unsigned long long zf_uniform_u64(unsigned long long 
 __device__ __forceinline__ double zf_uniform_f64(double v) {
     return __longlong_as_double((long long)zf_uniform_u64((unsigned long long)__double_as_longlong(v)));
 }
+// lane `i` (wave-uniform) of a double
+__device__ __forceinline__ double zf_readlane_f64(double v, int i) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, i);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), i);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 struct zf_pass_head {
     int cur, prev, ring;
     double lr, beta_next;
@@ -641,6 +649,24 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
 #pragma unroll
     for (int j = 1; j < S; ++j) beta[j] = NESTEROV ? A.beta_ring[(nit + j) % ZF_RING] : 0.0;
     const double tau = A.lam * lr;   // oracle: soft_threshold(x, lam * weight)
+    // The lagging iterations' parameters, one iteration per LANE (lag <= 31 < 64): replay step i takes its three
+    // doubles with v_readlane - no memory access inside the replay loop.  As wave-uniform scalar loads (one per step
+    // and load batch) they were a dependent K$ round trip per step, amortised over the 8 element recursions of a
+    // whole-tile batch and not at all over the 2 of a DMA unit (replay + 8 bodies by DMA: 2.2 ms per pass).
+    double rp_lr = 0.0, rp_beta = 0.0, rp_tau = 0.0;
+    if constexpr (!FULL && GRAD_INLINE) {
+        const int rl = (int)(tidx & 63);
+        if (rl < lag) {
+            rp_lr = A.ctl->lag_lr[rl];
+            rp_beta = NESTEROV ? A.beta_ring[(base + rl) % ZF_RING] : 0.0;
+            rp_tau = A.lam * rp_lr;
+        }
+    }
+    auto replay_param = [&](int i, double& b_i, double& lr_i, double& tau_i) {
+        b_i = zf_readlane_f64(rp_beta, i);
+        lr_i = zf_readlane_f64(rp_lr, i);
+        tau_i = zf_readlane_f64(rp_tau, i);
+    };
     int first, second;
     zf_free_bufs(cur, prev, ring, &first, &second);
     const double* __restrict__ xk = A.xb[cur];
@@ -722,9 +748,8 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
             // replay of the lagging iterations: trial-outer, unit-inner - 2 UB independent
             // element recursions per step, parameters are wave-uniform scalar loads
             for (int i = 0; i < lag; ++i) {
-                const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
-                const double lr_i = A.ctl->lag_lr[i];
-                const double tau_i = A.lam * lr_i;
+                double b_i, lr_i, tau_i;
+                replay_param(i, b_i, lr_i, tau_i);
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
                     zf_d2 r;
@@ -805,9 +830,8 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
                     // loads), then the fresh trials; one or two iterates are stored behind the DMA
                     zf_d2 a1 = a, o1 = o;
                     for (int i = 0; i < lag; ++i) {
-                        const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
-                        const double lr_i = A.ctl->lag_lr[i];
-                        const double tau_i = A.lam * lr_i;
+                        double b_i, lr_i, tau_i;
+                        replay_param(i, b_i, lr_i, tau_i);
                         zf_d2 r;
                         r.x = zf_elem_diag_replay<NESTEROV, BOX>(a1.x, o1.x, q.x, cc.x, b_i, lr_i, tau_i, A.lo, A.hi);
                         r.y = zf_elem_diag_replay<NESTEROV, BOX>(a1.y, o1.y, q.y, cc.y, b_i, lr_i, tau_i, A.lo, A.hi);
@@ -826,7 +850,7 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
             const int steady = total - (NST - 1);   // trips that still have a unit to issue
             int k = 0;
 #if ZF_GENERAL_SINGLE_LOOP
-            if constexpr (!FULL) {
+            if constexpr (MODE == 2) {   // (MODE 1 - replay, then S fresh trials, always two stores - takes the steady loop + peeled trips below)
                 // the general bodies: ONE loop, the issue and the wait chosen at run time (wave-uniform branches; these
                 // bodies branch per trial anyway).  Three instances of the 16-trial general body - a steady loop and
                 // two peeled end trips - ran the driver's 10-trial passes at 1.00-1.03 ms against 0.90 with one
@@ -845,9 +869,8 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
                     if (more) issue(k + NST - 1);
                     zf_d2 a1 = a, o1 = o;
                     for (int i = 0; i < lag; ++i) {
-                        const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
-                        const double lr_i = A.ctl->lag_lr[i];
-                        const double tau_i = A.lam * lr_i;
+                        double b_i, lr_i, tau_i;
+                        replay_param(i, b_i, lr_i, tau_i);
                         zf_d2 r;
                         r.x = zf_elem_diag_replay<NESTEROV, BOX>(a1.x, o1.x, q.x, cc.x, b_i, lr_i, tau_i, A.lo, A.hi);
                         r.y = zf_elem_diag_replay<NESTEROV, BOX>(a1.y, o1.y, q.y, cc.y, b_i, lr_i, tau_i, A.lo, A.hi);
@@ -928,9 +951,9 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
             const double q = p0[e], cc = GRAD_INLINE ? p1[e] : q;
             if constexpr (!FULL && GRAD_INLINE) {
                 for (int i = 0; i < lag; ++i) {
-                    const double b_i = NESTEROV ? A.beta_ring[(base + i) % ZF_RING] : 0.0;
-                    const double lr_i = A.ctl->lag_lr[i];
-                    const double r = zf_elem_diag_replay<NESTEROV, BOX>(a, o, q, cc, b_i, lr_i, A.lam * lr_i, A.lo, A.hi);
+                    double b_i, lr_i, tau_i;
+                    replay_param(i, b_i, lr_i, tau_i);
+                    const double r = zf_elem_diag_replay<NESTEROV, BOX>(a, o, q, cc, b_i, lr_i, tau_i, A.lo, A.hi);
                     o = a;
                     a = r;
                 }

@@ -180,6 +180,7 @@ struct zf_solver {
     size_t ev_used = 0;
     double ms_total = 0.0;
     int64_t ms_count = 0;
+    std::vector<std::pair<int, float>> records;   // (shape, ms) of every timed launch since the last zf_solver_pass_records
     // the per-pass exchange of a sharded solve (zf_gather_packs), bracketed the same way when timing is on
     std::vector<std::pair<hipEvent_t, hipEvent_t>> xev_pool;
     size_t xev_used = 0;
@@ -203,6 +204,7 @@ struct zf_solver {
     int persist_cap = -1;                 // co-resident workgroups of the persistent kernel (-1: not asked yet)
     bool persist = false;                 // ZF_PERSIST=1 at creation: consecutive full chains share a launch (measured: no gain)
     bool mid_chains = true;               // ZF_MID_CHAINS=0 at creation: tails of 9 .. 15 trials through the general body (A/B)
+    bool short_general = false;           // ZF_SHORT_VIA_GENERAL=1 at creation: the shapes of PART 1 through the general body (A/B)
     unsigned persist_spin = 1u << 20;     // polls a workgroup waits for a pass to be decided before it gives up
     int64_t persist_launches = 0, persist_passes = 0;
     bool speculate = true;                // ZF_SPECULATE=0 at creation: always launch every shape
@@ -271,6 +273,7 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     if (const char* e = getenv("ZF_SPECULATE")) s->speculate = atoi(e) != 0;
     if (const char* e = getenv("ZF_PERSIST")) s->persist = atoi(e) != 0;
     if (const char* e = getenv("ZF_MID_CHAINS")) s->mid_chains = atoi(e) != 0;
+    if (const char* e = getenv("ZF_SHORT_VIA_GENERAL")) s->short_general = atoi(e) != 0;
     if (const char* e = getenv("ZF_PERSIST_SPIN_LIMIT")) s->persist_spin = (unsigned)strtoul(e, nullptr, 10);
     s->stream = reinterpret_cast<hipStream_t>(stream);
     s->box = !(desc->box_lo == -INFINITY && desc->box_hi == INFINITY);
@@ -515,7 +518,7 @@ static bool zf_fin_kernel_mode() {
 }
 
 // grids of at most this many workgroups are latency-bound: a second (idle) launch per pass costs more than a slower body
-constexpr int ZF_SMALL_GRID = 512;
+constexpr int ZF_SMALL_GRID = 64;
 
 // move the shadow control block past a pass on the assumption that every fresh trial is accepted and nothing
 // terminates but max_iter - true for whole chunks in the regime a line search settles in
@@ -538,7 +541,7 @@ static void zf_shadow_advance(zf_control& c) {
 // * the last chunk saw rejections ("careful"): the first step after the poll is still exact; behind it the optimistic
 //   prediction plus the general body as its complement (whatever shape the pass has, exactly one of the two runs it)
 //   - on small grids, where an idle launch costs more than the general body loses, the general body alone;
-// * the shadow says the solve is over (and the device may not be: a chain broke): the general body on any shape.
+// * the shadow says the solve is over (and the device may not be: a chain broke): every shape again.
 // A wrong prediction costs passes that do nothing (no kernel finds its shape, the control block stays as it is) until
 // the next poll - never a wrong result.
 static int zf_predict_parts(zf_solver* s) {
@@ -552,7 +555,12 @@ static int zf_predict_parts(zf_solver* s) {
     const int S = s->sub;
     const bool s16 = S >= 16;
     if (c.status != ZF_RUNNING) {
-        if (!s16) return ZF_K_ALL;
+        // The shadow has reached the end of the solve.  If the device has not - chains broke; in a solve that crosses
+        // the resolution limit of the acceptance test MOST steps are issued in this state, the optimistic shadow being
+        // done after max_iter / S of them - any shape may be due: the three kernels that between them run every shape,
+        // each on the shapes it runs best (the general body alone took these solves from 5 880 to 4 900 it/s at n = 1e8:
+        // it runs the replaying shapes at 1.65 ms against 1.28).  Grids of a few workgroups: the general body alone.
+        if (!s16 || s->grid > ZF_SMALL_GRID) return ZF_K_ALL;
         s->fb_part = -1;
         return ZF_K_FALLBACK;
     }
@@ -563,16 +571,25 @@ static int zf_predict_parts(zf_solver* s) {
     if (part == 3 && (!s->mid_chains || !zf_have_s16_mid(v, nf))) part = 2;
     int mask = part == 3 ? ZF_K_MID : (1 << part);
     s->mid_len = nf;
+    if (part == 1 && s16 && s->short_general) {
+        s->fb_part = -1;
+        mask = ZF_K_FALLBACK;
+    }
     if (s->careful && s->steps_since_poll > 0) {
+        // Chains have been breaking: behind the first step the shape is no longer known.  A pass behind a broken chain
+        // replays and has at most S / 2 fresh trials, or only materialises (PART 1); a pass with nothing lagging far
+        // from max_iter is a full chain (PART 0); near max_iter it may be any length (PART 2 as well).  The general
+        // body could run all of them alone - one launch, never idle - but it runs the replaying shapes at 1.65 ms
+        // where PART 1 needs 1.28 (n = 1e8, tools/r4_noise.sh): only grids of a few workgroups, where a launch costs
+        // more than a body, take it.
+        const int64_t left = c.max_iter - c.nit;
         if (!s16) {
             mask = ZF_K_ALL;
         } else if (s->grid <= ZF_SMALL_GRID) {
             s->fb_part = -1;
             mask = ZF_K_FALLBACK;
         } else {
-            s->fb_part = part;
-            s->fb_len = nf;
-            mask |= ZF_K_FALLBACK;
+            mask = left >= 2 * (int64_t)S ? (ZF_K_FULL | ZF_K_SHORT) : ZF_K_ALL;
         }
     }
     zf_shadow_advance(c);
@@ -1373,6 +1390,7 @@ static int zf_collect_timing(zf_solver* s, bool log_in_mail = false) {
             // the launch found the solve finished and exited: the slot still holds what an earlier launch wrote
             if (entry < 0 || (entry >> 16) != (int)(launch & 0x7fff)) continue;
             const int shape = entry & 0xffff;   // zf_log_shape: fresh trials | lagging iterations << 5 | passes << 10
+            if (s->records.size() < 65536) s->records.emplace_back(shape, ms);
             const int nf = shape & 31, lag = (shape >> 5) & 31, cnt = (shape >> 10) & 63;
             if (lag == 0 && nf == s->sub) {
                 // (a persistent launch ran cnt full-chain passes back to back: its duration counts for all of them)
@@ -1395,6 +1413,25 @@ static int zf_collect_timing(zf_solver* s, bool log_in_mail = false) {
         s->xms_count += 1;
     }
     s->xev_used = 0;
+    return ZF_OK;
+}
+
+// Timing on: the launches that ran a pass since the last call, one (shape, milliseconds) pair each - shape = fresh trials |
+// lagging iterations << 5 | passes of a persistent launch << 10 (zf_log_shape) - oldest first; *count receives how
+// many pairs were written (at most cap_pairs; the rest is dropped).  For per-shape kernel statistics (tools/long_run.py).
+extern "C" int zf_solver_pass_records(zf_solver* s, double* out, int64_t cap_pairs, int64_t* count) {
+    ZF_REQUIRE(out && count && cap_pairs >= 0, "zf_solver_pass_records: bad argument");
+    ZF_REQUIRE(s, "zf_solver_pass_records: null solver");
+    ZF_HIP(hipStreamSynchronize(s->stream));
+    int rc = zf_collect_timing(s);
+    if (rc) return rc;
+    int64_t k = 0;
+    for (; k < (int64_t)s->records.size() && k < cap_pairs; ++k) {
+        out[2 * k] = (double)s->records[k].first;
+        out[2 * k + 1] = (double)s->records[k].second;
+    }
+    *count = k;
+    s->records.clear();
     return ZF_OK;
 }
 

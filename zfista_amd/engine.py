@@ -285,6 +285,18 @@ class DeviceSolver:
         _lib.check(self.lib.zf_solver_pass_stats_ex(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
         return (out[0], int(out[1])), (out[2], int(out[3])), (int(out[4]), int(out[5]))
 
+    def pass_records(self, cap=65536):
+        """[(lagging iterations, fresh trials, passes of a persistent launch, ms)] of every timed launch that ran a pass
+        since the last call (timing on)."""
+        out = np.zeros(2 * cap)
+        cnt = C.c_int64(0)
+        _lib.check(self.lib.zf_solver_pass_records(self.handle, C.c_void_p(_lib.ptr(out)), cap, C.byref(cnt)))
+        rec = []
+        for k in range(cnt.value):
+            shape = int(out[2 * k])
+            rec.append(((shape >> 5) & 31, shape & 31, (shape >> 10) & 63, float(out[2 * k + 1])))
+        return rec
+
     def exchange_stats(self):
         """(mean ms, count) of the per-pass pack exchanges the library issued since the last call (timing on)."""
         out = np.zeros(2)
