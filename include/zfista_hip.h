@@ -49,6 +49,9 @@ extern "C" {
 /* ---- problem kinds (single objective, recognised descriptors) ---------- */
 #define ZF_PROBLEM_DIAG_QUAD_L1 1     /* f = 1/2 sum d_i (x_i-c_i)^2, g = lam |x|_1 (+box) */
 #define ZF_PROBLEM_LEAST_SQUARES_L1 2 /* f = scale |Ax-b|^2,          g = lam |x|_1 (+box) */
+#define ZF_PROBLEM_BLUR_HAAR_L1 3     /* (ABI 5) f = scale |B W^-1 x - b|^2 with B an op_k x op_k correlation with symmetric
+                                         boundary and W one orthonormal Haar level: the operator-form LASSO of the
+                                         reference's examples/cameraman.ipynb:219-272; g = lam |x|_1 (+box)        */
 
 #define ZF_PACK_LEN 8    /* doubles in one per-trial scalar pack */
 #define ZF_MAX_SUB_ITERS 16 /* packs per pass: a rank's pack buffer holds sub_iters x ZF_PACK_LEN doubles */
@@ -124,6 +127,13 @@ typedef struct zf_problem_desc {
     double lam;        /* l1 weight                                                   */
     double box_lo;     /* -inf / +inf when there is no box                            */
     double box_hi;
+    /* (ABI 5) ZF_PROBLEM_BLUR_HAAR_L1: x = the Haar coefficients [cA, cH, cV, cD] (each op_h/2 x op_w/2, row-major) of an
+     * op_h x op_w image (both even; n = m_rows = op_h * op_w), b = the observed image (dev), op_taps = the correlation
+     * kernel, op_k x op_k row-major (dev; op_k odd, <= 15).  Zero for the other kinds. */
+    int64_t op_h, op_w;
+    const double* op_taps;
+    int32_t op_k;
+    int32_t op_reserved;
 } zf_problem_desc;
 
 typedef struct zf_options {  /* keyword arguments of proximal_gradient.py:317-330 */
@@ -191,6 +201,11 @@ typedef struct zf_comm_desc {
 int zf_comm_describe(zf_comm* c, zf_comm_desc* out, int64_t out_bytes);
 /* recv (world x count doubles, rank-major) <- send (count doubles) of every rank; stream-ordered */
 int zf_comm_all_gather(zf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream);
+
+/* f(x) and (grad_out_host != NULL) jac_f(x) of ZF_PROBLEM_BLUR_HAAR_L1 for a host vector x (n = h * w doubles): the
+ * problem's callbacks outside the device-resident loop (ABI 5) */
+int zf_op_eval(const double* taps_dev, int32_t k, const double* b_dev, int64_t h, int64_t w, double scale,
+               const double* x_host, double* f_out, double* grad_out_host);
 
 /* ---- the decision step on the host (no GPU needed) ----------------------
  * Same inline function the decide kernel runs (csrc/zf_decide.h); exported so

@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_mirrors():
     lib = _lib.load()
     assert lib.zf_sizeof_control() == C.sizeof(_lib.Control) == 416
-    assert C.sizeof(_lib.ProblemDesc) == 96
+    assert C.sizeof(_lib.ProblemDesc) == 128
     assert C.sizeof(_lib.Options) == 64
 
 

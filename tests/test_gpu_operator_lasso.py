@@ -1,0 +1,90 @@
+"""GPU parity: the operator-form LASSO of the reference's examples/cameraman.ipynb as a recognised,
+device-resident problem (zfista_amd.problems.BlurHaarL1, csrc/zf_kernels_op.h) against fixture G13 - the imported
+reference solver on the notebook's callbacks - and against the oracle run live.  Tolerance 1e-10 relative
+(north_star); the correlation sums its 81 products in another order than SciPy, so no bit-exactness is claimed."""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+CASES = {
+    "n64_fista": (64, dict(nesterov=True, nesterov_ratio=(0, 0.25), tol=0.0, max_iter=60)),
+    "n64_ista": (64, dict(nesterov=False, tol=0.0, max_iter=40)),
+    "n64_ab": (64, dict(nesterov=True, nesterov_ratio=(0.5, 1 / 16), tol=0.0, max_iter=40)),
+    "n64_tol": (64, dict(nesterov=True, nesterov_ratio=(0, 0.25), max_iter=400)),
+    "n256_fista": (256, dict(nesterov=True, nesterov_ratio=(0, 0.25), tol=0.0, max_iter=30)),
+}
+
+
+def _problem(size):
+    from oracle import operator_ref as O
+    from zfista_amd.problems import BlurHaarL1
+
+    kernel, observed, x0, L = O.make_deblur(size)
+    return BlurHaarL1(kernel, observed, O.L1_RATIO), O.BlurHaarL1Ref(kernel, observed), x0, L
+
+
+def test_callbacks_match_the_notebook_expressions():
+    """f, g, jac_f, prox_wsum_g as plain callables (types included: arrays of one value, a (1, n) Jacobian)."""
+    prob, ref, x0, L = _problem(64)
+    x = x0 + np.random.default_rng(3).standard_normal(x0.size) * 0.1
+    f, fr = prob.f(x), ref.f(x)
+    assert f.shape == fr.shape == (1,) and abs(f[0] - fr[0]) <= 1e-12 * abs(fr[0])
+    g, gr = prob.g(x), ref.g(x)
+    assert g.shape == gr.shape == (1,) and abs(g[0] - gr[0]) <= 1e-13 * abs(gr[0])
+    J, Jr = prob.jac_f(x), ref.jac_f(x)
+    assert J.shape == Jr.shape == (1, x.size) and rel_err(J, Jr) <= 1e-13
+    p, pr = prob.prox_wsum_g(1 / L, x), ref.prox_wsum_g(1 / L, x)
+    assert np.array_equal(p, pr)
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_device_resident_solve_matches_the_reference_fixture(tag, golden):
+    from zfista_amd import minimize_proximal_gradient
+
+    G = golden("g13_operator_lasso.npz")
+    size, kw = CASES[tag]
+    prob, _, x0, L = _problem(size)
+    assert 1 / L == float(G(f"{tag}.lr"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize_proximal_gradient(*prob.callbacks(), x0, lr=1 / L, decay_rate=1, return_all=True, **kw)
+    assert res.nit == int(G(f"{tag}.nit")) and res.status == int(G(f"{tag}.status"))
+    stride = 1 if size == 64 else 17
+    assert abs(np.linalg.norm(res.x) - float(G(f"{tag}.xnorm"))) <= TOL * float(G(f"{tag}.xnorm"))
+    assert np.linalg.norm(res.x[::stride] - G(f"{tag}.x")) <= TOL * float(G(f"{tag}.xnorm"))
+    assert np.asarray(res.fun).shape == (1,), "fun keeps the callbacks' type: an array of one value"
+    np.testing.assert_allclose(np.asarray(res.fun), G(f"{tag}.fun"), rtol=TOL)
+    np.testing.assert_allclose(np.concatenate([np.asarray(v).reshape(-1) for v in res.allfuns]), G(f"{tag}.allfuns"), rtol=TOL)
+    np.testing.assert_allclose(np.asarray(res.allerrs), G(f"{tag}.allerrs"), rtol=1e-9, atol=1e-16)
+    assert len(res.allvecs) == res.nit + 1 and res.allvecs[0] is x0
+
+
+def test_with_a_line_search_a_box_and_other_kernel_sizes():
+    """Beyond the notebook's options: backtracking from lr = 40 / L (decay_rate 0.5), a box, a 5 x 5 and a 15 x 15
+    kernel on a non-square image - against the oracle on the same callbacks."""
+    from oracle import cpu_ref, operator_ref as O
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.problems import BlurHaarL1
+
+    rng = np.random.default_rng(7)
+    for ksize, shape in ((5, (48, 80)), (15, (64, 32)), (9, (64, 64))):
+        kernel = O.gaussian_kernel(ksize, 2.0)
+        kernel = kernel / kernel.sum()
+        observed = rng.standard_normal(shape)
+        ref = O.BlurHaarL1Ref(kernel, observed, l1_ratio=0.02)
+        prob = BlurHaarL1(kernel, observed, 0.02)
+        x0 = O.dwt(observed)
+        kw = dict(lr=40.0, nesterov=True, tol=1e-9, max_iter=80)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = minimize_proximal_gradient(*prob.callbacks(), x0, **kw)
+            exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, **kw)
+        assert res.nit == exp.nit and res.status == exp.status, (ksize, res.nit, exp.nit)
+        assert rel_err(res.x, exp.x) <= TOL
+        np.testing.assert_allclose(np.asarray(res.fun), np.asarray(exp.fun), rtol=TOL)

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("ZF_LIB_PATH") or os.path.join(CSRC, "libzfista_hip.so
 
 ZF_OK = 0
 ZF_RUNNING, ZF_CONVERGED, ZF_MAXITER, ZF_BACKTRACK_FAILED = 0, 1, 2, 3
-ZF_PROBLEM_DIAG_QUAD_L1, ZF_PROBLEM_LEAST_SQUARES_L1 = 1, 2
+ZF_PROBLEM_DIAG_QUAD_L1, ZF_PROBLEM_LEAST_SQUARES_L1, ZF_PROBLEM_BLUR_HAAR_L1 = 1, 2, 3
 ZF_MO_GENERIC, ZF_MO_JOS1, ZF_MO_FDS = 0, 1, 2
 ZF_PACK_LEN, ZF_TRACE_COLS, ZF_RING = 8, 8, 1024
 ZF_MAX_SUB_ITERS = 16
@@ -61,6 +61,7 @@ class ProblemDesc(C.Structure):
         ("n", C.c_int64), ("m_rows", C.c_int64),
         ("d", C.c_void_p), ("c", C.c_void_p), ("A", C.c_void_p), ("b", C.c_void_p),
         ("scale", C.c_double), ("lam", C.c_double), ("box_lo", C.c_double), ("box_hi", C.c_double),
+        ("op_h", C.c_int64), ("op_w", C.c_int64), ("op_taps", C.c_void_p), ("op_k", C.c_int32), ("op_reserved", C.c_int32),
     ]
 
 
@@ -187,6 +188,7 @@ SIGNATURES = {
     "zf_mo_get_jac": (C.c_int, [_P, _P, C.c_int64]),
     "zf_mo_prox_host": (C.c_int, [_P, _P, _P, _P]),
     "zf_mo_post_terms": (C.c_int, [_P, C.c_double, _P, _P, _P]),
+    "zf_op_eval": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int64, C.c_double, _P, C.POINTER(C.c_double), _P]),
     "zf_ls_eval": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_double, _P, C.POINTER(C.c_double), _P]),
 }
 

@@ -18,6 +18,7 @@
 #include "zf_decide.h"
 #include "zf_kernels_gemv.h"
 #include "zf_kernels_ls_small.h"
+#include "zf_kernels_op.h"
 #include "zf_kernels_step.h"
 #include "zf_trial_launch.h"
 
@@ -245,6 +246,40 @@ static int zf_solver_free_all(zf_solver* s) {
 
 static bool zf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// least squares with an explicit matrix, or with the blur o inverse-Haar operator (zf_kernels_op.h): everything
+// around the two applications of A / its adjoint is shared
+static bool zf_is_ls(int kind) { return kind == ZF_PROBLEM_LEAST_SQUARES_L1 || kind == ZF_PROBLEM_BLUR_HAAR_L1; }
+static zf_op_args zf_op_of(const zf_problem_desc& d, const zf_control* ctl) {
+    zf_op_args P;
+    P.ctl = ctl;
+    P.H = (int)d.op_h;
+    P.W = (int)d.op_w;
+    P.K = (int)d.op_k;
+    P.taps = d.op_taps;
+    return P;
+}
+static int zf_op_grid(const zf_problem_desc& d) {
+    return (int)(((d.op_w + ZF_OP_TX - 1) / ZF_OP_TX) * ((d.op_h + ZF_OP_TY - 1) / ZF_OP_TY));
+}
+
+// s[(cur + slot) % 3] = A x[(cur + slot) % 3] inside the loop (ctl given), or sout.p[0] = A xr.p[0] outside it (ctl NULL)
+static void zf_launch_apply_A(zf_solver* s, const zf_control* ctl, zf_ring3 xr, zf_ring3 sout, int slot) {
+    const zf_problem_desc& d = s->desc;
+    const int64_t n = d.n, m = d.m_rows;
+    if (d.kind == ZF_PROBLEM_BLUR_HAAR_L1) {
+        hipLaunchKernelGGL(zf_op_apply_kernel, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, ctl), xr.p[0],
+                           xr.p[1], xr.p[2], sout.p[0], sout.p[1], sout.p[2], slot);
+        return;
+    }
+    const int V = (n % 2 == 0) ? 2 : 1;
+    int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
+    if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
+    if (V == 2)
+        hipLaunchKernelGGL(zf_gemv_rows_kernel<2>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, ctl, d.A, xr, sout, slot, m, n);
+    else
+        hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, ctl, d.A, xr, sout, slot, m, n);
+}
+
 extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, const zf_options* opt,
                                 void* stream) {
     ZF_REQUIRE(out && desc && opt, "zf_solver_create: null argument");
@@ -263,6 +298,15 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     } else if (desc->kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
         ZF_REQUIRE(desc->A && desc->b && desc->m_rows >= 1, "zf_solver_create: A, b, m_rows required");
         ZF_REQUIRE(zf_aligned16(desc->A), "zf_solver_create: A must be 16-byte aligned");
+    } else if (desc->kind == ZF_PROBLEM_BLUR_HAAR_L1) {
+        ZF_REQUIRE(desc->b && desc->op_taps, "zf_solver_create: b (the observed image) and op_taps are required");
+        ZF_REQUIRE(desc->op_h >= 2 && desc->op_w >= 2 && desc->op_h % 2 == 0 && desc->op_w % 2 == 0 &&
+                       desc->op_h * desc->op_w == desc->n && desc->m_rows == desc->n,
+                   "zf_solver_create: the image must be op_h x op_w (both even) with n = m_rows = op_h * op_w");
+        ZF_REQUIRE(desc->op_k >= 1 && desc->op_k % 2 == 1 && desc->op_k <= ZF_OP_MAXK && desc->op_k / 2 < desc->op_h &&
+                       desc->op_k / 2 < desc->op_w,
+                   "zf_solver_create: op_k must be odd, at most 15 and smaller than twice the image");
+        ZF_REQUIRE(desc->world == 1, "zf_solver_create: the operator problem is not sharded");
     } else {
         return zf_fail(ZF_ERR_ARG, "zf_solver_create: unknown problem kind");
     }
@@ -340,6 +384,14 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     ZF_TRY(hipMemsetAsync(s->trace, 0, sizeof(double) * ZF_RING * ZF_TRACE_COLS, s->stream));
     ZF_TRY(hipMemsetAsync(s->beta_ring, 0, sizeof(double) * ZF_RING, s->stream));
     ZF_TRY(hipMemsetAsync(s->pack_all, 0, sizeof(double) * ZF_PACK_LEN * s->sub * desc->world, s->stream));
+    if (desc->kind == ZF_PROBLEM_BLUR_HAAR_L1) {
+        const int64_t m_pad = n_pad;
+        ZF_TRY(hipMalloc(&s->grad, sizeof(double) * n_pad));
+        ZF_TRY(hipMalloc(&s->sbuf, sizeof(double) * 3 * m_pad));
+        for (int k = 0; k < 3; ++k) s->sring.p[k] = s->sbuf + k * m_pad;
+        ZF_TRY(hipMalloc(&s->resid, sizeof(double) * m_pad));
+        ZF_TRY(hipMalloc(&s->ls_scal, sizeof(double) * 8));
+    }
     if (desc->kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
         const int64_t m = desc->m_rows;
         const int64_t m_pad = (m + 63) & ~int64_t(63);
@@ -723,6 +775,23 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
                            (int)s->opt.nesterov);
         const int64_t nv = n / V;
         dim3 gT((unsigned)((nv + ZF_BLOCK - 1) / ZF_BLOCK), (unsigned)s->slices);
+        if (d.kind == ZF_PROBLEM_BLUR_HAAR_L1) {
+            // grad = 2 scale W B r in one launch (no slab, no combine); then the prox step and s+ = B W^-1 x+
+            hipLaunchKernelGGL(zf_op_adjoint_kernel, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, s->ctl),
+                               s->resid, s->grad, 2 * d.scale);
+            a.p0 = s->grad;
+            a.p1 = nullptr;
+            if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
+            zf_launch_trial_kernels(s, a, false);
+            if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+            zf_ring3 xr3 = {{s->xb[0], s->xb[1], s->xb[2]}};
+            zf_launch_apply_A(s, s->ctl, xr3, s->sring, 1);
+            hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1, d.b,
+                               d.scale, m, s->ls_scal + 1);
+            zf_launch_finalize(s, decide_in_launch);
+            ZF_HIP(hipGetLastError());
+            return ZF_OK;
+        }
         if (s->gemv_mfma) {
             dim3 gM((unsigned)((n + GEMVT_MFMA_COLS - 1) / GEMVT_MFMA_COLS), (unsigned)s->slices);
             hipLaunchKernelGGL(zf_gemvT_partial_mfma_kernel, gM, dim3(ZF_BLOCK), 0, s->stream, s->ctl, d.A,
@@ -984,19 +1053,10 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
     } else {
         // s0 = A x0 (sharded: this rank's A_p x0_p into s_part; zf_solver_enqueue_init_finish()
         // continues after the caller gathered the parts)
-        const int64_t m = d.m_rows;
-        const int V = (n % 2 == 0) ? 2 : 1;
         zf_ring3 xr = {{s->xb[0], s->xb[0], s->xb[0]}};
         double* dst = (d.world > 1 && !d.row_sharded) ? s->s_part : s->sring.p[0];   // row blocks: A_p x0 is local
         zf_ring3 s0 = {{dst, dst, dst}};
-        int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
-        if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
-        if (V == 2)
-            hipLaunchKernelGGL(zf_gemv_rows_kernel<2>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
-                               s0, -1, m, n);
-        else
-            hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
-                               s0, -1, m, n);
+        zf_launch_apply_A(s, nullptr, xr, s0, -1);
         ZF_HIP(hipGetLastError());
         if (d.world > 1 && !d.row_sharded) return ZF_OK;
         return zf_init_ls_tail(s);
@@ -1056,23 +1116,14 @@ extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const doubl
         ZF_HIP(hipMemsetAsync(s->pack_all, 0, sizeof(double) * ZF_PACK_LEN * s->sub * d.world, s->stream));
     ZF_HIP(hipMemcpyAsync(s->ctl, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));   // `c` is a stack object
-    if (d.kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
-        const int64_t m = d.m_rows;
-        const int V = (n % 2 == 0) ? 2 : 1;
-        int gr = (int)((m + GEMV_ROWS - 1) / GEMV_ROWS);
-        if (gr > 8 * ZF_MAX_GRID) gr = 8 * ZF_MAX_GRID;
+    if (zf_is_ls(d.kind)) {
         const int at[2] = {0, 2};   // A x_k -> sring[cur], A x_{k-1} -> sring[(cur + 2) % 3]
         for (int k = 0; k < 2; ++k) {
             double* xsrc = s->xb[at[k]];
             double* dst = s->sring.p[at[k]];
             zf_ring3 xr = {{xsrc, xsrc, xsrc}};
             zf_ring3 so = {{dst, dst, dst}};
-            if (V == 2)
-                hipLaunchKernelGGL(zf_gemv_rows_kernel<2>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
-                                   so, -1, m, n);
-            else
-                hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, nullptr, d.A, xr,
-                                   so, -1, m, n);
+            zf_launch_apply_A(s, nullptr, xr, so, -1);
         }
         ZF_HIP(hipGetLastError());
     }
@@ -1675,6 +1726,55 @@ extern "C" int zf_ls_eval(const double* A_dev, const double* b_dev, int64_t m_ro
     }
 #undef ZF_LS
     for (void* p : {(void*)x, (void*)s, (void*)slab, (void*)grad, (void*)fdev})
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+// f(x) = scale |B W^-1 x - b|^2 and (optionally) jac_f(x) = 2 scale W B (B W^-1 x - b) of the operator problem
+// (zf_kernels_op.h; reference: examples/cameraman.ipynb cell 8) for a host vector: the callbacks of
+// zfista_amd.problems.BlurHaarL1 outside the device-resident loop.  taps_dev: K x K, b_dev: H x W (device).
+extern "C" int zf_op_eval(const double* taps_dev, int32_t k, const double* b_dev, int64_t h, int64_t w, double scale,
+                          const double* x_host, double* f_out, double* grad_out_host) {
+    ZF_REQUIRE(taps_dev && b_dev && x_host && f_out, "zf_op_eval: null argument");
+    ZF_REQUIRE(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0 && k >= 1 && k % 2 == 1 && k <= ZF_OP_MAXK && k / 2 < h && k / 2 < w,
+               "zf_op_eval: the image must be even-sized and the kernel odd, at most 15 wide");
+    const int64_t n = h * w;
+    zf_problem_desc d;
+    memset(&d, 0, sizeof(d));
+    d.op_h = h;
+    d.op_w = w;
+    d.op_k = k;
+    d.op_taps = taps_dev;
+    double *x = nullptr, *sv = nullptr, *grad = nullptr, *fdev = nullptr;
+    int rc = ZF_OK;
+#define ZF_OP(expr)                                                               \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess && rc == ZF_OK)                                      \
+            rc = zf_fail(ZF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));     \
+    } while (0)
+    ZF_OP(hipMalloc(&x, sizeof(double) * n));
+    ZF_OP(hipMalloc(&sv, sizeof(double) * n));
+    ZF_OP(hipMalloc(&fdev, sizeof(double) * 2));
+    if (grad_out_host) ZF_OP(hipMalloc(&grad, sizeof(double) * n));
+    if (rc == ZF_OK) {
+        ZF_OP(hipMemcpyAsync(x, x_host, sizeof(double) * n, hipMemcpyHostToDevice, nullptr));
+        zf_ring3 sr = {{sv, sv, sv}};
+        hipLaunchKernelGGL(zf_op_apply_kernel, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, nullptr, zf_op_of(d, nullptr), x, x, x,
+                           sv, sv, sv, -1);
+        hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, nullptr, nullptr, sr, -1, b_dev, scale, n, fdev);
+        if (grad_out_host) {
+            hipLaunchKernelGGL(zf_axmb_kernel, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, nullptr, sv, b_dev, n);
+            hipLaunchKernelGGL(zf_op_adjoint_kernel, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, nullptr, zf_op_of(d, nullptr), sv,
+                               grad, 2 * scale);
+            ZF_OP(hipMemcpyAsync(grad_out_host, grad, sizeof(double) * n, hipMemcpyDeviceToHost, nullptr));
+        }
+        ZF_OP(hipGetLastError());
+        ZF_OP(hipMemcpyAsync(f_out, fdev, sizeof(double), hipMemcpyDeviceToHost, nullptr));
+        ZF_OP(hipStreamSynchronize(nullptr));
+    }
+#undef ZF_OP
+    for (void* p : {(void*)x, (void*)sv, (void*)grad, (void*)fdev})
         if (p) (void)hipFree(p);
     return rc;
 }

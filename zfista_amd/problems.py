@@ -199,6 +199,77 @@ class LeastSquaresL1(NativeProblem):
         return fields, (self.A, self.b)
 
 
+class BlurHaarL1(NativeProblem):
+    r"""Operator-form LASSO: f(x) = scale \|B W^{-1} x - b\|^2,  g(x) = lam \|x\|_1 (+ optional box), with B the
+    correlation with ``kernel`` (odd size <= 15, symmetric boundary - ``scipy.signal.correlate2d(..., mode="same",
+    boundary="symm")``) and W one orthonormal Haar level (``pywt.dwt2(.., "haar")``, coefficients flattened as
+    [cA, cH, cV, cD]): the image-deblurring problem of the reference's ``examples/cameraman.ipynb`` (cells 6-11,
+    ``l1_ratio`` = lam, scale = 1).  ``jac_f`` applies B itself as its adjoint, as the notebook does.
+
+    The callbacks keep the notebook's types - ``f`` and ``g`` return arrays of ONE value, ``jac_f`` a (1, n) array
+    (m = 1 by zfista/proximal_gradient.py:143) - and so do ``fun`` / ``allfuns`` of a solve.  Handed to
+    ``minimize_proximal_gradient`` as its four bound methods, the solve runs device-resident: the Haar levels are
+    folded into the tile loads / epilogues of the two correlation kernels (csrc/zf_kernels_op.h), B W^-1 y comes by
+    linearity from the cached B W^-1 x_k, B W^-1 x_{k-1}; no host synchronisation per iteration."""
+
+    kind = _lib.ZF_PROBLEM_BLUR_HAAR_L1
+    array_valued = True      # f, g -> (1,) arrays; jac_f -> (1, n)
+
+    def __init__(self, kernel, observed, l1_ratio, scale=1.0, bounds=None):
+        self.taps = _to_device(kernel, "kernel")
+        self.b = _to_device(observed, "observed")
+        if self.taps.ndim != 2 or self.taps.shape[0] != self.taps.shape[1] or self.taps.shape[0] % 2 != 1 or self.taps.shape[0] > 15:
+            raise ValueError("kernel must be square with an odd size of at most 15")
+        if self.b.ndim != 2 or self.b.shape[0] % 2 or self.b.shape[1] % 2:
+            raise ValueError("the observed image must be 2-D with even sides")
+        if self.taps.shape[0] // 2 >= min(self.b.shape):
+            raise ValueError("the kernel is too large for the image")
+        self.k = int(self.taps.shape[0])
+        self.h, self.w = int(self.b.shape[0]), int(self.b.shape[1])
+        self.lam, self.scale = float(l1_ratio), float(scale)
+        self.box = (-np.inf, np.inf) if bounds is None else (float(bounds[0]), float(bounds[1]))
+        self.n_features = self.h * self.w
+        self.group = None
+
+    def _op(self, x, want_grad):
+        x = _as_host(x).reshape(-1)
+        if x.size != self.n_features:
+            raise ValueError(f"len(x) should be equal to n_features, got {x}.")
+        lib = _lib.require_gpu()
+        fval = C.c_double(0.0)
+        grad = np.empty_like(x) if want_grad else None
+        _lib.check(lib.zf_op_eval(C.c_void_p(self.taps.data_ptr()), self.k, C.c_void_p(self.b.data_ptr()), self.h, self.w,
+                                  self.scale, C.c_void_p(_lib.ptr(x)), C.byref(fval),
+                                  C.c_void_p(_lib.ptr(grad)) if want_grad else None), "zf_op_eval")
+        return np.float64(fval.value), grad
+
+    def f(self, x):
+        return np.array([self._op(x, False)[0]])
+
+    def jac_f(self, x):
+        return self._op(x, True)[1].reshape(1, -1)
+
+    def g(self, x):
+        return np.array([NativeProblem.g(self, np.asarray(x).reshape(-1))])
+
+    def prox_wsum_g(self, weight, x):
+        # (weight is lr - a float - for m = 1, :148; tolerate the 1-element array a caller may pass)
+        return NativeProblem.prox_wsum_g(self, float(np.asarray(weight).reshape(-1)[0]), np.asarray(x).reshape(-1))
+
+    def _eval_fg(self, x):
+        lib = _lib.require_gpu()
+        s = C.c_double(0.0)
+        _lib.check(lib.zf_host_asum(C.c_void_p(_lib.ptr(x)), x.size, C.byref(s)), "zf_host_asum")
+        return None, np.float64(self.lam * s.value)
+
+    def _descriptor(self):
+        fields = dict(kind=self.kind, world=1, rank=0, n=self.n_features, m_rows=self.n_features, row_sharded=0,
+                      d=None, c=None, A=None, b=self.b.data_ptr(), scale=self.scale, lam=self.lam,
+                      box_lo=self.box[0], box_hi=self.box[1], op_h=self.h, op_w=self.w, op_taps=self.taps.data_ptr(),
+                      op_k=self.k)
+        return fields, (self.taps, self.b)
+
+
 def match_native(f, g, jac_f, prox_wsum_g):
     """The NativeProblem whose four bound methods these are, else None."""
     owner = getattr(f, "__self__", None)

@@ -384,6 +384,12 @@ def _solve_native(problem, x0, opts, solver_factory=None):
     ctl = run.solver.ctl
     x = run.solver.get_x()
     F = np.float64(ctl.F_old)
+    if getattr(problem, "array_valued", False):
+        # the problem's f and g return arrays of one value (m = 1 by :143, e.g. the notebook's deblurring callbacks):
+        # fun and allfuns carry that shape, as the reference's f(xk) + g(xk) would (:523, :547)
+        F = np.array([F])
+        if allfuns is not None:
+            allfuns = [np.array([v]) for v in allfuns]
     if run.status == _lib.ZF_BACKTRACK_FAILED:
         # proximal_gradient.py:493-509: reported, not raised
         print(f"An error occurred: {_MSG_BACKTRACK}")
