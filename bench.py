@@ -64,9 +64,10 @@ PMC_PROFILE = "r02_s{S}_pmc_traffic.json"          # round-2 sets (chains of 1 /
 ISA_PROFILE = "r02_isa_mix_trial_kernel_s{S}.json"
 # round 3: one PMC set per FLAG SET of this file, summarised per shape-specific kernel (tools/profile_r3.sh):
 # the line names the kernel that dominates its timed region and reads THAT kernel's counters
-PMC_R3 = {"full": ("r03_pmc_defaults_k100_w10.json", "part0"), "mid": ("r03_pmc_driver_k20_w5.json", "part3"),
-          "general": ("r03_pmc_driver_k20_w5.json", "part2")}
-MID_CHAIN = 10   # trials of the branch-free mid chain (csrc/zf_kernels_step.h: ZF_MID_CHAIN): the driver's K = 20 blocks run two
+# round 4: re-collected with the round's kernels (tools/profile_r4.sh); mid chains are keyed by their length
+PMC_R3 = {"full": ("r04_pmc_defaults_k100_w10.json", "part0"), "mid": ("r04_pmc_driver_k20_w5.json", "part3_L10"),
+          "general": ("r04_pmc_defaults_k100_w10.json", "part1")}
+MID_MIN, MID_MAX = 9, 15   # trials of the branch-free mid chains (csrc/zf_kernels_step.h: ZF_MID_MIN .. ZF_MID_MAX), one kernel per length
 
 
 def make_inputs(n, seed, device):
@@ -383,7 +384,10 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
     # at iteration ~89 and pay for two or three rounding-noise rejections.  The other one is measured
     # briefly after the main measurement (every rank takes part: the exchanges are collective).
     regimes = {}
-    for (k2, w2), tag in (((20, 5), "clean_regime_K20_W5"), ((100, 10), "across_the_noise_floor_K100_W10")):
+    # (round 4: K = 24 / 28 / 30 beside K = 20 - tails of 12 + 12, 14 + 14, 15 + 15 trials: every tail length has a
+    #  branch-free kernel of its own now, the line no longer has one privileged block length)
+    for (k2, w2), tag in (((20, 5), "clean_regime_K20_W5"), ((24, 5), "clean_regime_K24_W5"), ((28, 5), "clean_regime_K28_W5"),
+                          ((30, 5), "clean_regime_K30_W5"), ((100, 10), "across_the_noise_floor_K100_W10")):
         if (k2, w2) == (K, W):
             regimes[tag] = (world * K / dt * (n / N_PER_GPU)) if not args.total_n else K / dt
         elif not args.no_regimes:
@@ -451,8 +455,9 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
             trials = float(S) if on_full else part_fresh / part_n      # fresh trials per pass
             replays = 0.0 if on_full else part_lag / part_n             # replayed iterations per pass
             pass_bytes = (PASS_BYTES_PER_ELEM if S > 1 else ALG_BYTES_PER_ELEM) * n
-            mid = (not on_full) and S == 16 and abs(trials - MID_CHAIN) < 1e-9 and replays == 0
-            kp = kernel_profile(n, S, "full" if on_full else ("mid" if mid else "general"))   # THIS kernel's counters (round 3)
+            mid = (not on_full) and S == 16 and abs(trials - round(trials)) < 1e-9 and MID_MIN <= round(trials) <= MID_MAX and replays == 0
+            mid_len = int(round(trials)) if mid else 0
+            kp = kernel_profile(n, S, "full" if on_full else ("mid" if mid and mid_len == 10 else "general"))   # THIS kernel's counters
             traffic = kp.get("hbm_bytes_per_launch") if kp else measured_traffic(n, S)
             traffic_file = kp["file"] + " [" + kp["part"] + "]" if kp else "profiles/" + PMC_PROFILE.format(S=S)
             achieved = pass_bytes / (ker_ms * 1e-3) / 1e9
@@ -506,8 +511,8 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 "traffic_source": f"{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch "
                                   "of the kernel named below)" if traffic else None,
                 "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (full-chain passes)" if on_full else
-                          (f"zf_trial_kernel<grad inline, nesterov, nt, S={S}, PART 3> (branch-free chain of {MID_CHAIN} trials: "
-                           f"the K = {K} timed iterations are shared by passes of {MID_CHAIN}; no full chain runs)" if mid else
+                          (f"zf_trial_kernel<grad inline, nesterov, nt, S={S}, PART 3, L={mid_len}> (branch-free chain of {mid_len} trials: "
+                           f"the K = {K} timed iterations are shared by passes of {mid_len}; no full chain runs)" if mid else
                            f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (general body: passes of {trials:.1f} fresh "
                            f"trials + {replays:.1f} replayed iterations on average; no full chain dominates K = {K})"),
                 "kernel_avg_ms": ker_ms,

@@ -48,21 +48,31 @@ def test_harness_jos1_sweep_and_metric_tables(tmp_path):
         starts = rng.uniform(-2, 4, size=(6, n))
         ref = P.JOS1Ref(n) if prob.l1_ratios is None else P.JOS1Ref(n, l1_ratios=(np.arange(m) + 1) / n,
                                                                      l1_shifts=np.arange(m))
-        res = {}
+        res, res_perm = {}, {}
         for label, kw in variants.items():
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 res[label] = [cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, return_all=True,
                                                                  max_iter=100000000, tol_internal=1e-11, **kw)
                               for x0 in starts]
+                # the oracle's OWN spread (G10's rule): the same starts with their features permuted - JOS1 is
+                # symmetric in its features, so this is the same problem with every sum in another order
+                res_perm[label] = [cpu_ref.minimize_proximal_gradient(
+                    *ref.callbacks(), x0[np.random.default_rng(100 + k).permutation(n)], max_iter=100000000,
+                    tol_internal=1e-11, **kw) for k, x0 in enumerate(starts)]
         metrics, ratios = calculate_metrics(*res.items())
         got = rep[prob.name]
         for label in variants:
-            # (an accelerated solve stops when err < tol = 1e-5 on a trajectory that depends on the last bits of Brent's
-            #  dual solves: the oracle ITSELF gave 33.17 on one host and 31.17 on another for JOS1 n = 10 + l1,
-            #  "Accelerated" - twelve iterations over six starts - so the averages agree to 15 %, not exactly)
+            # Round 4: no flat 15 % any more.  The average iteration count is held to 10 x the spread the oracle itself
+            # shows between the two summation orders - measured per problem and variant, "Normal" included (zero for
+            # most; JOS1 n = 10 + l1: 47.0 vs 47.67 "Normal", 31.17 vs 31.5 "Accelerated") - and never tighter than
+            # one iteration on one of the six starts (a stop at err < tol = 1e-5 is a knife edge on a trajectory that
+            # depends on the last bits of Brent's dual solves).
             want_it = metrics["Avg iterations"][label]
-            assert abs(got["metrics"]["Avg iterations"][label] - want_it) <= 0.15 * want_it + 1.0, (prob.name, label)
+            spread = abs(want_it - float(np.mean([r.nit for r in res_perm[label]])))
+            tol_it = max(10.0 * spread, 1.0 / len(starts) + 1e-9)
+            assert abs(got["metrics"]["Avg iterations"][label] - want_it) <= tol_it, \
+                (prob.name, label, got["metrics"]["Avg iterations"][label], want_it, spread)
         # Hypervolume is a continuous function of the objective vectors: equal to 1e-3.  Purity / Gamma / Delta are
         # not - they count which variant's point DOMINATES when two variants reach the same Pareto point from the
         # same start up to ~1e-8 (the accuracy of Brent's dual solves), so the oracle's and the engine's tables may

@@ -136,3 +136,84 @@ def test_per_coordinate_bounds(cls):
     tol = 1e-7 if m == 2 else 1e-6
     assert np.linalg.norm(res.x - exp.x) <= tol * max(1.0, np.linalg.norm(exp.x))
     assert np.all(res.x >= lo) and np.all(res.x <= hi)
+
+
+@pytest.mark.parametrize("n", [20000, 300000])
+@pytest.mark.parametrize("m", [4, 5, 6, 8])
+def test_device_search_for_four_to_eight_objectives_kkt_in_oracle_arithmetic(m, n):
+    """Round 4: the persistent-kernel dual search (dual_solver="device") for every m the engine takes.  One trial of
+    m separable quadratics + shifted l1 (the well-conditioned family of fixture G11, a HOST-f family: J is uploaded,
+    f(y) supplied; n = 3e5 is beyond the LDS capacity for m = 8: the streamed path) judged in the oracle's own
+    arithmetic, as the m <= 3 cases are (test_gpu_mo_fullsize.py): at the kernel's w* the simplex KKT gap of
+    oracle.cpu_ref.dual_value_and_grad (:161-177) must not exceed that of SciPy's end point for the same trial (up to
+    the resolution of the gradient's sums), and x+ must equal prox(lr w*, y - lr w* @ J) (:206) to 1e-12."""
+    from oracle import cpu_ref, problems_ref as P
+    from test_gpu_mo_fullsize import _quad_class
+    from zfista_amd.multiobjective import X_K, X_NEW, Y, device_dual, solve_dual
+
+    D, C = P.make_quad_mo(n, m, seed=5 + m)
+    kw = dict(l1_ratios=0.02 + 0.01 * np.arange(m), l1_shifts=0.25 * np.arange(m) - 0.5)
+    prob, ref = _quad_class()(D, C, **kw), P.DiagQuadMORef(D, C, **kw)
+    x0 = np.random.default_rng(1).uniform(-2, 2, n)
+    y = x0 + 0.1 * np.random.default_rng(2).standard_normal(n)
+    lr = 0.45
+    eng = prob._engine()
+    eng.set_x0(x0)
+    eng.put(Y, y)
+    _, g0 = eng.eval_F(X_K, builtin_f=False)
+    F_old = np.asarray(prob.f(x0), float) + g0
+    eng.set_jac(prob.jac_f(y))
+    f_y = np.asarray(prob.f(y), float)
+    out = eng.solve_dual_device(lr, f_y, F_old, False, None, 1e-12, 100000)
+    assert out is not None, f"the device search was not attempted for m = {m}"
+    w, x = np.asarray(out[0], float), eng.get(X_NEW)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        w_sp, _, _ = solve_dual(device_dual(eng, lr, f_y, F_old, False), m, np.ones(m) / m, 1e-12, 100000)
+    J, f_y_ref, F_old_ref = ref.jac_f(y), ref.f(y), ref.f(x0) + ref.g(x0)
+
+    def gap(wv):
+        wv = np.asarray(wv, float)
+        _, grad = cpu_ref.dual_value_and_grad(wv, ref.g, ref.prox_wsum_g, lr, y, J, f_y_ref, F_old_ref)
+        return float(np.dot(wv, grad - grad.min())), float(np.abs(grad).max())
+
+    g_dev, scale = gap(w)
+    g_sp, _ = gap(w_sp)
+    assert abs(w.sum() - 1.0) <= 1e-12 and np.all(w >= 0)
+    assert g_dev <= max(g_sp, 1e-13 * scale * np.sqrt(n)), (m, n, g_dev, g_sp)
+    x_oracle = ref.prox_wsum_g(lr * w, y - lr * (w @ J))
+    assert np.linalg.norm(x - x_oracle) <= 1e-12 * np.linalg.norm(x_oracle)
+    eng.close()
+
+
+def test_device_search_is_attempted_for_every_problem_family():
+    """dual_solver="device" through the public entry for every Problem subclass of zfista_amd.problems: the result says
+    which search produced the weights of how many trials (dual_search_trials) - all of them the device's - and agrees
+    with the host-driven library search (the same machine, evaluation by evaluation through launches)."""
+    from zfista_amd import problems as Z
+
+    rng = np.random.default_rng(3)
+    cases = [
+        (Z.JOS1(500, l1_ratios=np.array([1, 2]) / 500, l1_shifts=[0, 1]), rng.uniform(-2, 2, 500), dict(lr=100.0)),
+        (Z.FDS(20, l1_ratios=np.array([1, 2, 3]) / 20, l1_shifts=[0, 1, 2]), rng.uniform(-2, 2, 20), dict(lr=0.05)),
+        (Z.SD(), None, dict(lr=0.5)),
+        (Z.ZDT1(30), None, dict(lr=0.1)),
+        (Z.TOI4(l1_ratios=[0.1, 0.2], l1_shifts=[0.0, 0.5]), None, dict(lr=0.5)),
+        (Z.TRIDIA(), None, dict(lr=0.05)),
+        (Z.LinearFunctionRank1(), None, dict(lr=1e-4)),
+        (Z.LinearFunctionRank1(16, 7, l1_ratios=(np.arange(7) + 1) / 160, l1_shifts=np.arange(7) / 10), None, dict(lr=1e-5)),
+    ]
+    for prob, x0, kw in cases:
+        if x0 is None:
+            x0 = rng.uniform(0.1, 0.5, prob.n_features)
+        o = dict(nesterov=True, tol=1e-7, max_iter=8, **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            dev = prob.minimize_proximal_gradient(x0, dual_solver="device", **o)
+            nat = prob.minimize_proximal_gradient(x0, dual_solver="native", **o)
+        name = type(prob).__name__
+        if "dual_search_trials" in dev:      # (an error-shaped result carries it too)
+            t = dev["dual_search_trials"]
+            assert t["device"] >= 1 and t["native"] == 0 and t["scipy"] == 0, (name, t)
+        assert dev.nit == nat.nit, (name, dev.nit, nat.nit)
+        assert np.linalg.norm(np.asarray(dev.x) - np.asarray(nat.x)) <= 1e-6 * max(1.0, np.linalg.norm(nat.x)), name

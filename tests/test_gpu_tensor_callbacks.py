@@ -117,10 +117,9 @@ def test_operator_form_lasso_example_matches_numpy_callbacks():
     import os
 
     import torch
-    from scipy.signal import correlate2d
 
     from conftest import ROOT
-    from oracle import cpu_ref
+    from oracle import cpu_ref, operator_ref as O
     from zfista_amd import minimize_proximal_gradient
 
     spec = importlib.util.spec_from_file_location("deblur_example", os.path.join(ROOT, "examples",
@@ -128,13 +127,10 @@ def test_operator_form_lasso_example_matches_numpy_callbacks():
     ex = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ex)
     size = 64
-    kernel = ex.gaussian_kernel()
-    observed = correlate2d(ex.synthetic_image(size), kernel, mode="same", boundary="symm") \
-        + np.random.default_rng(1).standard_normal((size, size)) * 1e-3
-    cbs_np, dwt_np, idwt_np = ex.numpy_problem(kernel, observed)
+    kernel, observed, x0, _ = O.make_deblur(size)
+    cbs_np = O.BlurHaarL1Ref(kernel, observed).callbacks()
     cbs_t, dwt_t, idwt_t = ex.tensor_problem(kernel, observed)
-    x0 = dwt_np(observed)
-    assert np.allclose(idwt_np(x0), observed, atol=1e-14)                       # orthonormal Haar level
+    assert np.allclose(O.idwt(x0, observed.shape), observed, atol=1e-14)        # orthonormal Haar level
     assert np.array_equal(dwt_t(torch.from_numpy(observed).cuda()).cpu().numpy(), x0)
     kw = dict(lr=1 / (2 * kernel.sum() ** 2), decay_rate=1, nesterov=True, tol=0.0, max_iter=25, return_all=True)
     with warnings.catch_warnings():

@@ -287,7 +287,10 @@ __global__ void k_f_from_sums(int kind, double dn, const double* __restrict__ t,
 //   and max|x+ - y| (:510) are fused in.  One launch, one result read-back per trial.
 typedef unsigned long long mo_u64;
 constexpr int MO_SOLVE_TPB = 512;
-constexpr int MO_SOLVE_LDS_BYTES = 156 * 1024;   // dynamic LDS for the resident elements (static LDS: ~3 KB)
+constexpr int MO_SOLVE_LDS_BYTES = 156 * 1024;   // dynamic LDS for the resident elements (static LDS: ~3 KB for m <= 3;
+                                                 // larger m: what the kernel's own static part leaves of the CU's 160 KB)
+// hand-over records per parity: batches of NB points x NQP sums, at most 2 x (2 m + 2 + m^2) for m = 8 with the exact Hessian
+constexpr int MO_REC_CAP = 2 * (2 * MO_MAX_M + 2 + MO_MAX_M * MO_MAX_M + 2);
 constexpr int MO_SOLVE_WAVES = MO_SOLVE_TPB / 64;
 constexpr unsigned MO_SPIN_LIMIT = 1u << 24;   // polls (each >= ~100 ns): a stuck grid gives up after seconds (default of
                                                // mo_solve_args.spin_limit; ZF_MO_SPIN_LIMIT in the environment overrides it)
@@ -546,14 +549,20 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
         // the reducer: wave w takes quantities w, w + WAVES, ...; lane l takes workgroups l, l + 64, ...
         constexpr int GL = 4;   // workgroups per lane (<= 256 workgroups)
         double pv[QW][GL];
+        // (one 4-bit group per quantity of this wave: a single 32-bit mask held QW x GL <= 32 records - enough for
+        //  m <= 4, silently wrong from m = 5 on, where a batch hands over 78 .. 166 values)
+        unsigned pend[QW];
         unsigned pending = 0;
 #pragma unroll
-        for (int a = 0; a < QW; ++a)
+        for (int a = 0; a < QW; ++a) {
+            pend[a] = 0;
 #pragma unroll
             for (int c = 0; c < GL; ++c) {
                 pv[a][c] = 0.0;
-                if (wave + a * MO_SOLVE_WAVES < count && lane + 64 * c < G) pending |= 1u << (a * GL + c);
+                if (wave + a * MO_SOLVE_WAVES < count && lane + 64 * c < G) pend[a] |= 1u << c;
             }
+            pending |= pend[a];
+        }
         unsigned spins = 0;
         while (pending) {
             // all records of this lane in flight at once, then the checks: loading one record, checking it
@@ -570,14 +579,17 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
                     rlo[a][c] = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     rhi[a][c] = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            pending = 0;
 #pragma unroll
-            for (int a = 0; a < QW; ++a)
+            for (int a = 0; a < QW; ++a) {
 #pragma unroll
                 for (int c = 0; c < GL; ++c)
-                    if ((pending & (1u << (a * GL + c))) && (rlo[a][c] ^ rhi[a][c]) == key) {
+                    if ((pend[a] & (1u << c)) && (rlo[a][c] ^ rhi[a][c]) == key) {
                         pv[a][c] = __longlong_as_double((long long)rlo[a][c]);
-                        pending &= ~(1u << (a * GL + c));
+                        pend[a] &= ~(1u << c);
                     }
+                pending |= pend[a];
+            }
             if (pending) {
                 __builtin_amdgcn_s_sleep(2);   // (do not hammer the memory system while the others still compute)
                 if (++spins > spin_limit) {
@@ -668,7 +680,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
     constexpr int NB = mach_t::NB;
     constexpr bool XH = mach_t::XH;
     constexpr int NQP = (NQ + (XH ? M * M : 0) + 1) & ~1;
-    constexpr int REC_CAP = zf_dual::MAXB * (2 * MO_MAX_M + 2);   // records per parity (the host allocates 2 x this)
+    constexpr int REC_CAP = MO_REC_CAP;   // records per parity (the host allocates 2 x this)
     static_assert(NB * NQP <= REC_CAP, "hand-over buffers too small");
     __shared__ mach_t s_mach;
     __shared__ double s_hess[NB * M * M];
@@ -1198,6 +1210,7 @@ struct zf_mo {
     int last_slot = 0;                         // slot of the most recent launch (zf_mo_solve_stats)
     int solve_grid = 0;
     size_t solve_lds_set = (size_t)-1;         // dynamic LDS size last registered for k_dual_solve
+    int64_t solve_static_lds = -1;             // static LDS of k_dual_solve<m> (hipFuncGetAttributes, once)
     double* f_y_dev = nullptr;                 // f(y) of zf_mo_prepare_async (device, MO_MAX_M)
     bool f_y_on_device = false;
     // fused outer iteration (zf_mo_set_fused): zf_mo_commit and zf_mo_prepare_async only RECORD what is
@@ -1786,7 +1799,7 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
                       (s->kind == ZF_MO_JOS1 || s->kind == ZF_MO_FDS);
     if (!fuse)
         if (int rc = mo_flush(s)) return rc;
-    if (s->exchange || s->comm || s->m > 3) return ZF_OK;   // sharded x: every evaluation needs an exchange; m > 3: register budget
+    if (s->exchange || s->comm) return ZF_OK;   // sharded x: every evaluation needs an exchange
     if (s->solve_unavailable) return ZF_OK;      // (the grid cannot be co-resident on this device: the caller's host loop)
     if (!s->solve_partials) {
         int dev = 0, cus = 0;
@@ -1800,15 +1813,14 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
             const long long v = atoll(sl);
             if (v > 0) s->spin_limit = v > 0x7fffffffLL ? 0x7fffffffu : (unsigned)v;
         }
-        const size_t nq = 2 * MO_MAX_M + 2;
         // the hand-over records in UNCACHED device memory: every access is an agent-scope atomic that has to
         // reach memory anyway (the 8 XCDs' L2s are not coherent with each other); without the L2 in the way a
         // hand-over is ~0.5 us shorter (cfg4 9 700 -> 10 150-10 300 it/s, same box, A/B)
-        ZF_HIP(hipExtMallocWithFlags((void**)&s->solve_partials, 16 * 2 * zf_dual::MAXB * nq * s->solve_grid,
+        ZF_HIP(hipExtMallocWithFlags((void**)&s->solve_partials, 16 * 2 * (size_t)MO_REC_CAP * s->solve_grid,
                                      hipDeviceMallocUncached));
-        ZF_HIP(hipExtMallocWithFlags((void**)&s->solve_totals, 16 * 2 * zf_dual::MAXB * nq, hipDeviceMallocUncached));
-        ZF_HIP(hipMemsetAsync(s->solve_partials, 0, 16 * 2 * zf_dual::MAXB * nq * s->solve_grid, s->stream));
-        ZF_HIP(hipMemsetAsync(s->solve_totals, 0, 16 * 2 * zf_dual::MAXB * nq, s->stream));
+        ZF_HIP(hipExtMallocWithFlags((void**)&s->solve_totals, 16 * 2 * (size_t)MO_REC_CAP, hipDeviceMallocUncached));
+        ZF_HIP(hipMemsetAsync(s->solve_partials, 0, 16 * 2 * (size_t)MO_REC_CAP * s->solve_grid, s->stream));
+        ZF_HIP(hipMemsetAsync(s->solve_totals, 0, 16 * 2 * (size_t)MO_REC_CAP, s->stream));
         // the result records: pinned host memory the kernel writes directly (fine-grained, device-visible)
         ZF_HIP(hipHostMalloc((void**)&s->h_solve_out, 2 * sizeof(mo_solve_result), hipHostMallocMapped));
         memset(s->h_solve_out, 0, 2 * sizeof(mo_solve_result));
@@ -1867,7 +1879,24 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
     const dim3 grid(s->solve_grid), block(MO_SOLVE_TPB);
     // rows of MO_SOLVE_TPB elements a workgroup owns / can keep in LDS
     const int64_t per_wg = (s->n + (int64_t)s->solve_grid * MO_SOLVE_TPB - 1) / ((int64_t)s->solve_grid * MO_SOLVE_TPB);
-    const int64_t cap = MO_SOLVE_LDS_BYTES / ((int64_t)(s->m + 1) * MO_SOLVE_TPB * sizeof(double));
+    // (round 4: the search for every m the engine takes, 2 .. 8.  m <= 3 fit 256 VGPRs without scratch; from m = 4 on the
+    //  solver step of the one deciding wave - the lane-parallel KKT systems of the simplex QP, (m + 1) x (m + 1) each -
+    //  spills 270 B .. 2 KB per thread to scratch, outside the element loops for m <= 6: tests/test_abi.py)
+    const void* fn = nullptr;
+#define MO_PICK(M_) case M_: fn = (const void*)k_dual_solve<M_>; break;
+    switch (s->m) {
+        MO_PICK(2) MO_PICK(3) MO_PICK(4) MO_PICK(5) MO_PICK(6) MO_PICK(7) MO_PICK(8)
+        default: return ZF_OK;
+    }
+#undef MO_PICK
+    if (s->solve_static_lds < 0) {
+        hipFuncAttributes fa;
+        ZF_HIP(hipFuncGetAttributes(&fa, fn));
+        s->solve_static_lds = (int64_t)fa.sharedSizeBytes;
+    }
+    int64_t lds_budget = (int64_t)160 * 1024 - s->solve_static_lds - 512;
+    if (lds_budget > MO_SOLVE_LDS_BYTES) lds_budget = MO_SOLVE_LDS_BYTES;
+    const int64_t cap = lds_budget / ((int64_t)(s->m + 1) * MO_SOLVE_TPB * sizeof(double));
     A.resident_rows = (int)(per_wg < cap ? per_wg : cap);
     const size_t lds = (size_t)A.resident_rows * (s->m + 1) * MO_SOLVE_TPB * sizeof(double);
     const bool set_attr = s->solve_lds_set != lds;   // (driver calls of several microseconds: once, not per trial)
@@ -1878,7 +1907,6 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
         s->force_timeouts -= 1;
         A.force_timeout = 1;
     }
-    const void* fn = s->m == 2 ? (const void*)k_dual_solve<2> : (const void*)k_dual_solve<3>;
     if (set_attr) {
         ZF_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // Every workgroup spins on grid-wide hand-overs: the whole grid has to be resident at once.  What the
@@ -1888,8 +1916,7 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
         int per_cu = 0, dev = 0, cus = 0;
         ZF_HIP(hipGetDevice(&dev));
         ZF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (s->m == 2) ZF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dual_solve<2>, MO_SOLVE_TPB, lds));
-        else ZF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dual_solve<3>, MO_SOLVE_TPB, lds));
+        ZF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, MO_SOLVE_TPB, lds));
         if ((int64_t)per_cu * cus < (int64_t)s->solve_grid) {
             s->solve_unavailable = true;
             s->solve_lds_set = (size_t)-1;
@@ -1897,8 +1924,10 @@ int mo_trial_launch(zf_mo* s, double lr, const double* f_y, const double* F_old,
             return ZF_OK;
         }
     }
-    if (s->m == 2) hipLaunchKernelGGL(k_dual_solve<2>, grid, block, lds, s->stream, A);
-    else hipLaunchKernelGGL(k_dual_solve<3>, grid, block, lds, s->stream, A);
+    {
+        void* kargs[] = {(void*)&A};
+        ZF_HIP(hipLaunchKernel(fn, grid, block, kargs, lds, s->stream));
+    }
     ZF_HIP(hipGetLastError());
     s->last_nonce[slot] = A.nonce;
     s->last_slot = slot;

@@ -612,7 +612,12 @@ static int zf_predict_parts(zf_solver* s) {
         // done after max_iter / S of them - any shape may be due: the three kernels that between them run every shape,
         // each on the shapes it runs best (the general body alone took these solves from 5 880 to 4 900 it/s at n = 1e8:
         // it runs the replaying shapes at 1.65 ms against 1.28).  Grids of a few workgroups: the general body alone.
-        if (!s16 || s->grid > ZF_SMALL_GRID) return ZF_K_ALL;
+        if (!s16) return ZF_K_ALL;
+        if (s->grid > ZF_SMALL_GRID) {   // PART 1 on its shapes, the general body on every other one: two launches, one of them runs
+            s->fb_part = 1;
+            s->fb_len = 0;
+            return ZF_K_SHORT | ZF_K_FALLBACK;
+        }
         s->fb_part = -1;
         return ZF_K_FALLBACK;
     }
@@ -641,7 +646,13 @@ static int zf_predict_parts(zf_solver* s) {
             s->fb_part = -1;
             mask = ZF_K_FALLBACK;
         } else {
-            mask = left >= 2 * (int64_t)S ? (ZF_K_FULL | ZF_K_SHORT) : ZF_K_ALL;
+            if (left >= 2 * (int64_t)S) {
+                mask = ZF_K_FULL | ZF_K_SHORT;
+            } else {   // near max_iter any length may be due: PART 1 on its shapes, the general body on all others
+                s->fb_part = 1;
+                s->fb_len = 0;
+                mask = ZF_K_SHORT | ZF_K_FALLBACK;
+            }
         }
     }
     zf_shadow_advance(c);

@@ -544,7 +544,12 @@ def solve_dual_native(dual, m, w0, tol, max_iter):
             # where the values no longer resolve the decrease (~1e-12 |D| of rounding noise near the optimum) the
             # derivative along d decides: the approximate Wolfe conditions of Hager & Zhang (zf_dual::machine::ls_accept)
             dphi = (g_try - g_try.mean()) @ d
-            if f_try <= fun + 1e-10 * abs(fun) and 0.9 * slope <= dphi <= -(1.0 - 2e-4) * slope:
+            # (the value guard is waived where the values contradict the gradients - the reference's composed prox is
+            #  not the exact prox of several shifted l1 terms, so its dual value and gradient are not consistent there;
+            #  SciPy follows the gradient field: zf_dual::machine::ls_accept)
+            df, pred = f_try - fun, 0.5 * t * (slope + dphi)
+            value_ok = df <= 1e-10 * abs(fun) or abs(df - pred) > 0.5 * abs(df)
+            if value_ok and 0.9 * slope <= dphi <= -(1.0 - 2e-4) * slope:
                 break
             t *= 0.5
         w_prev = w
@@ -627,14 +632,19 @@ def solve_native(problem, x0, o):
     betas = []
     nit_done = trials_done = 0
     w_last = None
+    # which search produced the weights of how many trials (reported with the result when another search than the
+    # reference's was asked for: a requested "device" that was not attempted shows up as "native" / "scipy" counts)
+    searches = {"device": 0, "native": 0, "scipy": 0}
     if (lazy_f_y and not o["return_all"] and o["max_iter"] >= 1
             and os.environ.get("ZF_MO_LAUNCH_AHEAD", "1") != "0"):
-        out = _solve_native_ahead(eng, o, m, F_old, res, t0)
+        out = _solve_native_ahead(eng, o, m, F_old, res, t0, searches)
         if isinstance(out, _HandOver):
             # a device trial gave up in the middle of the solve: the loop below continues from the state it
             # left - x_k, x_{k-1}, y in the engine, the line search of iteration nit_done + 1 under way
             nit_done, trials_done, lr, F_old, t_state, betas, w_last = out
         elif out is not None:
+            if dual_solver != "scipy":
+                out[0]["dual_search_trials"] = dict(searches)
             return out
         else:
             eng.set_x0(x0)              # (no device trial for this problem: the loop below, from the start)
@@ -661,14 +671,18 @@ def solve_native(problem, x0, o):
                                                 o["max_iter_internal"])
                     if out is not None:
                         out, err, F_dev, f_y = out[:3], out[3], out[4:6], out[6]
+                        searches["device"] += 1
                 if f_y is None:   # the device search was not attempted (non-finite start): fetch f(y)
                     f_y = eng.get_f_y()
                 if out is None and use_native:   # the library's own dual solver: no Python between the evaluations
                     out = eng.solve_dual(lr, f_y, F_old, o["deprecated"], w0, o["tol_internal"],
                                          o["max_iter_internal"])
+                    if out is not None:
+                        searches["native"] += 1
                 if out is None:
                     dual = device_dual(eng, lr, f_y, F_old, o["deprecated"])
                     out = solve_dual(dual, m, w0, o["tol_internal"], o["max_iter_internal"], dual_solver)
+                    searches["native" if dual_solver in ("native", "device") else "scipy"] += 1
                 weight, dual_fun, nit_int = out
                 if err is None:
                     err = eng.recover(lr, weight)      # x+ and max|x+ - y|   (:206, :510)
@@ -696,6 +710,8 @@ def solve_native(problem, x0, o):
             bad = OptimizeResult()
             bad.update(success=False, message=f"Error: {str(exc)}", x=eng.get(X_K), fun=F_old, nit=nit - 1,
                        time=time.time() - t0, allvecs=allvecs, allfuns=allfuns, allerrs=allerrs)
+            if dual_solver != "scipy":
+                bad["dual_search_trials"] = dict(searches)
             return bad, _lib.ZF_BACKTRACK_FAILED
         if o["verbose"]:
             _print_row(nit, nit_int, err, fun, lr)
@@ -719,6 +735,8 @@ def solve_native(problem, x0, o):
         res.status, res.message, res.success = 0, _MSG_MAXITER, False
     res.update(x=eng.get(X_K), fun=F_old, nit=nit, allvecs=allvecs, allfuns=allfuns, allerrs=allerrs,
                time=time.time() - t0)
+    if dual_solver != "scipy":
+        res["dual_search_trials"] = dict(searches)   # (extension field: absent with the reference's own search)
     return res, status
 
 
@@ -728,7 +746,7 @@ class _HandOver(tuple):
     are what a ``warm_start`` search starts from)."""
 
 
-def _solve_native_ahead(eng, o, m, F_old, res, t0):
+def _solve_native_ahead(eng, o, m, F_old, res, t0, searches):
     """The outer loop (:474-538) with every trial launched AHEAD of its predecessor's result
     (dual_solver="device", built-in problems): while the host reads the record of trial k and does its
     bookkeeping, the kernel of trial k + 1 - enqueued under the assumption that k is accepted, gated on
@@ -795,6 +813,7 @@ def _solve_native_ahead(eng, o, m, F_old, res, t0):
                     return None                               # from the start: the caller's loop (host search)
                 raise RuntimeError("the device-side trial was not attempted in the middle of a solve")
             weight, dual_fun, nit_int, err, f_x, g_x, f_y, accepted = out
+            searches["device"] += 1
             w_last = weight
             fun = -dual_fun                                   # (:207)
             F_new = f_x + g_x                                 # (:295) formed and tested on the device
