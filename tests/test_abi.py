@@ -33,6 +33,7 @@ def test_struct_mirrors():
     assert lib.zf_sizeof_control() == C.sizeof(_lib.Control) == 416
     assert C.sizeof(_lib.ProblemDesc) == 128
     assert C.sizeof(_lib.Options) == 64
+    assert C.sizeof(_lib.CommDesc) == 296
 
 
 def test_error_reporting_is_c_style():
@@ -94,6 +95,17 @@ def test_short_output_buffers_are_refused():
     rc = raw(lib.zf_solver_launch_counts, [P, P, I], C.addressof(dummy), _lib.ptr(iout), 1)
     assert rc == -2 and not iout.any()
     rc = raw(lib.zf_mo_solve_stats, [P, P, I], C.addressof(dummy), _lib.ptr(iout), 5)
+    assert rc == -2 and not iout.any()
+    # ABI 5: the communicator's self-description, the exchange timing and the per-launch records
+    desc = _lib.CommDesc()
+    rc = raw(lib.zf_comm_describe, [P, P, I], C.addressof(dummy), C.addressof(desc), C.sizeof(desc) - 8)
+    assert rc == -2 and b"out_bytes" in lib.zf_last_error() and bytes(desc) == bytes(C.sizeof(desc))
+    rc = raw(lib.zf_solver_exchange_stats, [P, P, I], C.addressof(dummy), _lib.ptr(out), 1)
+    assert rc == -2 and not out.any()
+    cnt = C.c_int64(7)
+    rc = raw(lib.zf_solver_pass_records, [P, P, I, P], C.addressof(dummy), None, 4, C.addressof(cnt))
+    assert rc == -2 and cnt.value == 7
+    rc = raw(lib.zf_solver_launch_counts, [P, P, I], C.addressof(dummy), _lib.ptr(iout), 0)
     assert rc == -2 and not iout.any()
     assert (np.frombuffer(dummy, dtype=np.uint8) == 0xA5).all(), "an entry point wrote through the handle before checking its arguments"
 

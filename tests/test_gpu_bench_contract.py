@@ -58,6 +58,15 @@ def test_bench_json_line():
 def test_bench_flags():
     d = _run("--no-cpu-baseline", "--no-kernel-events")
     assert "cpu_baseline" not in d and d["steps"] == 21
+    assert d["config"]["rccl"] is None and d["config"]["overrides"] == {}
+    regimes = d["config"]["iterations_per_sec_by_regime"]
+    assert {"clean_regime_K20_W5", "clean_regime_K24_W5", "clean_regime_K28_W5", "clean_regime_K30_W5",
+            "across_the_noise_floor_K100_W10"} <= set(regimes) and all(v > 0 for v in regimes.values())
+    # the per-pass exchange through a REAL (1-rank) RCCL communicator: the line says what RCCL itself reports
+    d = _run("--no-cpu-baseline", "--no-regimes", "--libcomm")
+    r = d["config"]["rccl"]
+    assert r["via"].startswith("zf_comm (RCCL") and (r["world"], r["rank_count_seen"], r["rccl_user_rank"]) == (1, 1, 0)
+    assert "rccl" in r["library"].lower() and r["exchanges_timed"] > 0 and 0.0 < r["exchange_ms_per_pass"] < 5.0
     d = _run("--no-cpu-baseline", "--total-n", "3000000")
     assert d["scaling"] == "strong" and d["config"]["n_total"] == 3000000
 
@@ -102,6 +111,10 @@ def test_bench_n_gt_1_code_path_with_eight_thread_ranks():
     assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["dtype"]) == (1, 20, 5, "weak", "f64")
     cfg = d["config"]
     assert cfg["thread_ranks"] == 8 and cfg["n_total"] == 80000000 and cfg["n_per_gpu"] == 10000000
+    # what carried the per-pass exchange, as the communicator reports it, and what one exchange cost on rank 0's stream
+    assert cfg["rccl"]["world"] == 8 and cfg["rccl"]["rank_count_seen"] == 8 and "thread-rank" in cfg["rccl"]["via"]
+    assert cfg["rccl"]["exchanges_timed"] > 0 and cfg["rccl"]["exchange_ms_per_pass"] > 0.0
+    assert cfg["overrides"] == {}
     assert "DRY RUN" in cfg["parallelism"] and "cpu_baseline" not in d
     assert cfg["passes_per_block"] >= 2 and cfg["temporal_blocking_chain"] == 16
     # whole-job aggregate in units of one 1e8-element shard: 8 ranks x 0.1 shard each

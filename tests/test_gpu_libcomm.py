@@ -30,6 +30,12 @@ def test_one_rank_rccl_communicator_in_the_library():
     comm.all_gather(a, b)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+    # what the communicator says about itself (zf_comm_describe): RCCL's OWN queries of the ncclComm_t, the library file
+    # the symbols came from, the all-gathers issued - the record bench.py puts on its line (config.rccl)
+    info = comm.describe()
+    assert info["via"].startswith("zf_comm (RCCL") and (info["world"], info["rank"]) == (1, 0)
+    assert info["rank_count_seen"] == 1 and info["rccl_user_rank"] == 0 and info["rccl_device"] == torch.cuda.current_device()
+    assert "rccl" in info["library"].lower() and info["rccl_version"] > 0 and info["all_gathers_issued"] == 1
     n = 50001
     d, c, lam = P.make_pdiag(n, seed=1)
     kw = dict(lr=4.0, nesterov=True, tol=1e-8, max_iter=80)
@@ -49,6 +55,21 @@ def test_one_rank_rccl_communicator_in_the_library():
     # (the unsharded small matrix takes the two-launch path, the sharded sequence the general one: other
     #  summation orders of grad and f, same iterates to rounding)
     assert shard.nit == plain.nit and np.linalg.norm(shard.x - plain.x) <= 1e-12 * np.linalg.norm(plain.x)
+    assert comm.describe()["all_gathers_issued"] > 10      # every pass of the sharded solves exchanged through it
+    # the per-pass exchange timed by the solver itself (zf_solver_exchange_stats) and the per-launch records
+    from zfista_amd import _lib
+    from zfista_amd.proximal_gradient import NativeRun
+
+    o = dict(lr=0.45, tol=0.0, tol_internal=1e-12, max_iter=64, max_backtrack_iter=100, decay_rate=0.5, nesterov=True,
+             nesterov_ratio=(0, 0.25), deprecated=False, sub_iters=16)
+    run = NativeRun(DiagQuadL1(d, c, lam, group=comm), np.zeros(n), o, timing=True)
+    while run.status == _lib.ZF_RUNNING:
+        run.advance(2)
+    ms, cnt = run.solver.exchange_stats()
+    rec = run.solver.pass_records()
+    assert len(rec) == 4 and cnt >= 4 and 0.0 < ms < 5.0, (ms, cnt, rec)   # (the init exchange is timed too)
+    assert all(lag == 0 and fresh == 16 and passes == 0 and t > 0 for lag, fresh, passes, t in rec), rec
+    run.solver.close()
     comm.close()
 
 
