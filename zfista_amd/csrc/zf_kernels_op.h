@@ -30,6 +30,30 @@ struct zf_op_args {
     const double* taps;      // K x K, row-major
 };
 
+// The fused forms (inside the solver loop: three launches per trial instead of six).
+// zf_op_adjoint_kernel<true>: the residual at y is formed in the tile load - r = (s_k + beta (s_k - s_{k-1})) - b by
+// linearity from the cached B W^-1 x_k, B W^-1 x_{k-1} - and the workgroup's share of |r|^2 (its own tile, no halo)
+// goes to part_y.  zf_op_apply_kernel<true>: the workgroup's share of |s+ - b|^2 goes to part_x, and the LAST workgroup
+// to arrive adds both in workgroup order, adds the partials of the prox step, builds the pack and runs the decide
+// pass (model value, acceptance, lr decay, termination, buffer hand-over, trace row:
+// proximal_gradient.py:149-155,:298-307,:510,:525,:539) - the tail of zf_ls_small_rows_kernel for this operator.
+struct zf_op_fuse {
+    const double* b;          // observed image
+    const double* sk[3];      // ring of B W^-1 x (zf_solver::sring)
+    double scale, lam;
+    int nesterov;
+    double* part_y;           // [workgroups] shares of |r(y)|^2   (written when need_grad)
+    double* part_x;           // [workgroups] shares of |s+ - b|^2
+    unsigned* cnt;            // arrival counter of zf_op_apply_kernel<true> (zero between launches)
+    const double* blk_part;   // the prox step's partials, quantity-major [6][grid_step]
+    int grid_step;
+    double* ls_scal;          // [0] f(y) [1] f(x+)
+    double* pack;
+    zf_control* ctl_rw;
+    double* trace;
+    const double* beta_ring;
+};
+
 // scipy.signal.correlate2d(..., boundary="symm"): the image mirrored about its edges, edge sample included
 __device__ __forceinline__ int zf_op_reflect(int i, int n) {
     if (i < 0) i = -i - 1;
@@ -58,13 +82,19 @@ __device__ __forceinline__ double zf_op_correlate(const double* tile, const doub
     return acc;
 }
 
-// s = B W^-1 x.   SRC_RING: x = ring buffer (cur + slot) % 3 and s likewise (the trial's x+: slot 1); else x / s as given.
+// s = B W^-1 x.   Inside the loop (ctl given): x = ring buffer (cur + slot) % 3 and s likewise (the trial's x+: slot 1);
+// else x / s as given.  FUSED: see zf_op_fuse.
+template <bool FUSED>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, const double* __restrict__ x0,
                                                                const double* __restrict__ x1,
                                                                const double* __restrict__ x2, double* s0, double* s1,
-                                                               double* s2, int slot) {
+                                                               double* s2, int slot, zf_op_fuse F) {
     __shared__ double tile[ZF_OP_LH * ZF_OP_LW];
     __shared__ double taps[ZF_OP_MAXK * ZF_OP_MAXK];
+    __shared__ double s_w[ZF_WAVES];
+    __shared__ double s_pack[ZF_PACK_LEN];
+    __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
+    __shared__ int s_last;
     int idx = 0;
     if (P.ctl) {
         if (P.ctl->status != ZF_RUNNING) return;
@@ -85,16 +115,98 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
     __syncthreads();
     const int ty = threadIdx.x / ZF_OP_TX, tx = threadIdx.x % ZF_OP_TX;
     const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy < P.H && ox < P.W) s[(int64_t)oy * P.W + ox] = zf_op_correlate(tile, taps, K, ty, tx);
+    double sq = 0.0;
+    if (oy < P.H && ox < P.W) {
+        const double v = zf_op_correlate(tile, taps, K, ty, tx);
+        s[(int64_t)oy * P.W + ox] = v;
+        if constexpr (FUSED) {
+            const double rv = v - F.b[(int64_t)oy * P.W + ox];
+            sq = rv * rv;
+        }
+    }
+    if constexpr (FUSED) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        sq = zf_wave_sum(sq);
+        if (lane == 0) s_w[wave] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            double t = s_w[0];
+            for (int w = 1; w < ZF_WAVES; ++w) t += s_w[w];
+            zf_publish(F.part_x + blockIdx.x, t);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(F.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (tk == (unsigned)(gridDim.x - 1));
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(F.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last || wave != 0) return;
+        // last arriver, wave 0: f(y), f(x+) from the workgroup shares (chunks of 64 workgroups in order, within a chunk
+        // the fixed shuffle tree), the prox step's partials, the pack, the decide pass
+        double fy = 0.0, fx = 0.0;
+        for (int g0 = 0; g0 < (int)gridDim.x; g0 += 64) {
+            const int g = g0 + lane;
+            const bool in = g < (int)gridDim.x;
+            fx += zf_wave_sum(in ? zf_consume(F.part_x + g) : 0.0);
+            fy += zf_wave_sum(in ? F.part_y[g] : 0.0);
+        }
+        const double nx = sqrt(fx), ny = sqrt(fy);
+        const double f_x = F.scale * (nx * nx), f_y = F.scale * (ny * ny);     // np.linalg.norm(.) ** 2
+        double dot = 0.0, ss = 0.0, l1 = 0.0, mx = 0.0;
+        const int64_t G = F.grid_step;
+        for (int64_t g0 = 0; g0 < G; g0 += 64) {
+            const int64_t g = g0 + lane;
+            const bool in = g < G;
+            dot += zf_wave_sum(in ? F.blk_part[1 * G + g] : 0.0);
+            ss += zf_wave_sum(in ? F.blk_part[2 * G + g] : 0.0);
+            l1 += zf_wave_sum(in ? F.blk_part[3 * G + g] : 0.0);
+            mx = fmax(mx, zf_wave_max(in ? F.blk_part[5 * G + g] : 0.0));
+        }
+        double pk[ZF_PACK_LEN];
+        // (a rejected trial leaves y as it is: the shares of |r(y)|^2 - and f(y) - are those of the trial before)
+        pk[ZF_PK_FY] = __shfl(f_y, 0, 64);
+        pk[ZF_PK_DOT] = __shfl(dot, 0, 64);
+        pk[ZF_PK_SS] = __shfl(ss, 0, 64);
+        pk[ZF_PK_GX] = F.lam * __shfl(l1, 0, 64);
+        pk[ZF_PK_FX] = __shfl(f_x, 0, 64);
+        pk[ZF_PK_ERR] = __shfl(mx, 0, 64);
+        pk[6] = 0.0;
+        pk[7] = 0.0;
+        if (lane == 0) {
+            F.ls_scal[0] = pk[ZF_PK_FY];
+            F.ls_scal[1] = pk[ZF_PK_FX];
+#pragma unroll
+            for (int k = 0; k < ZF_PACK_LEN; ++k) {
+                F.pack[k] = pk[k];
+                s_pack[k] = pk[k];
+            }
+        }
+        zf_decide_pass_wave(F.ctl_rw, s_pack, pk, F.trace, F.beta_ring, lane, 64, s_pre);
+    }
 }
 
-// grad = 2 scale W (B r):  r an H x W image (the residual at y); skipped unless ctl->need_grad.
+// grad = 2 scale W (B r):  r an H x W image (the residual at y); skipped unless ctl->need_grad.  FUSED: r is formed in
+// the tile load from the ring of B W^-1 x (zf_op_fuse), `r` is not read.
+template <bool FUSED>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, const double* __restrict__ r,
-                                                                 double* __restrict__ grad, double two_scale) {
+                                                                 double* __restrict__ grad, double two_scale, zf_op_fuse F) {
     __shared__ double tile[ZF_OP_LH * ZF_OP_LW];
     __shared__ double taps[ZF_OP_MAXK * ZF_OP_MAXK];
     __shared__ double blurred[ZF_OP_TY * ZF_OP_TX];
+    __shared__ double s_w[ZF_WAVES];
     if (P.ctl && (P.ctl->status != ZF_RUNNING || !P.ctl->need_grad)) return;
+    const double* __restrict__ sk = nullptr;
+    const double* __restrict__ so = nullptr;
+    double beta = 0.0;
+    if constexpr (FUSED) {
+        const int cur = P.ctl->cur;
+        sk = F.sk[cur];
+        so = F.sk[(cur + 2) % 3];
+        beta = F.nesterov ? P.ctl->beta_next : 0.0;
+    }
     const int K = P.K, half = K / 2, off = ZF_OP_HALO - half;
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
     const int oy0 = ((int)blockIdx.x / tiles_x) * ZF_OP_TY, ox0 = ((int)blockIdx.x % tiles_x) * ZF_OP_TX;
@@ -103,12 +215,37 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
     for (int k = threadIdx.x; k < lw * lh; k += ZF_BLOCK) {
         const int ly = k / lw, lx = k % lw;
         const int iy = zf_op_reflect(oy0 + ly - half, P.H), ix = zf_op_reflect(ox0 + lx - half, P.W);
-        tile[(ly + off) * ZF_OP_LW + lx + off] = r[(int64_t)iy * P.W + ix];
+        const int64_t at = (int64_t)iy * P.W + ix;
+        double rv;
+        if constexpr (FUSED) {
+            double ay = sk[at];
+            if (F.nesterov) ay = ay + beta * (ay - so[at]);   // B W^-1 y by linearity (zf_resid_y_kernel's expression)
+            rv = ay - F.b[at];
+        } else {
+            rv = r[at];
+        }
+        tile[(ly + off) * ZF_OP_LW + lx + off] = rv;
     }
     __syncthreads();
     const int ty = threadIdx.x / ZF_OP_TX, tx = threadIdx.x % ZF_OP_TX;
     blurred[ty * ZF_OP_TX + tx] = (oy0 + ty < P.H && ox0 + tx < P.W) ? zf_op_correlate(tile, taps, K, ty, tx) : 0.0;
+    if constexpr (FUSED) {   // this workgroup's share of |r|^2: its own pixels (the halo belongs to the neighbours)
+        double sq = 0.0;
+        if (oy0 + ty < P.H && ox0 + tx < P.W) {
+            const double rv = tile[(ty + ZF_OP_HALO) * ZF_OP_LW + tx + ZF_OP_HALO];
+            sq = rv * rv;
+        }
+        sq = zf_wave_sum(sq);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sq;
+    }
     __syncthreads();
+    if constexpr (FUSED) {
+        if (threadIdx.x == 0) {
+            double t = s_w[0];
+            for (int w = 1; w < ZF_WAVES; ++w) t += s_w[w];
+            F.part_y[blockIdx.x] = t;
+        }
+    }
     // one Haar level of the tile: thread t < 64 owns the 2 x 2 block (t / 16, t % 16)
     if (threadIdx.x < (ZF_OP_TY / 2) * (ZF_OP_TX / 2)) {
         const int by = threadIdx.x / (ZF_OP_TX / 2), bx = threadIdx.x % (ZF_OP_TX / 2);

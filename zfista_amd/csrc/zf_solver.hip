@@ -267,8 +267,8 @@ static void zf_launch_apply_A(zf_solver* s, const zf_control* ctl, zf_ring3 xr, 
     const zf_problem_desc& d = s->desc;
     const int64_t n = d.n, m = d.m_rows;
     if (d.kind == ZF_PROBLEM_BLUR_HAAR_L1) {
-        hipLaunchKernelGGL(zf_op_apply_kernel, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, ctl), xr.p[0],
-                           xr.p[1], xr.p[2], sout.p[0], sout.p[1], sout.p[2], slot);
+        hipLaunchKernelGGL(zf_op_apply_kernel<false>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, ctl), xr.p[0],
+                           xr.p[1], xr.p[2], sout.p[0], sout.p[1], sout.p[2], slot, zf_op_fuse());
         return;
     }
     const int V = (n % 2 == 0) ? 2 : 1;
@@ -391,6 +391,10 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         for (int k = 0; k < 3; ++k) s->sring.p[k] = s->sbuf + k * m_pad;
         ZF_TRY(hipMalloc(&s->resid, sizeof(double) * m_pad));
         ZF_TRY(hipMalloc(&s->ls_scal, sizeof(double) * 8));
+        ZF_TRY(hipMalloc(&s->row_part, sizeof(double) * 2 * zf_op_grid(*desc)));   // shares of |r(y)|^2 and of |s+ - b|^2
+        ZF_TRY(hipMemsetAsync(s->row_part, 0, sizeof(double) * 2 * zf_op_grid(*desc), s->stream));
+        ZF_TRY(hipMalloc(&s->ls_cnt, 64));
+        ZF_TRY(hipMemsetAsync(s->ls_cnt, 0, 64, s->stream));
     }
     if (desc->kind == ZF_PROBLEM_LEAST_SQUARES_L1) {
         const int64_t m = desc->m_rows;
@@ -781,25 +785,50 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         const int64_t n = d.n, m = d.m_rows;
         const int V = (n % 2 == 0) ? 2 : 1;
         // (1) r = A y - b by linearity, f(y); grad = 2 scale A^T r   [only when y changed]
-        hipLaunchKernelGGL(zf_resid_y_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl,
-                           s->beta_ring, s->sring, d.b, s->resid, d.scale, m, s->ls_scal + 0,
-                           (int)s->opt.nesterov);
+        if (d.kind != ZF_PROBLEM_BLUR_HAAR_L1)   // (the operator problem forms r inside its adjoint kernel)
+            hipLaunchKernelGGL(zf_resid_y_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl,
+                               s->beta_ring, s->sring, d.b, s->resid, d.scale, m, s->ls_scal + 0,
+                               (int)s->opt.nesterov);
         const int64_t nv = n / V;
         dim3 gT((unsigned)((nv + ZF_BLOCK - 1) / ZF_BLOCK), (unsigned)s->slices);
         if (d.kind == ZF_PROBLEM_BLUR_HAAR_L1) {
-            // grad = 2 scale W B r in one launch (no slab, no combine); then the prox step and s+ = B W^-1 x+
-            hipLaunchKernelGGL(zf_op_adjoint_kernel, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, s->ctl),
-                               s->resid, s->grad, 2 * d.scale);
+            // THREE launches per trial (unsharded, deciding in the launch): the residual at y formed inside the adjoint
+            // kernel's tile load, the prox step, and s+ = B W^-1 x+ whose last workgroup sums f(y), f(x+) and the prox
+            // step's partials and decides (zf_op_fuse) - instead of resid_y / adjoint / prox / apply / resid_x / finalize
+            zf_op_fuse F;
+            memset(&F, 0, sizeof(F));
+            F.b = d.b;
+            for (int k = 0; k < 3; ++k) F.sk[k] = s->sring.p[k];
+            F.scale = d.scale;
+            F.lam = d.lam;
+            F.nesterov = s->opt.nesterov;
+            F.part_y = s->row_part;
+            F.part_x = s->row_part + zf_op_grid(d);
+            F.cnt = s->ls_cnt;
+            F.blk_part = s->blk_part;
+            F.grid_step = s->grid;
+            F.ls_scal = s->ls_scal;
+            F.pack = s->pack_local;
+            F.ctl_rw = s->ctl;
+            F.trace = s->trace;
+            F.beta_ring = s->beta_ring;
+            hipLaunchKernelGGL(zf_op_adjoint_kernel<true>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, s->ctl),
+                               nullptr, s->grad, 2 * d.scale, F);
             a.p0 = s->grad;
             a.p1 = nullptr;
             if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
             zf_launch_trial_kernels(s, a, false);
             if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
-            zf_ring3 xr3 = {{s->xb[0], s->xb[1], s->xb[2]}};
-            zf_launch_apply_A(s, s->ctl, xr3, s->sring, 1);
-            hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1, d.b,
-                               d.scale, m, s->ls_scal + 1);
-            zf_launch_finalize(s, decide_in_launch);
+            if (decide_in_launch) {
+                hipLaunchKernelGGL(zf_op_apply_kernel<true>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, s->ctl),
+                                   s->xb[0], s->xb[1], s->xb[2], s->sring.p[0], s->sring.p[1], s->sring.p[2], 1, F);
+            } else {   // (a host-driven step sequence: s+, f(x+) and the finalize launch as for a matrix)
+                zf_ring3 xr3 = {{s->xb[0], s->xb[1], s->xb[2]}};
+                zf_launch_apply_A(s, s->ctl, xr3, s->sring, 1);
+                hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->ctl, s->sring, 1, d.b,
+                                   d.scale, m, s->ls_scal + 1);
+                zf_launch_finalize(s, false);
+            }
             ZF_HIP(hipGetLastError());
             return ZF_OK;
         }
@@ -1771,13 +1800,13 @@ extern "C" int zf_op_eval(const double* taps_dev, int32_t k, const double* b_dev
     if (rc == ZF_OK) {
         ZF_OP(hipMemcpyAsync(x, x_host, sizeof(double) * n, hipMemcpyHostToDevice, nullptr));
         zf_ring3 sr = {{sv, sv, sv}};
-        hipLaunchKernelGGL(zf_op_apply_kernel, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, nullptr, zf_op_of(d, nullptr), x, x, x,
-                           sv, sv, sv, -1);
+        hipLaunchKernelGGL(zf_op_apply_kernel<false>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, nullptr, zf_op_of(d, nullptr), x, x, x,
+                           sv, sv, sv, -1, zf_op_fuse());
         hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, nullptr, nullptr, sr, -1, b_dev, scale, n, fdev);
         if (grad_out_host) {
             hipLaunchKernelGGL(zf_axmb_kernel, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, nullptr, sv, b_dev, n);
-            hipLaunchKernelGGL(zf_op_adjoint_kernel, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, nullptr, zf_op_of(d, nullptr), sv,
-                               grad, 2 * scale);
+            hipLaunchKernelGGL(zf_op_adjoint_kernel<false>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, nullptr, zf_op_of(d, nullptr), sv,
+                               grad, 2 * scale, zf_op_fuse());
             ZF_OP(hipMemcpyAsync(grad_out_host, grad, sizeof(double) * n, hipMemcpyDeviceToHost, nullptr));
         }
         ZF_OP(hipGetLastError());
