@@ -45,6 +45,17 @@ if os.environ.get("ZF_PERSIST") == "0":
             continue
         s0, b, tl = t[slot, :, 0], t[slot, :, 2], t[slot, :, 3]
         base = s0.min()
+        hw = raw[:8 * G * 8].reshape(8, G, 8)[slot, :, 7]
+        cu = ((hw >> 32) & 0xF) * 65536 + (hw & 0xFF00)          # XCC, SE / SH / CU of HW_ID
+        ncu = len(set(cu.tolist()))
+        overlap = 0
+        for key in set(cu.tolist()):
+            idx = np.where(cu == key)[0]
+            iv = sorted((s0[i], tl[i]) for i in idx)
+            overlap += sum(1 for a, b_ in zip(iv, iv[1:]) if b_[0] < a[1])
+        per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
+        print(f"         CUs used {ncu}, workgroups per CU min {per_cu.min()} max {per_cu.max()}, pairs on one CU that overlap in time: {overlap}; "
+              f"starts in the first 5 us: {(s0 - base < 5).sum()}, later than 30 us: {(s0 - base > 30).sum()}")
         print(f"slot {slot}: start spread {s0.max() - base:5.1f} | body mean {(b - s0).mean():7.1f} (min {(b - s0).min():.1f} max {(b - s0).max():.1f}) | "
               f"last body end {b.max() - base:7.1f} | last tail end {tl.max() - base:7.1f} (+{tl.max() - b.max():5.1f})")
     sys.exit(0)

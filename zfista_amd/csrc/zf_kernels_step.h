@@ -123,6 +123,9 @@ constexpr int ZF_TILE_U = 4;
 #ifndef ZF_X_NT
 #define ZF_X_NT 1   // nontemporal loads of x_k, x_{k-1} in chained passes: read once per pass (tools/tune_trial.hip: -1 %)
 #endif
+#ifndef ZF_X_COH
+#define ZF_X_COH 0   // (experiment) agent-coherent x loads / stores in the full chain
+#endif
 #ifndef ZF_S8_UB
 #define ZF_S8_UB 2   // units per load batch of the 8-trial chain: half a tile, software-pipelined (4 = whole tile, no pipeline)
 #endif
@@ -143,14 +146,24 @@ template <bool NT> __device__ __forceinline__ void zf_st2(zf_d2* p, zf_d2 v) {
     if (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
+// AGENT-COHERENT 16-byte accesses (sc1): written through / read past the L2 of the XCD, which is not coherent with the
+// other seven - what a workgroup of ANOTHER kernel running at the same time stored this way is seen by a load of
+// this kind as soon as the store has been acknowledged (s_waitcnt vmcnt).  The compiler does not count an asm store
+// in its s_waitcnt bookkeeping; vector-memory operations retire in issue order, so its own waits only get stricter.
+__device__ __forceinline__ void zf_st2_coh(zf_d2* p, zf_d2 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
 
 // LDS-DMA: one 16-byte global load per lane straight into LDS (no VGPR destination).  The wave's 64
 // pieces land lane-linear at the wave-uniform byte address `lds_dst` (M0) + lane * 16.  hipcc does not
 // count an asm load in its s_waitcnt bookkeeping: the caller waits with zf_wait_vm<N>() before the
 // LDS is read.  M0 is compiler-reserved: saved and restored inside the statement (guide, 5 / asm notes).
-template <bool NT> __device__ __forceinline__ void zf_glds16(const void* gsrc, unsigned lds_dst) {
+template <bool NT, bool COH = false> __device__ __forceinline__ void zf_glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
-    if (NT)
+    if (COH)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else if (NT)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     else
@@ -705,8 +718,13 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
                     zf_st2<NT>(reinterpret_cast<zf_d2*>(A.hist + ((nit + j + 1) % A.hist_cap) * A.hist_stride) + i, a);
             }
         }
-        zf_st2<NT>(reinterpret_cast<zf_d2*>(out_last) + i, a);
-        if (S > 1 && (FRESH_FULL || ntr >= 2)) zf_st2<NT>(reinterpret_cast<zf_d2*>(out_prev) + i, o);
+        if constexpr (ZF_X_COH != 0 && FULL && !HIST) {
+            zf_st2_coh(reinterpret_cast<zf_d2*>(out_last) + i, a);
+            zf_st2_coh(reinterpret_cast<zf_d2*>(out_prev) + i, o);
+        } else {
+            zf_st2<NT>(reinterpret_cast<zf_d2*>(out_last) + i, a);
+            if (S > 1 && (FRESH_FULL || ntr >= 2)) zf_st2<NT>(reinterpret_cast<zf_d2*>(out_prev) + i, o);
+        }
         // long chains: finish one unit before the next (interleaving four 8-trial chains costs
         // ~100 more VGPRs and halves the occupancy)
         if (S >= 8) __builtin_amdgcn_sched_barrier(0);
@@ -784,8 +802,8 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
         auto issue = [&](int k) {
             const int64_t i = unit_of(k);
             const unsigned base = lds0 + (unsigned)(k % NST) * (ZF_GLDS_STAGE_UNITS * 16u);
-            zf_glds16<NT && (ZF_X_NT != 0)>(xk2 + i, base);
-            if (NESTEROV) zf_glds16<NT && (ZF_X_NT != 0)>(xo2 + i, base + ZF_BLOCK * 16u);
+            zf_glds16<NT && (ZF_X_NT != 0), ZF_X_COH != 0>(xk2 + i, base);
+            if (NESTEROV) zf_glds16<NT && (ZF_X_NT != 0), ZF_X_COH != 0>(xo2 + i, base + ZF_BLOCK * 16u);
             zf_glds16<NT>(p02 + i, base + 2 * ZF_BLOCK * 16u);
             zf_glds16<NT>(p12 + i, base + 3 * ZF_BLOCK * 16u);
         };
@@ -1048,8 +1066,18 @@ __device__ __forceinline__ void zf_pass_finish(const zf_step_args& A, const doub
 // the branches (S = 16: 274 VGPRs for parts 0 + 1, ~400 for parts 1 + 2 - one wave per SIMD instead of two;
 // S = 8: 207 instead of 190); every further launch costs a kernel boundary (~1.5-4 us) per pass - so the host
 // launches the ONE kernel it predicts (zf_predict_parts) and all of 0, 1, 2 only when it cannot know.
+// (debug builds with phase stamps: the stamps cost registers - 258 instead of 240 for the full chain, ONE wave per SIMD
+//  instead of two, and every conclusion drawn from them would be about another kernel; hold the allocator to the product's
+//  occupancy there)
+#ifndef ZF_TRIAL_ATTR
+#ifdef ZF_PERSIST_DEBUG
+#define ZF_TRIAL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define ZF_TRIAL_ATTR
+#endif
+#endif
 template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false, int PART = 0, int L = 0>
-__global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
+__global__ __launch_bounds__(ZF_BLOCK) ZF_TRIAL_ATTR void zf_trial_kernel(zf_step_args A) {
     static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
     static_assert(PART <= 1 || S >= 16, "the third and fourth kernels exist for chains of 16 only");
     static_assert(PART != 3 || (L >= ZF_MID_MIN && L <= ZF_MID_MAX), "mid chains: ZF_MID_MIN .. ZF_MID_MAX trials");
@@ -1085,6 +1113,9 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
                 dbg = reinterpret_cast<long long*>(A.hist) + ((int64_t)(A.pass_seq % 8) * gridDim.x + blockIdx.x) * 8;
                 dbg[0] = wall_clock64();
                 dbg[6] = gridDim.x;
+                // where this workgroup runs: XCC_ID (hwreg 20) above HW_ID (hwreg 4: cu_id [11:8], sh_id [12], se_id [15:13])
+                dbg[7] = ((long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |
+                         (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
             }
         }
 #endif
