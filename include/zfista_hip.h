@@ -315,7 +315,11 @@ int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches);
  * launches the one it expects once a poll has shown it the control block - unsharded, and sharded through the
  * library's communicator; behind a chunk that saw rejections the general body rides along as the complement of the
  * expected kernel (on small grids: alone); with nothing known, the three kernels that between them run every shape.
- * On grids the device holds at once, consecutive full chains share ONE launch (zf_persist_kernel; ZF_PERSIST=0: off). */
+ * With ZF_PERSIST=1, on grids the device holds at once, consecutive full chains share ONE launch (zf_persist_kernel).
+ * With count >= 6 also out[4] = run-ahead passes launched, out[5] = those of them launched while their predecessor
+ * was still in flight: on such grids consecutive full chains go alternately to the solver's stream and a second one
+ * of its own, pass p + 1 running while pass p is finalised (zf_runahead_kernel; ZF_RUNAHEAD=0: off; six iterate
+ * buffers instead of four).  zf_solver_enqueue_steps returns with the solver's stream made to wait for the second. */
 int zf_solver_launch_counts(zf_solver* s, int64_t* out, int64_t count /* >= 2 */);
 /* the same window split by the shape of the pass, which the kernel logs itself: out[0], out[1] = mean
  * ms and count of full chains (sub_iters fresh trials, nothing replayed); out[2], out[3] = every other

@@ -1,0 +1,124 @@
+"""GPU: run-ahead passes (zf_runahead_kernel).
+
+On grids the device holds at once (n up to ~2.5e7) consecutive full-chain passes go alternately to two streams: pass
+p + 1 starts while pass p is still being finalised - workgroup j as soon as workgroup j of pass p has stored its
+iterates - on the control block the host EXPECTS pass p to leave.  A pass whose predecessor did not go as expected
+(a rejected trial, a termination inside the chain) is void.  Everything a solve with one launch per pass on one stream
+produces - trace rows, iterates, lr / trial sequences, statuses - must come out bit for bit the same (ZF_RUNAHEAD=0
+is that solve), whatever the chunking of the host loop, and equal the one-trial-per-pass loop."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(lr=1, tol=1e-5, tol_internal=1e-12, max_iter=1000000, max_backtrack_iter=100, decay_rate=0.5,
+            nesterov=False, nesterov_ratio=(0, 0.25), deprecated=False, return_all=False)
+
+
+def _pdiag(n, seed=1, bounds=None):
+    from oracle import problems_ref as P
+    from zfista_amd.problems import DiagQuadL1
+
+    d, c, lam = P.make_pdiag(n, seed=seed)
+    return DiagQuadL1(d, c, lam) if bounds is None else DiagQuadL1(d, c, lam, bounds=bounds)
+
+
+def _run(prob, x0, opts, sub=16, chunk=64):
+    from zfista_amd import _lib
+    from zfista_amd.proximal_gradient import NativeRun
+
+    o = dict(BASE)
+    o.update(opts)
+    o["sub_iters"] = sub
+    run = NativeRun(prob, x0, o)
+    rows = [np.zeros((0, _lib.ZF_TRACE_COLS))]
+    while run.status == _lib.ZF_RUNNING:
+        rows.append(run.advance(chunk))
+    ctl = run.solver.ctl
+    out = dict(rows=np.concatenate(rows), x=run.solver.get_x(), xp=run.solver.get_x_prev(), nit=int(ctl.nit), status=int(ctl.status),
+               lr=ctl.lr, F=ctl.F_old, trials=int(ctl.total_trials), ra=run.solver.runahead_counts(), launches=run.solver.launch_counts())
+    run.solver.close()
+    return out
+
+
+def _same(a, b):
+    assert (a["nit"], a["status"], a["lr"], a["F"], a["trials"]) == (b["nit"], b["status"], b["lr"], b["F"], b["trials"])
+    assert np.array_equal(a["rows"], b["rows"]) and np.array_equal(a["x"], b["x"]) and np.array_equal(a["xp"], b["xp"])
+
+
+CASES = [
+    (10007, dict(lr=0.45, nesterov=True, tol=0.0, max_iter=200), None),            # clean: long runs of full chains
+    (10007, dict(lr=0.45, nesterov=False, tol=0.0, max_iter=333), None),
+    (4099, dict(lr=0.45, nesterov=True, tol=0.0, max_iter=160), (-0.3, 0.4)),      # a box; two workgroups + a remainder
+    (300001, dict(lr=0.45, nesterov=True, tol=1e-7, max_iter=5000), None),         # terminates inside a chain: the pass behind is void
+    (300001, dict(lr=16.0, nesterov=True, tol=0.0, max_iter=150), None),           # rejections first, then chains
+    (1_000_001, dict(lr=0.45, nesterov=True, nesterov_ratio=(0.5, 1 / 16), tol=0.0, max_iter=170), None),
+    (2_000_003, dict(lr=0.45, nesterov=True, tol=0.0, max_iter=100), None),        # one round of 489 workgroups of two tiles
+    (10_000_000, dict(lr=0.45, nesterov=True, tol=0.0, max_iter=150), None),       # cfg2: 489 workgroups x 10 tiles; crosses the noise floor (chains break)
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_runahead_passes_equal_one_launch_per_pass(case, monkeypatch):
+    n, opts, bounds = CASES[case]
+    prob = _pdiag(n, seed=2 + case, bounds=bounds)
+    x0 = np.zeros(n) if case % 2 == 0 else np.random.default_rng(case).standard_normal(n)
+    monkeypatch.setenv("ZF_RUNAHEAD", "0")
+    ref = _run(prob, x0, opts)
+    assert ref["ra"] == (0, 0)
+    monkeypatch.delenv("ZF_RUNAHEAD")
+    for chunk in (64, 5, 2, 1):
+        got = _run(prob, x0, opts, chunk=chunk)
+        _same(got, ref)
+        passes, ahead = got["ra"]
+        if chunk >= 2:
+            assert passes >= 2 and ahead >= 1, "run-ahead passes were expected (a grid of <= 512 workgroups, full chains)"
+        else:
+            assert ahead == 0   # one step per call: nothing to run ahead of
+    if n <= 2_000_003:
+        one = _run(prob, x0, opts, sub=1)     # and both equal the one-trial-per-pass loop
+        _same(one, ref)
+
+
+def test_runahead_is_not_used_beyond_the_resident_grid():
+    n = 30_000_000     # two rounds of workgroups
+    r = _run(_pdiag(n, seed=9), np.zeros(n), dict(lr=0.45, nesterov=True, tol=0.0, max_iter=48))
+    assert r["ra"] == (0, 0) and r["nit"] == 48
+
+
+def test_a_wait_that_gives_up_voids_the_pass_and_the_solve_recovers(monkeypatch):
+    """ZF_RUNAHEAD_SPIN_LIMIT=0: every workgroup that finds its predecessor unfinished gives up at once - the pass
+    contributes rows of zeros and must be void; the solve continues from the control block the next poll reads."""
+    n = 1_000_001
+    prob = _pdiag(n, seed=31)
+    opts = dict(lr=0.45, nesterov=True, tol=0.0, max_iter=160)
+    monkeypatch.setenv("ZF_RUNAHEAD", "0")
+    ref = _run(prob, np.zeros(n), opts)
+    monkeypatch.delenv("ZF_RUNAHEAD")
+    monkeypatch.setenv("ZF_RUNAHEAD_SPIN_LIMIT", "0")
+    got = _run(prob, np.zeros(n), opts, chunk=8)
+    _same(got, ref)
+
+
+def test_snapshot_and_resume_across_runahead_passes():
+    from zfista_amd import _lib
+    from zfista_amd.proximal_gradient import NativeRun
+
+    n = 500_003
+    prob = _pdiag(n, seed=41)
+    o = dict(BASE, lr=0.45, nesterov=True, tol=0.0, max_iter=192, sub_iters=16)
+    run = NativeRun(prob, np.zeros(n), o)
+    while run.status == _lib.ZF_RUNNING:
+        run.advance(64)
+    want_x, want_F = run.solver.get_x(), run.solver.ctl.F_old
+    run.solver.close()
+    run = NativeRun(prob, np.zeros(n), o)
+    run.advance(5)
+    snap = run.snapshot()
+    run.solver.close()
+    run = NativeRun.from_snapshot(prob, snap, o)
+    while run.status == _lib.ZF_RUNNING:
+        run.advance(3)
+    assert run.solver.runahead_counts()[1] >= 1
+    assert np.array_equal(run.solver.get_x(), want_x) and run.solver.ctl.F_old == want_F
+    run.solver.close()

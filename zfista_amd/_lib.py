@@ -259,7 +259,8 @@ def require_gpu():
 # ``config.overrides``): numerics never change silently with the environment.
 ENV_SWITCHES = ("ZF_FIN_KERNEL", "ZF_SPECULATE", "ZF_NT", "ZF_LS_SMALL", "ZF_GEMV_MFMA", "ZF_TILES_PER_WG", "ZF_SUB_ITERS",
                 "ZF_COMM", "ZF_MO_COMM", "ZF_MO_LAUNCH_AHEAD", "ZF_MO_SPIN_LIMIT", "ZF_RCCL_LIB", "ZF_DUAL_SOLVER",
-                "ZF_FORCE_SPLIT", "ZF_LIB_PATH", "ZF_PERSIST", "ZF_PERSIST_SPIN_LIMIT", "ZF_MID_CHAINS", "ZF_BENCH_BACKEND")
+                "ZF_FORCE_SPLIT", "ZF_LIB_PATH", "ZF_PERSIST", "ZF_PERSIST_SPIN_LIMIT", "ZF_MID_CHAINS", "ZF_BENCH_BACKEND",
+                "ZF_RUNAHEAD", "ZF_RUNAHEAD_SPIN_LIMIT", "ZF_SHORT_VIA_GENERAL")
 
 
 def env_overrides() -> dict:

@@ -64,8 +64,18 @@ ZF_HD inline void zf_reduce_packs(const double* packs, int world, int stride, do
 // x_{k+n-1} -> *first, x_{k+n} -> *second (ring_size 4).
 ZF_HD inline void zf_free_bufs(int cur, int prev, int ring, int* first, int* second) {
     int f[2] = {-1, -1}, m = 0;
-    for (int i = 0; i < ring && m < 2; ++i)
-        if (i != cur && i != prev) f[m++] = i;
+    if (ring >= 5) {
+        // run-ahead passes (6 buffers): the buffers BEHIND x_k in ring order, so that the pass after a pass never
+        // writes what that pass reads - it may start before that pass has been decided, and a chain that breaks
+        // is replayed from its inputs (cur = 0, prev = 5: -> 1, 2;  then cur = 2, prev = 1: -> 3, 4;  then -> 5, 0)
+        for (int k = 1; k < ring && m < 2; ++k) {
+            const int i = (cur + k) % ring;
+            if (i != prev) f[m++] = i;
+        }
+    } else {
+        for (int i = 0; i < ring && m < 2; ++i)
+            if (i != cur && i != prev) f[m++] = i;
+    }
     *first = f[0];
     *second = (m > 1) ? f[1] : f[0];
 }

@@ -123,9 +123,6 @@ constexpr int ZF_TILE_U = 4;
 #ifndef ZF_X_NT
 #define ZF_X_NT 1   // nontemporal loads of x_k, x_{k-1} in chained passes: read once per pass (tools/tune_trial.hip: -1 %)
 #endif
-#ifndef ZF_X_COH
-#define ZF_X_COH 0   // (experiment) agent-coherent x loads / stores in the full chain
-#endif
 #ifndef ZF_S8_UB
 #define ZF_S8_UB 2   // units per load batch of the 8-trial chain: half a tile, software-pipelined (4 = whole tile, no pipeline)
 #endif
@@ -256,7 +253,15 @@ ZF_HD inline bool zf_pass_claims(int PART, int L, int S, int lag, int nf) {
 #ifndef ZF_S16_UB
 #define ZF_S16_UB 1   // units per load batch of the 16-trial chain (192 VGPRs of running sums leave room for one)
 #endif
-constexpr int ZF_MAX_RING = 4;
+constexpr int ZF_MAX_RING = 6;   // 3: one trial per pass; 4: chains; 6: chains whose passes run ahead of each other's decision
+
+// what a pass reads of the control block before its first vector load
+struct zf_pass_head {
+    int cur, prev, ring;
+    double lr, beta_next;
+    int64_t nit;
+};
+
 
 struct zf_step_args {
     const zf_control* ctl;
@@ -292,6 +297,16 @@ struct zf_step_args {
     int fb_on, fb_part, fb_len;
     // the persistent kernel: pass descriptors, one 128-byte line per group of the finalisation (zf_pass_desc)
     unsigned long long* pdesc;
+    // run-ahead passes (zf_runahead_kernel): a pass launched on the OTHER of two streams while its predecessor
+    // is still finalising - workgroup j waits for workgroup j of the predecessor only (ra_flags), runs on the control
+    // block the host EXPECTS (ra_head), and its deciding wave accepts the pass only if every pass since the last
+    // one that was verified against the real block turned out as expected (ra_word)
+    unsigned long long* ra_word;   // done_seq << 32 | good_seq: the last pass decided (or voided) / the last that matched its prediction
+    unsigned* ra_flags;            // [grid] pass_seq of the last pass whose workgroup j has stored its iterates; [grid + (pass_seq & 3)]: poison (a wait of that pass timed out)
+    int ra_wait;                   // pass_seq of the predecessor in flight on the other stream (0: nothing in flight - the block is read)
+    int ra_need;                   // entry: good_seq must have reached this pass_seq (the pass whose inputs this one overwrites); 0: no condition
+    unsigned ra_spin;              // polls before a wait gives up (the pass is then void)
+    zf_pass_head ra_head;          // the head of this pass by the host's account (beta_next: unused - taken from the momentum ring)
 };
 
 // pass_log entry (low 16 bits; the high 16 are the launch tag): fresh trials | lagging iterations << 5 | passes << 10
@@ -457,8 +472,15 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 // before the one that writes it gets there.
 // FETCH_CTL (the persistent kernel): the deciding wave first fetches the control block past the caches from A.ctl
 // (global) into A.ctl_rw (its workgroup's LDS copy) and decides on that copy.
-template <int SP, bool OPAQUE_TID = false, bool FETCH_CTL = false>
+// RA (run-ahead passes, zf_runahead_kernel; implies FETCH_CTL): behind its row every workgroup also publishes
+// that its iterates are stored (ra_flags - what workgroup j of the NEXT pass waits for); the deciding wave waits until
+// the pass before this one has been decided, accepts this pass only if that one - and every pass since the last that
+// was checked against the real block - went as the host expected, decides on a copy of the block fetched past the
+// caches, writes it back through them and publishes done_seq / good_seq (ra_word) last.  A pass that is not accepted
+// is VOID: the block stays as it is, its iterates lie in buffers nobody reads.
+template <int SP, bool OPAQUE_TID = false, bool FETCH_CTL = false, bool RA = false>
 __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double v) {
+    static_assert(!RA || FETCH_CTL, "a run-ahead pass decides on a fetched copy of the control block");
     constexpr int NQ = SP * ZF_NPART;
     __shared__ int s_role;
     __shared__ double s_tot[NQ];
@@ -476,6 +498,8 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // (NQ up to 96: the publishers sit in two waves)
     if (t == 0) {
+        // (every wave has waited for its own stores above - the iterates of its units among them - and passed the barrier)
+        if constexpr (RA) __hip_atomic_store(A.ra_flags + b, (unsigned)A.pass_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int g = grouped ? b / gsz : 0;
         unsigned* cnt = grouped ? A.fin_cnt + (1 + g) * ZF_FIN_CNT_STRIDE : A.fin_cnt;
         int members = G;
@@ -568,6 +592,47 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
             s_pack[trial * ZF_PACK_LEN + k] = pk[k];
         }
     }
+    if constexpr (RA) {
+        constexpr int CW = (int)(sizeof(zf_control) / 8);
+        static_assert(sizeof(zf_control) % 8 == 0 && CW <= 64, "one lane per word of the control block");
+        unsigned long long* gw = reinterpret_cast<unsigned long long*>(const_cast<zf_control*>(A.ctl));
+        unsigned long long* lw = reinterpret_cast<unsigned long long*>(A.ctl_rw);
+        // the pass before this one (on the other stream) must have been decided; wave-uniform
+        unsigned long long W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        if (A.ra_wait != 0) {
+            for (unsigned k = 0; (int)(W >> 32) < A.ra_wait && k < A.ra_spin; ++k) {
+                __builtin_amdgcn_s_sleep(2);
+                W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ok = ((int)(W >> 32) >= A.ra_wait && (int)(unsigned)W >= A.ra_wait) ? 1 : 0;
+        }
+        // a workgroup of this pass gave up waiting for its predecessor (it contributed a row of zeros)
+        if (__hip_atomic_load(A.ra_flags + G + (A.pass_seq & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.pass_seq) ok = 0;
+        zf_control* c = A.ctl_rw;
+        if (ok) {
+            if (t < CW) lw[t] = __hip_atomic_load(gw + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_wave_barrier();
+            // belt and braces: the block IS what the host expected (by induction it is, if ok)
+            ok = (c->status == ZF_RUNNING && c->pend_status == 0 && c->lag == 0 && c->nit == A.ra_head.nit &&
+                  c->lr == A.ra_head.lr && c->cur == A.ra_head.cur && c->prev == A.ra_head.prev && zf_fresh_len(c) == SP) ? 1 : 0;
+        }
+        ok = __builtin_amdgcn_readfirstlane(ok);
+        unsigned good = (unsigned)W;
+        if (ok) {
+            zf_decide_pass_wave(c, s_pack, pk, A.trace, A.beta_ring, t, LSTR, s_pre);
+            if (t == 0) c->pass_seq = A.pass_seq;
+            __builtin_amdgcn_wave_barrier();
+            if (t < CW) __hip_atomic_store(gw + t, lw[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // as expected: every trial accepted, nothing terminated - the next pass's head is the one the host predicted
+            if (c->status == ZF_RUNNING && c->pend_status == 0 && c->lag == 0 && c->nit == A.ra_head.nit + SP && c->lr == A.ra_head.lr)
+                good = (unsigned)A.pass_seq;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0)
+            __hip_atomic_store(A.ra_word, ((unsigned long long)(unsigned)A.pass_seq << 32) | good, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (A.decide) {
         if constexpr (FETCH_CTL) {
             constexpr int CW = (int)(sizeof(zf_control) / 8);
@@ -602,11 +667,6 @@ __device__ __forceinline__ double zf_readlane_f64(double v, int i) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), i);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-struct zf_pass_head {
-    int cur, prev, ring;
-    double lr, beta_next;
-    int64_t nit;
-};
 __device__ __forceinline__ zf_pass_head zf_head_of(const zf_control* c) {
     zf_pass_head h;
     h.cur = c->cur;
@@ -642,10 +702,15 @@ __device__ __forceinline__ zf_pass_head zf_head_of(const zf_control* c) {
 // SP: packs per pass of the solver (rows of partials written, S <= SP: a 16-chain solver runs its short
 // passes through the 8-trial bodies and leaves the packs of trials 8 .. 15 zero)
 // Returns the workgroup's row: thread t < 6 S holds quantity t % 6 of fresh trial t / 6 (0 for the other threads).
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST, int SP = S, bool OPAQUE_TID = false>
+// COH: the iterates are loaded and stored agent-coherently (sc1, zf_st2_coh) - a run-ahead pass reads what a kernel
+// still running on another XCD has just stored (full chains through the DMA pipeline only; +0.7-1 % per pass, measured)
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST, int SP = S, bool OPAQUE_TID = false,
+          bool COH = false>
 __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* lds, const zf_pass_head& HD, const int lag,
                                                 const int nf, zf_d2* stage = nullptr) {
     constexpr bool FULL = (MODE == 0);          // nothing replayed, S fresh trials
+    static_assert(!COH || (FULL && !HIST && GRAD_INLINE && zf_uses_glds<S, MODE, HIST, GRAD_INLINE, SP>()),
+                  "coherent iterate traffic: the full chain through the DMA pipeline");
     const unsigned tidx = zf_tid<OPAQUE_TID>();   // threadIdx.x (opaque per call inside the persistent kernel's pass loop)
     constexpr bool FRESH_FULL = (MODE <= 1);    // S fresh trials
     const int cur = HD.cur;
@@ -718,7 +783,7 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
                     zf_st2<NT>(reinterpret_cast<zf_d2*>(A.hist + ((nit + j + 1) % A.hist_cap) * A.hist_stride) + i, a);
             }
         }
-        if constexpr (ZF_X_COH != 0 && FULL && !HIST) {
+        if constexpr (COH) {
             zf_st2_coh(reinterpret_cast<zf_d2*>(out_last) + i, a);
             zf_st2_coh(reinterpret_cast<zf_d2*>(out_prev) + i, o);
         } else {
@@ -802,8 +867,8 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
         auto issue = [&](int k) {
             const int64_t i = unit_of(k);
             const unsigned base = lds0 + (unsigned)(k % NST) * (ZF_GLDS_STAGE_UNITS * 16u);
-            zf_glds16<NT && (ZF_X_NT != 0), ZF_X_COH != 0>(xk2 + i, base);
-            if (NESTEROV) zf_glds16<NT && (ZF_X_NT != 0), ZF_X_COH != 0>(xo2 + i, base + ZF_BLOCK * 16u);
+            zf_glds16<NT && (ZF_X_NT != 0), COH>(xk2 + i, base);
+            if (NESTEROV) zf_glds16<NT && (ZF_X_NT != 0), COH>(xo2 + i, base + ZF_BLOCK * 16u);
             zf_glds16<NT>(p02 + i, base + 2 * ZF_BLOCK * 16u);
             zf_glds16<NT>(p12 + i, base + 3 * ZF_BLOCK * 16u);
         };
@@ -965,7 +1030,14 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
     const int64_t rem0 = full_tiles * ZF_TILE_UNITS * 2;
     if (rem0 != n && b32 == full_tiles32 % G32) {
         for (int64_t e = rem0 + tidx; e < n; e += ZF_BLOCK) {
-            double a = xk[e], o = NESTEROV ? xo[e] : a;
+            double a, o;
+            if constexpr (COH) {
+                a = __hip_atomic_load(xk + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                o = NESTEROV ? __hip_atomic_load(xo + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a;
+            } else {
+                a = xk[e];
+                o = NESTEROV ? xo[e] : a;
+            }
             const double q = p0[e], cc = GRAD_INLINE ? p1[e] : q;
             if constexpr (!FULL && GRAD_INLINE) {
                 for (int i = 0; i < lag; ++i) {
@@ -988,8 +1060,13 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
                     if (HIST) A.hist[((nit + j + 1) % A.hist_cap) * A.hist_stride + e] = a;
                 }
             }
-            out_last[e] = a;
-            if (S > 1 && (FRESH_FULL || ntr >= 2)) out_prev[e] = o;
+            if constexpr (COH) {
+                __hip_atomic_store(out_last + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(out_prev + e, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                out_last[e] = a;
+                if (S > 1 && (FRESH_FULL || ntr >= 2)) out_prev[e] = o;
+            }
         }
     }
 
@@ -1151,6 +1228,81 @@ __global__ __launch_bounds__(ZF_BLOCK) ZF_TRIAL_ATTR void zf_trial_kernel(zf_ste
         }
 #endif
     }
+}
+
+// A RUN-AHEAD full chain (zf_runahead_kernel).  Consecutive full-chain passes of a grid the device holds at once are launched
+// alternately on two streams: pass p + 1 starts while pass p still runs - workgroup j as soon as workgroup j of pass p
+// has stored its iterates (the recursion is elementwise: that is its only data dependency) - on the control block the
+// host expects pass p to leave (every trial accepted, which is what happens for whole chunks once a line search has
+// settled).  The finalisation of pass p (~18 us of dependent trips to memory by one workgroup), the kernel boundary and
+// the ramp of pass p + 1 no longer lie between two passes.  Pass p + 1 becomes VOID - decides nothing, its iterates lie
+// in buffers nobody reads (six iterate buffers: a pass never writes what its predecessor reads) - when pass p did not
+// go as expected; passes p and p + 2 share a stream, so pass p + 2 starts after pass p was decided and exits at once
+// (ra_need) if that went wrong.  Results are those of one launch per pass, bit for bit (tests/test_gpu_runahead.py).
+// (Held to two waves per SIMD like the full chain it is: with the entry logic in front of the chain the allocator
+//  otherwise takes 258 registers; capped it parks one 8-byte value in scratch across the tile loop, stored and loaded once.)
+template <bool NESTEROV, bool BOX, bool NT>
+__global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void zf_runahead_kernel(zf_step_args A) {
+    constexpr int S = ZF_MAX_SUB;
+    static_assert(S == 16, "run-ahead passes are full chains of 16");
+    __shared__ double lds[ZF_WAVES * S * ZF_NPART];
+    __shared__ zf_d2 stage[ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS];
+    __shared__ zf_control s_ctl;   // the deciding workgroup's copy of the control block
+    __shared__ int s_go;           // 1: run; 0: leave (the whole pass does); 2: no body - a row of zeros (the predecessor is void / a wait timed out)
+    zf_pass_head HD = A.ra_head;
+    const int b = (int)blockIdx.x, G = (int)gridDim.x;
+    if (A.ra_wait == 0) {
+        // nothing is in flight: the block is what an earlier launch left - checked as every per-pass kernel checks it
+        const zf_control* c = A.ctl;
+        const bool same = c->status == ZF_RUNNING && c->pend_status == 0 && c->lag == 0 && c->nit == HD.nit && c->lr == HD.lr &&
+                          c->cur == HD.cur && c->prev == HD.prev && zf_fresh_len(c) == S;
+        if (!same) {   // (every workgroup finds the same) - decided: void; a pass launched behind this one must not wait for it
+            if (b == 0 && threadIdx.x == 0) {
+                const unsigned long long W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(A.ra_word, ((unsigned long long)(unsigned)A.pass_seq << 32) | (unsigned)W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    } else {
+        if (threadIdx.x == 0) {
+            int go = 1;
+            unsigned long long W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (A.ra_need != 0 && (int)(unsigned)W < A.ra_need) {
+                go = 0;   // the pass whose inputs this one would overwrite broke its chain (it is decided: same stream)
+            } else {
+                unsigned k = 0;
+                for (;;) {
+                    if ((int)__hip_atomic_load(A.ra_flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.ra_wait) break;
+                    W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(W >> 32) >= A.ra_wait && (int)(unsigned)W < A.ra_wait) {   // the predecessor is void
+                        go = 2;
+                        break;
+                    }
+                    if (++k > A.ra_spin) {   // gave up: this pass is void (its deciding wave reads the poison word)
+                        // (a word per pass in flight - this one, the one behind it: the slot of pass_seq & 3)
+                        __hip_atomic_store(A.ra_flags + G + (A.pass_seq & 3), (unsigned)A.pass_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        go = 2;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            s_go = go;
+        }
+        __syncthreads();
+    }
+    // (wave-uniform, in a scalar register: as a value out of LDS it made the chain's control flow divergent)
+    const int go = A.ra_wait == 0 ? 1 : __builtin_amdgcn_readfirstlane(s_go);
+    if (go == 0) return;
+    const bool run = go == 1;
+    if (A.pass_log && b == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(0, S, 0);
+    HD.beta_next = NESTEROV ? A.beta_ring[HD.nit % ZF_RING] : 0.0;   // (zf_resolve_beta with nothing lagging)
+    double v = 0.0;
+    if (run) v = zf_trial_body<true, NESTEROV, BOX, NT, S, 0, false, S, false, true>(A, lds, HD, 0, S, stage);
+    zf_step_args T = A;   // decided on the deciding workgroup's own copy of the block
+    T.ctl = A.ctl_rw;
+    T.ctl_rw = &s_ctl;
+    zf_pass_tail<S, false, true, true>(T, v);
 }
 
 // ---------------------------------------------------------------------------

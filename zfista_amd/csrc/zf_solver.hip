@@ -216,6 +216,24 @@ struct zf_solver {
     bool careful = false;                 // the last chunk saw rejections: launch every kernel a pass may need
     int64_t steps_since_poll = 0;         // trial steps issued since the shadow was read
     int64_t polled_rejections = 0;
+    // Run-ahead passes (zf_runahead_kernel): consecutive full chains of a grid the device holds at once go alternately
+    // to `stream` and `stream2`; stream k has its own rows / group rows / counters / packs (two passes are in flight)
+    bool ra = false;                      // eligible (separable f, chains of 16, one rank, a one-round grid) and not switched off (ZF_RUNAHEAD=0)
+    int ra_cap = -1;                      // co-resident workgroups of the run-ahead kernel (-1: not asked yet)
+    unsigned ra_spin = 1u << 20;          // polls before a wait gives up (ZF_RUNAHEAD_SPIN_LIMIT)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ra_join = nullptr;         // stream2 -> stream at the end of a run of run-ahead passes
+    bool ra_b_pending = false;            // stream2 holds work `stream` has not been made to wait for
+    int ra_last = 0, ra_last2 = 0;        // pass_seq of the last / last but one run-ahead pass of the current run (0: none)
+    int ra_last_idx = 0;                  // stream of the last one
+    zf_pass_head ra_last_head = {};       // its head (whose buffers the next pass must not write)
+    unsigned long long* ra_word = nullptr;
+    unsigned* ra_flags = nullptr;         // max_grid + 32 words
+    double* blk_part2 = nullptr;
+    double* grp_part2 = nullptr;
+    unsigned* fin_cnt2 = nullptr;
+    double* pack2 = nullptr;
+    int64_t ra_passes = 0, ra_ahead = 0;  // run-ahead kernels launched / of them behind a pass still in flight (zf_solver_launch_counts)
     // streaming return_all: caller-owned ring of iterates in HBM (zf_solver_set_history)
     double* hist = nullptr;
     int64_t hist_cap = 0, hist_stride = 0;
@@ -225,8 +243,14 @@ constexpr size_t ZF_CTL_SLOT = (sizeof(zf_control) + 255) / 256 * 256;   // byte
 constexpr size_t ZF_TRACE_BYTES = sizeof(double) * ZF_RING * ZF_TRACE_COLS;
 constexpr size_t ZF_MAIL_BYTES = ZF_CTL_SLOT + ZF_TRACE_BYTES + sizeof(int) * ZF_PASS_LOG;
 
+static int zf_tiles_for(int64_t ntiles);
+static bool zf_fin_kernel_mode();
+
 static int zf_solver_free_all(zf_solver* s) {
+    if (s->stream2) (void)hipStreamDestroy(s->stream2);
+    if (s->ra_join) (void)hipEventDestroy(s->ra_join);
     void* ptrs[] = {s->row_part, s->ls_cnt, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->pdesc, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
+                    s->ra_word, s->ra_flags, s->blk_part2, s->grp_part2, s->fin_cnt2, s->pack2,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
                     s->own_svec ? s->s_part : nullptr, s->own_svec ? s->s_all : nullptr};
@@ -356,6 +380,29 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         s->sub = sub >= 16 ? 16 : sub >= 8 ? 8 : sub >= 4 ? 4 : sub >= 2 ? 2 : 1;
     }
     s->ring = s->sub > 1 ? 4 : 3;   // x_k, x_{k-1} + the one or two iterates a pass stores
+    {   // run-ahead passes: chains of 16 on one rank whose grid the device holds at once (the geometry is a function of n)
+        const char* e = getenv("ZF_RUNAHEAD");
+        const bool on = e ? atoi(e) != 0 : true;
+        const char* te = getenv("ZF_TILES_PER_WG");
+        const int t = te ? std::max(1, atoi(te)) : zf_tiles_for(s->ntiles);
+        const int64_t grid = (s->ntiles + t - 1) / t;
+        if (const char* l = getenv("ZF_RUNAHEAD_SPIN_LIMIT")) s->ra_spin = (unsigned)strtoul(l, nullptr, 10);
+        s->ra = on && desc->kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->sub >= 16 && desc->world == 1 && grid <= 512 && !zf_fin_kernel_mode();
+    }
+    if (s->ra) {
+        s->ring = 6;   // a pass never writes what its predecessor reads (zf_free_bufs)
+        ZF_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+        ZF_TRY(hipEventCreateWithFlags(&s->ra_join, hipEventDisableTiming));
+        ZF_TRY(hipMalloc(&s->ra_word, 128));
+        ZF_TRY(hipMemsetAsync(s->ra_word, 0, 128, s->stream));
+        ZF_TRY(hipMalloc(&s->ra_flags, sizeof(unsigned) * (s->max_grid + 32)));
+        ZF_TRY(hipMemsetAsync(s->ra_flags, 0, sizeof(unsigned) * (s->max_grid + 32), s->stream));
+        ZF_TRY(hipMalloc(&s->blk_part2, sizeof(double) * ZF_NPART * s->sub * s->max_grid));
+        ZF_TRY(hipMalloc(&s->grp_part2, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_GROUPS));
+        ZF_TRY(hipMalloc(&s->fin_cnt2, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2)));
+        ZF_TRY(hipMemsetAsync(s->fin_cnt2, 0, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2), s->stream));
+        ZF_TRY(hipMalloc(&s->pack2, sizeof(double) * ZF_PACK_LEN * s->sub));
+    }
     ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * s->ring * n_pad));
     for (int k = 0; k < s->ring; ++k) s->xb[k] = s->xbuf + k * n_pad;
     ZF_TRY(hipMalloc(&s->partials, sizeof(double) * ZF_NPART * ZF_MAX_GRID));
@@ -579,13 +626,17 @@ constexpr int ZF_SMALL_GRID = 64;
 // move the shadow control block past a pass on the assumption that every fresh trial is accepted and nothing
 // terminates but max_iter - true for whole chunks in the regime a line search settles in
 static void zf_shadow_advance(zf_control& c) {
+    const int ring = c.ring_size > 0 ? c.ring_size : 3;
     if (c.pend_status != 0) {
+        if (c.lag > 0) zf_commit_chain(&c, c.cur, c.prev, ring, c.lag);
         c.lag = 0;
         if (c.pend_status > 0) c.status = c.pend_status;
         c.pend_status = 0;
         return;
     }
-    c.nit += zf_fresh_len(&c);
+    const int nf = zf_fresh_len(&c);
+    c.nit += nf;
+    if (c.lag + nf > 0) zf_commit_chain(&c, c.cur, c.prev, ring, c.lag + nf);   // (the buffers too: a run-ahead pass is told where to read)
     c.lag = 0;
     if (c.nit >= c.max_iter) c.status = ZF_MAXITER;
 }
@@ -684,6 +735,69 @@ static int zf_persist_run(zf_solver* s, int64_t max_steps) {
     return run;
 }
 
+// `stream` waits for what stream2 holds; the next run-ahead pass starts a new run (it reads the real control block)
+static int zf_ra_join(zf_solver* s) {
+    if (s->ra_b_pending) {
+        ZF_HIP(hipEventRecord(s->ra_join, s->stream2));
+        ZF_HIP(hipStreamWaitEvent(s->stream, s->ra_join, 0));
+        s->ra_b_pending = false;
+    }
+    s->ra_last = s->ra_last2 = 0;
+    return ZF_OK;
+}
+
+// A full chain the shadow predicts exactly, as a run-ahead pass (zf_runahead_kernel): behind another one of the same
+// run it goes to the other stream and starts while that one is still finalising.  `before`: the shadow control block
+// in front of this pass.
+static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& before, hipEvent_t e0, hipEvent_t e1) {
+    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+    zf_pass_head h;
+    h.cur = before.cur;
+    h.prev = before.prev;
+    h.ring = before.ring_size;
+    h.lr = before.lr;
+    h.beta_next = 0.0;
+    h.nit = before.nit;
+    bool chain = s->ra_last != 0 && a.pass_seq > s->ra_last;
+    if (chain) {   // what this pass writes, the pass in flight must not be reading (six buffers in ring order: it never is)
+        int f0, f1;
+        zf_free_bufs(h.cur, h.prev, h.ring, &f0, &f1);
+        const zf_pass_head& q = s->ra_last_head;
+        if (f0 == q.cur || f0 == q.prev || f1 == q.cur || f1 == q.prev || h.nit != q.nit + s->sub) chain = false;
+    }
+    int idx = 0;
+    if (!chain) {
+        int rc = zf_ra_join(s);
+        if (rc) return rc;
+    } else {
+        idx = 1 - s->ra_last_idx;
+    }
+    a.ra_word = s->ra_word;
+    a.ra_flags = s->ra_flags;
+    a.ra_wait = chain ? s->ra_last : 0;
+    a.ra_need = chain ? s->ra_last2 : 0;
+    a.ra_spin = s->ra_spin;
+    a.ra_head = h;
+    if (idx == 1) {
+        a.blk_part = s->blk_part2;
+        a.grp_part = s->grp_part2;
+        a.fin_cnt = s->fin_cnt2;
+        a.pack = s->pack2;
+    }
+    hipStream_t st = idx == 1 ? s->stream2 : s->stream;
+    if (e0) ZF_HIP(hipEventRecord(e0, st));
+    zf_launch_s16_runahead(v, s->grid, st, a);
+    if (e1) ZF_HIP(hipEventRecord(e1, st));
+    s->ra_last2 = chain ? s->ra_last : 0;
+    s->ra_last = a.pass_seq;
+    s->ra_last_idx = idx;
+    s->ra_last_head = h;
+    if (idx == 1) s->ra_b_pending = true;
+    s->ra_passes += 1;
+    if (chain) s->ra_ahead += 1;
+    return ZF_OK;
+}
+
 static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false) {
     const zf_problem_desc& d = s->desc;
     zf_step_args a;
@@ -727,7 +841,26 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             s->pass_seq = s->pass_seq >= 0x7ffffff0 ? 1 : s->pass_seq + 1;
             a.pass_seq = s->pass_seq;
         }
+        zf_control before;
+        const bool have_before = s->ra && !dry && decide_in_launch && !s->comm && s->shadow_valid && !fin_kernel && !s->hist;
+        if (have_before) before = s->shadow;
         s->part_mask = (dry || !(decide_in_launch || s->comm)) ? ZF_K_ALL : zf_predict_parts(s);
+        // run-ahead: the ONE kernel the shadow predicts is the full chain (not a pair behind a chunk that saw rejections)
+        bool ra_ok = have_before && s->part_mask == ZF_K_FULL && before.status == ZF_RUNNING && before.lag == 0 &&
+                     before.pend_status == 0 && zf_fresh_len(&before) == s->sub && before.ring_size == s->ring;
+        if (ra_ok) {
+            if (s->ra_cap < 0) {
+                const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+                s->ra_cap = zf_runahead_capacity(v);
+            }
+            ra_ok = s->grid <= s->ra_cap;
+        }
+        if (s->ra && a.pass_seq == 1 && !dry) {   // (the step counter started or wrapped: sequence numbers are compared)
+            int rc = zf_ra_join(s);
+            if (rc) return rc;
+            ZF_HIP(hipMemsetAsync(s->ra_word, 0, 128, s->stream));
+            ZF_HIP(hipMemsetAsync(s->ra_flags, 0, sizeof(unsigned) * (s->max_grid + 32), s->stream));
+        }
         if (!dry) {
             s->steps_since_poll += 1;
             const int shapes = s->part_mask & (s->sub >= 16 ? 31 : s->sub > 1 ? 3 : 1);
@@ -739,9 +872,18 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             if (!s->hist) a.hist = reinterpret_cast<double*>(strtoull(e, nullptr, 0));
         }
 #endif
-        if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
-        zf_launch_trial_kernels(s, a, true);
-        if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+        if (ra_ok) {
+            int rc = zf_launch_runahead(s, a, before, e0, e1);
+            if (rc) return rc;
+        } else {
+            if (s->ra) {
+                int rc = zf_ra_join(s);
+                if (rc) return rc;
+            }
+            if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
+            zf_launch_trial_kernels(s, a, true);
+            if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+        }
         s->part_mask = ZF_K_ALL;
         if (!dry && fin_kernel) zf_launch_finalize(s, d.world == 1 && decide_in_launch);
     } else if (s->ls_small && !dry && decide_in_launch) {
@@ -1267,6 +1409,10 @@ extern "C" int zf_solver_launch_counts(zf_solver* s, int64_t* out, int64_t count
         out[2] = s->persist_launches;
         out[3] = s->persist_passes;
     }
+    if (count >= 6) {   // run-ahead passes launched, and those of them launched behind a pass still in flight
+        out[4] = s->ra_passes;
+        out[5] = s->ra_ahead;
+    }
     return ZF_OK;
 }
 
@@ -1371,6 +1517,7 @@ extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
             // full chains ahead on a grid the device holds at once: several passes in one launch
             const int run = zf_persist_run(s, steps - k);
             if (run >= 2) {
+                if (s->ra && (rc = zf_ra_join(s))) return rc;
                 if ((rc = zf_launch_persist(s, run))) return rc;
                 k += run - 1;
                 continue;
@@ -1386,6 +1533,9 @@ extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
         if ((rc = zf_gather_packs(s, s->sub))) return rc;
         if ((rc = zf_solver_enqueue_decide(s))) return rc;
     }
+    // everything enqueued on the solver's stream after this call (a poll's copy, a snapshot, another solver's work on
+    // the caller's stream) comes behind the passes on the second stream as well
+    if (s->ra) return zf_ra_join(s);
     return ZF_OK;
 }
 

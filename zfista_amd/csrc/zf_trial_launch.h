@@ -21,6 +21,9 @@ bool zf_have_s16_mid(const zf_trial_sel& v, int len);
 void zf_launch_s16_persist(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a, int npass, unsigned spin_limit);
 // workgroups of the persistent kernel the device holds at once (0: could not be determined)
 int zf_persist_capacity(const zf_trial_sel& v);
+// the run-ahead full chain (zf_runahead_kernel) and the workgroups of it the device holds at once
+void zf_launch_s16_runahead(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
+int zf_runahead_capacity(const zf_trial_sel& v);
 // chains of 8 / 4 / 2 (part 0: full chain, part 1: every other shape) and single trials (S = 1, part 0)
 void zf_launch_chain(const zf_trial_sel& v, int S, int part, int grid, hipStream_t st, const zf_step_args& a);
 // history-recording kernels (streaming return_all; nontemporal policy only): separable S = 8 / 1, gradient vector S = 1

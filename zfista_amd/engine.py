@@ -279,6 +279,13 @@ class DeviceSolver:
         _lib.check(self.lib.zf_solver_launch_counts(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
         return int(out[2]), int(out[3])
 
+    def runahead_counts(self):
+        """(run-ahead passes launched, those of them launched while their predecessor was still in flight) since the
+        solver was created (zf_runahead_kernel: consecutive full chains on two streams)."""
+        out = np.zeros(6, dtype=np.int64)
+        _lib.check(self.lib.zf_solver_launch_counts(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
+        return int(out[4]), int(out[5])
+
     def pass_stats_ex(self):
         """pass_stats() plus (fresh trials, replayed iterations) the other passes carried in total."""
         out = np.zeros(6)
