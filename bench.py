@@ -346,6 +346,9 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 m["part_n"] += pn
                 m["part_fresh"] += pf
                 m["part_lag"] += pl
+            ra = run.solver.runahead_counts()
+            m["ra_passes"] = m.get("ra_passes", 0) + ra[0]
+            m["ra_ahead"] = m.get("ra_ahead", 0) + ra[1]
             note_comm(run)
             dt = max_over_ranks(dt)
             m["blocks"].append(dt)
@@ -439,6 +442,9 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 # cost on rank 0's stream (HIP events: my packs ready -> gathered packs here); None on one GPU without one
                 "rccl": comm_seen or None,
                 "overrides": _lib.env_overrides(),
+                # consecutive full chains of a one-round grid (n <= ~2.5e7) on two streams, pass p + 1 running while pass p
+                # is finalised; at the headline size the grid is four rounds deep and none are launched
+                "runahead": {"passes": M.get("ra_passes", 0), "launched_behind_a_pass_in_flight": M.get("ra_ahead", 0)},
                 "parallelism": (f"DRY RUN: x sharded over {world} rank threads on ONE GPU (in-process communicator group of the "
                                 "library); the N > 1 step sequence, not a scaling measurement") if thread_ranks else
                                f"x sharded over {world} GPU(s); per-pass scalar pack all-gather (RCCL inside the library)"
@@ -516,6 +522,9 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                            f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (general body: passes of {trials:.1f} fresh "
                            f"trials + {replays:.1f} replayed iterations on average; no full chain dominates K = {K})"),
                 "kernel_avg_ms": ker_ms,
+                "kernel_avg_ms_note": ("run-ahead passes overlap: the event interval of a pass includes its wait for the pass before "
+                                       "it, so this figure - and the fractions computed from it - UNDERSTATE the kernel; the rate "
+                                       "of the line follows from ms_per_step") if M.get("ra_ahead", 0) > 0 else None,
                 "kernel_launches_timed": full_n if on_full else part_n,
                 "trials_per_pass": trials,
                 "replayed_iterations_per_pass": replays,

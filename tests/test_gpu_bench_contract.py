@@ -55,10 +55,24 @@ def test_bench_json_line():
     assert abs(d["ms_per_step"] * d["steps"] / 1e3 - d["steps"] / d["value"] * (2000000 / 1e8)) < 1e-9
 
 
+def test_bench_line_says_when_passes_ran_ahead():
+    """64 iterations from iteration 16 at n = 2e6: four full chains in a row on a one-round grid - the second to
+    fourth are launched on the other stream while their predecessor is finalised, and the line says so."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "2000000", "--steps", "64", "--warmup", "16",
+                          "--min-seconds", "0.05", "--no-cpu-baseline", "--no-regimes"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+    ra = d["config"]["runahead"]
+    assert ra["passes"] >= 4 * d["config"]["blocks"] and ra["launched_behind_a_pass_in_flight"] >= 3 * d["config"]["blocks"]
+    assert "run-ahead" in d["roofline"]["kernel_avg_ms_note"] and d["config"]["full_chain_passes"] == 4 * d["config"]["blocks"]
+
+
 def test_bench_flags():
     d = _run("--no-cpu-baseline", "--no-kernel-events")
     assert "cpu_baseline" not in d and d["steps"] == 21
     assert d["config"]["rccl"] is None and d["config"]["overrides"] == {}
+    # (21 iterations = two passes of 11 + 10 trials: no two full chains in a row, nothing runs ahead)
+    assert d["config"]["runahead"] == {"passes": 0, "launched_behind_a_pass_in_flight": 0}
     regimes = d["config"]["iterations_per_sec_by_regime"]
     assert {"clean_regime_K20_W5", "clean_regime_K24_W5", "clean_regime_K28_W5", "clean_regime_K30_W5",
             "across_the_noise_floor_K100_W10"} <= set(regimes) and all(v > 0 for v in regimes.values())

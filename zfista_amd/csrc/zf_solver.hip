@@ -387,7 +387,10 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         const int t = te ? std::max(1, atoi(te)) : zf_tiles_for(s->ntiles);
         const int64_t grid = (s->ntiles + t - 1) / t;
         if (const char* l = getenv("ZF_RUNAHEAD_SPIN_LIMIT")) s->ra_spin = (unsigned)strtoul(l, nullptr, 10);
-        s->ra = on && desc->kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->sub >= 16 && desc->world == 1 && grid <= 512 && !zf_fin_kernel_mode();
+        // (not with a box: clipping costs the chain the registers the entry logic needs - held to two waves per SIMD that
+        //  variant reloads a spilled value inside the tile loop)
+        s->ra = on && desc->kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->sub >= 16 && desc->world == 1 && grid <= 512 && !s->box &&
+                !zf_fin_kernel_mode();
     }
     if (s->ra) {
         s->ring = 6;   // a pass never writes what its predecessor reads (zf_free_bufs)

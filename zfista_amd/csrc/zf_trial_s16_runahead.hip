@@ -3,9 +3,11 @@
 #include "zf_trial_launch.h"
 
 void zf_launch_s16_runahead(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a) {
-#define CALL(N, B, T) hipLaunchKernelGGL((zf_runahead_kernel<N, B, T>), dim3(grid), dim3(ZF_BLOCK), 0, st, a)
-    ZF_SEL_NBT(v, CALL);
-#undef CALL
+    // (no box variant: zf_solver_create does not enable run-ahead passes for clipped problems)
+    if (v.nest && v.nt) hipLaunchKernelGGL((zf_runahead_kernel<true, false, true>), dim3(grid), dim3(ZF_BLOCK), 0, st, a);
+    else if (v.nest) hipLaunchKernelGGL((zf_runahead_kernel<true, false, false>), dim3(grid), dim3(ZF_BLOCK), 0, st, a);
+    else if (v.nt) hipLaunchKernelGGL((zf_runahead_kernel<false, false, true>), dim3(grid), dim3(ZF_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((zf_runahead_kernel<false, false, false>), dim3(grid), dim3(ZF_BLOCK), 0, st, a);
 }
 
 // workgroups of the run-ahead kernel the device holds at once (0: could not be determined): two passes in flight never
@@ -15,9 +17,10 @@ int zf_runahead_capacity(const zf_trial_sel& v) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     hipError_t e = hipErrorUnknown;
-#define CALL(N, B, T) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zf_runahead_kernel<N, B, T>, ZF_BLOCK, 0)
-    ZF_SEL_NBT(v, CALL);
-#undef CALL
+    if (v.nest && v.nt) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zf_runahead_kernel<true, false, true>, ZF_BLOCK, 0);
+    else if (v.nest) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zf_runahead_kernel<true, false, false>, ZF_BLOCK, 0);
+    else if (v.nt) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zf_runahead_kernel<false, false, true>, ZF_BLOCK, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zf_runahead_kernel<false, false, false>, ZF_BLOCK, 0);
     if (e != hipSuccess) return 0;
     return per_cu * prop.multiProcessorCount;
 }
