@@ -125,3 +125,17 @@ def test_snapshot_and_resume_across_runahead_passes():
     assert run.solver.runahead_counts()[1] >= 1
     assert np.array_equal(run.solver.get_x(), want_x) and run.solver.ctl.F_old == want_F
     run.solver.close()
+
+
+def test_the_step_counter_wraps_under_run_ahead_passes(monkeypatch):
+    """Sequence numbers are compared (flags, done / good words); the counter wraps at 0x7ffffff0 -> 1: the run of passes
+    is joined there and the words are cleared before the second stream may look at them."""
+    n = 300_001
+    prob = _pdiag(n, seed=51)
+    opts = dict(lr=0.45, nesterov=True, tol=0.0, max_iter=240)
+    ref = _run(prob, np.zeros(n), opts)
+    monkeypatch.setenv("ZF_PASS_SEQ_START", str(0x7ffffff0 - 6))
+    for chunk in (64, 3):
+        got = _run(prob, np.zeros(n), opts, chunk=chunk)
+        _same(got, ref)
+        assert got["ra"][1] >= 4

@@ -260,7 +260,7 @@ def require_gpu():
 ENV_SWITCHES = ("ZF_FIN_KERNEL", "ZF_SPECULATE", "ZF_NT", "ZF_LS_SMALL", "ZF_GEMV_MFMA", "ZF_TILES_PER_WG", "ZF_SUB_ITERS",
                 "ZF_COMM", "ZF_MO_COMM", "ZF_MO_LAUNCH_AHEAD", "ZF_MO_SPIN_LIMIT", "ZF_RCCL_LIB", "ZF_DUAL_SOLVER",
                 "ZF_FORCE_SPLIT", "ZF_LIB_PATH", "ZF_PERSIST", "ZF_PERSIST_SPIN_LIMIT", "ZF_MID_CHAINS", "ZF_BENCH_BACKEND",
-                "ZF_RUNAHEAD", "ZF_RUNAHEAD_SPIN_LIMIT", "ZF_SHORT_VIA_GENERAL")
+                "ZF_RUNAHEAD", "ZF_RUNAHEAD_SPIN_LIMIT", "ZF_SHORT_VIA_GENERAL", "ZF_PASS_SEQ_START")
 
 
 def env_overrides() -> dict:

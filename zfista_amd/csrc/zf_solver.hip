@@ -343,6 +343,7 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     if (const char* e = getenv("ZF_MID_CHAINS")) s->mid_chains = atoi(e) != 0;
     if (const char* e = getenv("ZF_SHORT_VIA_GENERAL")) s->short_general = atoi(e) != 0;
     if (const char* e = getenv("ZF_PERSIST_SPIN_LIMIT")) s->persist_spin = (unsigned)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("ZF_PASS_SEQ_START")) s->pass_seq = atoi(e);   // (tests: the step counter wraps at 0x7ffffff0)
     s->stream = reinterpret_cast<hipStream_t>(stream);
     s->box = !(desc->box_lo == -INFINITY && desc->box_hi == INFINITY);
     const int64_t n = desc->n;
@@ -863,6 +864,9 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             if (rc) return rc;
             ZF_HIP(hipMemsetAsync(s->ra_word, 0, 128, s->stream));
             ZF_HIP(hipMemsetAsync(s->ra_flags, 0, sizeof(unsigned) * (s->max_grid + 32), s->stream));
+            // (the second stream must not find the flags of the numbers before the wrap: they satisfy every wait)
+            ZF_HIP(hipEventRecord(s->ra_join, s->stream));
+            ZF_HIP(hipStreamWaitEvent(s->stream2, s->ra_join, 0));
         }
         if (!dry) {
             s->steps_since_poll += 1;
