@@ -84,6 +84,39 @@ def test_decide_termination_order_and_flags():
     assert c.nit == 0 and c.trial == 1
 
 
+def test_six_buffer_ring_never_hands_a_pass_its_predecessors_inputs():
+    """ring_size 6 (run-ahead passes): a pass writes the two buffers BEHIND x_k in ring order, so the pass launched behind
+    it - before it is decided - never overwrites what it reads, whatever mixture of whole chains, single trials and
+    rejections came before; rings of 3 and 4 keep the lowest-numbered free buffers."""
+    ok = [10.2, -2.0, 1.0, 1.0, 8.0, 0.5, 0, 0]       # accepted against F_old = 10 (test above)
+    bad = [10.0, -2.0, 1.0, 1.0, 20.0, 0.5, 0, 0]     # rejected
+    rng = np.random.default_rng(3)
+    for sub in (1, 2, 4):
+        c = _ctl(ring_size=6, sub_iters=sub, cur=0, prev=5, max_iter=10 ** 6, max_backtrack=50)
+        prev_inputs = None
+        for step in range(200):
+            inputs = (c.cur, c.prev)
+            accept_all = rng.random() < 0.7
+            packs = []
+            for j in range(sub):
+                packs += ok if (accept_all or j < sub - 1) else bad
+            lag0, nit0 = c.lag, c.nit
+            c.F_old = 10.0
+            _decide(c, packs)
+            if (c.cur, c.prev) != inputs:   # the pass stored iterates: where?
+                outputs = {c.cur, c.prev} - set(inputs) if sub == 1 else {c.cur, c.prev}
+                assert not (outputs & set(inputs)), (sub, step, inputs, c.cur, c.prev)
+                if prev_inputs is not None:
+                    assert not (outputs & set(prev_inputs)), (sub, step, prev_inputs, inputs, c.cur, c.prev)
+                assert c.cur == (inputs[0] + (1 if c.nit - nit0 + lag0 == 1 else 2)) % 6   # ring order
+                prev_inputs = inputs
+            c.lr = 1.0
+    for ring, want in ((3, (1, 0)), (4, (2, 1))):
+        c = _ctl(ring_size=ring, sub_iters=1 if ring == 3 else 2, cur=0, prev=ring - 1)
+        _decide(c, ok * (1 if ring == 3 else 2))
+        assert (c.cur, c.prev) == want
+
+
 def test_decide_sums_packs_in_rank_order():
     c = _ctl(world=3)
     packs = np.array([[1.0, -1.0, 0.25, 0.5, 2.0, 0.1, 0, 0],
