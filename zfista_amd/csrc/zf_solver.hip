@@ -220,9 +220,10 @@ struct zf_solver {
     // to `stream` and `stream2`; stream k has its own rows / group rows / counters / packs (two passes are in flight)
     bool ra = false;                      // eligible (separable f, chains of 16, one rank, a one-round grid) and not switched off (ZF_RUNAHEAD=0)
     int ra_cap = -1;                      // co-resident workgroups of the run-ahead kernel (-1: not asked yet)
-    unsigned ra_spin = 1u << 20;          // polls before a wait gives up (ZF_RUNAHEAD_SPIN_LIMIT)
+    unsigned ra_spin = 1u << 17;          // polls before a wait gives up (ZF_RUNAHEAD_SPIN_LIMIT): ~0.3 s, a thousand passes' worth
     hipStream_t stream2 = nullptr;
     hipEvent_t ra_join = nullptr;         // stream2 -> stream at the end of a run of run-ahead passes
+    hipEvent_t ra_fork = nullptr;         // stream -> stream2 in front of a run
     bool ra_b_pending = false;            // stream2 holds work `stream` has not been made to wait for
     int ra_last = 0, ra_last2 = 0;        // pass_seq of the last / last but one run-ahead pass of the current run (0: none)
     int ra_last_idx = 0;                  // stream of the last one
@@ -249,6 +250,7 @@ static bool zf_fin_kernel_mode();
 static int zf_solver_free_all(zf_solver* s) {
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->ra_join) (void)hipEventDestroy(s->ra_join);
+    if (s->ra_fork) (void)hipEventDestroy(s->ra_fork);
     void* ptrs[] = {s->row_part, s->ls_cnt, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->pdesc, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
                     s->ra_word, s->ra_flags, s->blk_part2, s->grp_part2, s->fin_cnt2, s->pack2,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
@@ -397,6 +399,7 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         s->ring = 6;   // a pass never writes what its predecessor reads (zf_free_bufs)
         ZF_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
         ZF_TRY(hipEventCreateWithFlags(&s->ra_join, hipEventDisableTiming));
+        ZF_TRY(hipEventCreateWithFlags(&s->ra_fork, hipEventDisableTiming));
         ZF_TRY(hipMalloc(&s->ra_word, 128));
         ZF_TRY(hipMemsetAsync(s->ra_word, 0, 128, s->stream));
         ZF_TRY(hipMalloc(&s->ra_flags, sizeof(unsigned) * (s->max_grid + 32)));
@@ -773,6 +776,12 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
     if (!chain) {
         int rc = zf_ra_join(s);
         if (rc) return rc;
+        // The second stream may go on once the solver's stream has reached this point - NOT earlier: were a per-pass
+        // kernel still running in front of this pass, the pass behind it would fill the CUs with waiting workgroups
+        // before this one is dispatched, and this one would trickle through the slots they leave (measured in thought,
+        // avoided in deed).  Recorded before the launch, so the two passes still start together.
+        ZF_HIP(hipEventRecord(s->ra_fork, s->stream));
+        ZF_HIP(hipStreamWaitEvent(s->stream2, s->ra_fork, 0));
     } else {
         idx = 1 - s->ra_last_idx;
     }
@@ -865,8 +874,8 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             ZF_HIP(hipMemsetAsync(s->ra_word, 0, 128, s->stream));
             ZF_HIP(hipMemsetAsync(s->ra_flags, 0, sizeof(unsigned) * (s->max_grid + 32), s->stream));
             // (the second stream must not find the flags of the numbers before the wrap: they satisfy every wait)
-            ZF_HIP(hipEventRecord(s->ra_join, s->stream));
-            ZF_HIP(hipStreamWaitEvent(s->stream2, s->ra_join, 0));
+            ZF_HIP(hipEventRecord(s->ra_fork, s->stream));
+            ZF_HIP(hipStreamWaitEvent(s->stream2, s->ra_fork, 0));
         }
         if (!dry) {
             s->steps_since_poll += 1;
