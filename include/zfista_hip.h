@@ -91,7 +91,7 @@ typedef struct zf_control {
                              momentum ring by the decide step so that a trial kernel needs
                              ONE dependent scalar load (this block) before its first
                              vector load                                               */
-    int32_t ring_size;    /* x buffers: 3 (one iteration per pass) or 4                */
+    int32_t ring_size;    /* x buffers: 3 (one iteration per pass), 4 (chains), 6 (run-ahead) */
     int32_t sub_iters;    /* S: trials one pass chains in registers (temporal blocking) */
     int32_t prev;         /* which x buffer holds x_{k-1}                             */
     /* Deferred materialisation (temporal blocking, csrc/zf_decide.h).  A pass stores only the last two
