@@ -1273,10 +1273,14 @@ __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
                 unsigned k = 0;
                 for (;;) {
                     if ((int)__hip_atomic_load(A.ra_flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.ra_wait) break;
-                    W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((int)(W >> 32) >= A.ra_wait && (int)(unsigned)W < A.ra_wait) {   // the predecessor is void
-                        go = 2;
-                        break;
+                    // (the word every waiting workgroup would poll - one line, one memory channel, the one the deciding
+                    //  wave of the predecessor writes to - only now and then: it matters when the predecessor is void)
+                    if ((k & 15) == 15) {
+                        W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((int)(W >> 32) >= A.ra_wait && (int)(unsigned)W < A.ra_wait) {   // the predecessor is void
+                            go = 2;
+                            break;
+                        }
                     }
                     if (++k > A.ra_spin) {   // gave up: this pass is void (its deciding wave reads the poison word)
                         // (a word per pass in flight - this one, the one behind it: the slot of pass_seq & 3)
