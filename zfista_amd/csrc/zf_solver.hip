@@ -225,6 +225,7 @@ struct zf_solver {
     hipEvent_t ra_join = nullptr;         // stream2 -> stream at the end of a run of run-ahead passes
     hipEvent_t ra_fork = nullptr;         // stream -> stream2 in front of a run
     bool ra_b_pending = false;            // stream2 holds work `stream` has not been made to wait for
+    bool ra_fork_due = false;             // ra_fork was recorded in front of the current run and stream2 has not waited for it yet
     int ra_last = 0, ra_last2 = 0;        // pass_seq of the last / last but one run-ahead pass of the current run (0: none)
     int ra_last_idx = 0;                  // stream of the last one
     zf_pass_head ra_last_head = {};       // its head (whose buffers the next pass must not write)
@@ -781,9 +782,13 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
         // before this one is dispatched, and this one would trickle through the slots they leave (measured in thought,
         // avoided in deed).  Recorded before the launch, so the two passes still start together.
         ZF_HIP(hipEventRecord(s->ra_fork, s->stream));
-        ZF_HIP(hipStreamWaitEvent(s->stream2, s->ra_fork, 0));
+        s->ra_fork_due = true;   // (waited for when - if - a pass of this run goes to the second stream)
     } else {
         idx = 1 - s->ra_last_idx;
+        if (idx == 1 && s->ra_fork_due) {
+            ZF_HIP(hipStreamWaitEvent(s->stream2, s->ra_fork, 0));
+            s->ra_fork_due = false;
+        }
     }
     a.ra_word = s->ra_word;
     a.ra_flags = s->ra_flags;
