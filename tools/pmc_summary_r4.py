@@ -21,6 +21,8 @@ out, n, label = sys.argv[1], int(float(sys.argv[2])), sys.argv[3]
 def part_of(name):
     """zf_trial_kernel<GI, NEST, BOX, NT, S, HIST, PART, L>: "part<PART>", mid chains "part3_L<L>" (round 4: the
     template list ends with the mid-chain length)."""
+    if "zf_runahead_kernel" in name:   # the run-ahead full chain (its duration includes the wait for the pass before it)
+        return "runahead"
     ints = re.findall(r"(?<![\w])(\d+)(?=[,>])", name)
     if len(ints) < 3:
         return "part?"
@@ -32,7 +34,7 @@ def rows(sub):
     for path in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as fh:
             for row in csv.DictReader(fh):
-                if "zf_trial_kernel" in row.get("Kernel_Name", ""):
+                if "zf_trial_kernel" in row.get("Kernel_Name", "") or "zf_runahead_kernel" in row.get("Kernel_Name", ""):
                     yield row
 
 

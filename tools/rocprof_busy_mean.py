@@ -20,7 +20,7 @@ out = {}
 for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for row in csv.DictReader(open(path, newline="")):
         name = row["Kernel_Name"]
-        if "zf_trial_kernel" not in name:
+        if "zf_trial_kernel" not in name and "zf_runahead_kernel" not in name:
             continue
         dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
         e = out.setdefault(name.split("(")[0], {"launches": 0, "idle_launches": 0, "busy_ns": 0, "idle_ns": 0})
