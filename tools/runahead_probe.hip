@@ -2,7 +2,7 @@
 // finalising?  Each workgroup j of launch s waits for flag[j] >= s-1 (its own predecessor only - the element-wise data
 // dependency of a chained pass), works ~W us, publishes flag[j] = s; the last arriver then spends ~T us alone (the
 // finalisation tail).  Modes: 0 plain launches on one stream; 1 hipExtAnyOrderLaunch on one stream; 2 alternating
-// between two streams.   hipcc -O3 --offload-arch=gfx950 tools/runahead_probe.hip -o runahead_probe && ./runahead_probe
+// between two streams; 3 between three.   hipcc -O3 --offload-arch=gfx950 tools/runahead_probe.hip -o runahead_probe && ./runahead_probe
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <chrono>
@@ -57,16 +57,16 @@ int main(int argc, char** argv) {
     const int L = 40;
     unsigned *flags, *tickets; long long* stamps;
     CK(hipMalloc(&flags, grid * 128)); CK(hipMalloc(&tickets, 8 * 128)); CK(hipMalloc(&stamps, (size_t)(L + 2) * grid * 32));
-    hipStream_t st[2]; CK(hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking));
+    hipStream_t st[3]; for (int k = 0; k < 3; ++k) CK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
     std::vector<long long> h((size_t)(L + 2) * grid * 4);
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipMemset(flags, 0, grid * 128)); CK(hipMemset(tickets, 0, 8 * 128)); CK(hipMemset(stamps, 0, (size_t)(L + 2) * grid * 32));
             CK(hipDeviceSynchronize());
             auto w0 = std::chrono::steady_clock::now();
             for (int s = 1; s <= L; ++s) {
                 if (mode == 1) hipExtLaunchKernelGGL(probe, dim3(grid), dim3(256), 0, st[0], nullptr, nullptr, hipExtAnyOrderLaunch, flags, tickets, stamps, s, work, tail, 2000000u);
-                else hipLaunchKernelGGL(probe, dim3(grid), dim3(256), 0, st[mode == 2 ? (s & 1) : 0], flags, tickets, stamps, s, work, tail, 2000000u);
+                else hipLaunchKernelGGL(probe, dim3(grid), dim3(256), 0, st[mode == 2 ? (s & 1) : mode == 3 ? (s % 3) : 0], flags, tickets, stamps, s, work, tail, 2000000u);
             }
             CK(hipGetLastError());
             CK(hipDeviceSynchronize());
@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
                 first_start[s] = fs / 100; last_end[s] = le / 100; last_body[s] = lb / 100;
             }
             printf("mode %d (%s): wall %.0f us for %d launches = %.1f us each; device: period %.1f us, body %.1f us, waited at start %.1f us mean, tail after last body %.1f us, timeouts %d\n",
-                   mode, mode == 0 ? "one stream" : mode == 1 ? "hipExtAnyOrderLaunch" : "two streams", wall, L, wall / L,
+                   mode, mode == 0 ? "one stream" : mode == 1 ? "hipExtAnyOrderLaunch" : mode == 2 ? "two streams" : "three streams", wall, L, wall / L,
                    (last_end[L] - last_end[L / 2]) / (L - L / 2), body / 100 / (L * grid), waited / 100 / (L * grid), last_end[L] - last_body[L], timeouts);
             printf("   launch s: first start / last body end / end (us):");
             for (int s = L - 3; s <= L; ++s) printf("  %d: %.1f / %.1f / %.1f", s, first_start[s], last_body[s], last_end[s]);
