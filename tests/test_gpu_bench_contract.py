@@ -64,7 +64,11 @@ def test_bench_line_says_when_passes_ran_ahead():
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
     ra = d["config"]["runahead"]
     assert ra["passes"] >= 4 * d["config"]["blocks"] and ra["launched_behind_a_pass_in_flight"] >= 3 * d["config"]["blocks"]
-    assert "run-ahead" in d["roofline"]["kernel_avg_ms_note"] and d["config"]["full_chain_passes"] == 4 * d["config"]["blocks"]
+    r = d["roofline"]
+    assert "run-ahead" in r["kernel_avg_ms_note"] and d["config"]["full_chain_passes"] == 4 * d["config"]["blocks"]
+    # the cost of a pass on such a line is what the block delivers per pass, not an interval around one launch
+    assert abs(r["kernel_avg_ms"] - d["ms_per_step"] * 64 / 4) < 1e-9 and r["kernel_event_interval_ms"] > 0
+    assert r["hbm"]["achieved"] == r["hbm"]["bytes_per_launch"] / (r["kernel_avg_ms"] * 1e-3) / 1e9
 
 
 def test_bench_flags():
