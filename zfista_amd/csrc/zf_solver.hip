@@ -779,8 +779,8 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
         if (rc) return rc;
         // The second stream may go on once the solver's stream has reached this point - NOT earlier: were a per-pass
         // kernel still running in front of this pass, the pass behind it would fill the CUs with waiting workgroups
-        // before this one is dispatched, and this one would trickle through the slots they leave (measured in thought,
-        // avoided in deed).  Recorded before the launch, so the two passes still start together.
+        // before this one is dispatched, and this one would trickle through the slots they leave (not measured: ruled
+        // out by construction).  Recorded before the launch, so the two passes still start together.
         ZF_HIP(hipEventRecord(s->ra_fork, s->stream));
         s->ra_fork_due = true;   // (waited for when - if - a pass of this run goes to the second stream)
     } else {
