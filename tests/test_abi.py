@@ -185,6 +185,20 @@ def test_kernels_use_no_scratch_memory(tmp_path):
             runahead = "zf_runahead_kernel" in name
             persist += 0 if runahead else 1
             ahead += 1 if runahead else 0
+            if runahead:
+                # Its iterate traffic must be agent-coherent (sc1): it reads what a kernel still running on another XCD has
+                # just stored.  Without it the GPU tests could still pass - while workgroup j of two launches happens
+                # to land on the same XCD - so the instruction stream itself is held to it: the iterate streams of the DMA
+                # pipeline load with sc1 (d, c: nt), every 16-byte iterate store is sc1, none is nontemporal.
+                body = re.search(re.escape(name) + r":.*?\.end_amdhsa_kernel", text, re.S).group(0)
+                dma_sc1 = len(re.findall(r"global_load_lds_dwordx4 [^\n]*\bsc1\b", body))
+                dma_nt = len(re.findall(r"global_load_lds_dwordx4 [^\n]*\bnt\b", body))
+                dma_all = len(re.findall(r"global_load_lds_dwordx4 ", body))
+                # (the once-read streams d, c: nontemporal, or plain in the variant without the nontemporal policy; as many DMA
+                #  instructions as the iterate streams with momentum - x_k, x_{k-1} - twice as many without)
+                assert dma_sc1 > 0 and dma_nt in (0, dma_all - dma_sc1) and dma_all - dma_sc1 in (dma_sc1, 2 * dma_sc1), (name, dma_sc1, dma_nt, dma_all)
+                assert len(re.findall(r"global_store_dwordx4 [^\n]*\bsc1\b", body)) >= 2, name
+                assert not re.findall(r"global_store_dwordx4 [^\n]*\bnt\b", body), name
             assert size <= 192, f"{name} uses {size} B of scratch per thread"
             code = re.search(re.escape(name) + r":.*?\.end_amdhsa_kernel", text, re.S).group(0)
             depth = 0
