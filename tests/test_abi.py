@@ -187,9 +187,10 @@ def test_kernels_use_no_scratch_memory(tmp_path):
             ahead += 1 if runahead else 0
             if runahead:
                 # Its iterate traffic must be agent-coherent (sc1): it reads what a kernel still running on another XCD has
-                # just stored.  Without it the GPU tests could still pass - while workgroup j of two launches happens
-                # to land on the same XCD - so the instruction stream itself is held to it: the iterate streams of the DMA
-                # pipeline load with sc1 (d, c: nt), every 16-byte iterate store is sc1, none is nontemporal.
+                # just stored.  The GPU tests catch a dropped modifier (built with nontemporal iterate traffic 10 of the 13
+                # tests of tests/test_gpu_runahead.py fail: profiles/r04_runahead_without_sc1.txt); this catches it where no
+                # GPU is: the iterate streams of the DMA pipeline load with sc1 (d, c: nt), every 16-byte iterate store is
+                # sc1, none is nontemporal.
                 body = re.search(re.escape(name) + r":.*?\.end_amdhsa_kernel", text, re.S).group(0)
                 dma_sc1 = len(re.findall(r"global_load_lds_dwordx4 [^\n]*\bsc1\b", body))
                 dma_nt = len(re.findall(r"global_load_lds_dwordx4 [^\n]*\bnt\b", body))
