@@ -65,8 +65,10 @@ ISA_PROFILE = "r02_isa_mix_trial_kernel_s{S}.json"
 # round 3: one PMC set per FLAG SET of this file, summarised per shape-specific kernel (tools/profile_r3.sh):
 # the line names the kernel that dominates its timed region and reads THAT kernel's counters
 # round 4: re-collected with the round's kernels (tools/profile_r4.sh); mid chains are keyed by their length
-PMC_R3 = {"full": ("r04_pmc_defaults_k100_w10.json", "part0"), "mid": ("r04_pmc_driver_k20_w5.json", "part3_L10"),
-          "general": ("r04_pmc_defaults_k100_w10.json", "part1")}
+# (round 5: "general" names the general body - part2, it read part1's counters, the short bodies'; mid chains are looked
+#  up by their length and report no counters when that length was not profiled)
+PMC_R3 = {"full": ("r04_pmc_defaults_k100_w10.json", "part0"), "mid": ("r04_pmc_driver_k20_w5.json", "part3_L{len}"),
+          "general": ("r04_pmc_defaults_k100_w10.json", "part2")}
 MID_MIN, MID_MAX = 9, 15   # trials of the branch-free mid chains (csrc/zf_kernels_step.h: ZF_MID_MIN .. ZF_MID_MAX), one kernel per length
 
 
@@ -106,13 +108,14 @@ def measured_clock_ghz(n, sub_iters):
     return prof["engine_clock_GHz"]["median"]
 
 
-def kernel_profile(n, sub_iters, kind):
+def kernel_profile(n, sub_iters, kind, mid_len=0):
     """The committed PMC summary of the kernel this line is about - the full chain (PART 0) under the default
     flags, the branch-free 10-trial chain (PART 3) or the general 16-trial body (PART 2) under the driver's - or
     None (another n / chain length)."""
     if sub_iters != 16:
         return None
     name, part = PMC_R3[kind]
+    part = part.format(len=mid_len)
     prof = _profile(name)
     if not prof or prof.get("n") != n or part not in prof.get("kernels", {}):
         return None
@@ -169,6 +172,10 @@ def main():
     ap.add_argument("--libcomm", action="store_true",
                     help="N = 1 only: run the sharded step sequence over a 1-rank RCCL communicator created "
                          "inside the library (zf_comm): what the per-pass exchange costs without a second GPU")
+    ap.add_argument("--acceptance", choices=("reference", "resolved"), default="reference",
+                    help="how the sufficient-decrease test is evaluated (zfista_amd.minimize_proximal_gradient's keyword): "
+                         "'reference' = zfista/proximal_gradient.py:303 as written (the metric's configuration); 'resolved' = the "
+                         "same inequality with f(x+) - f(y) accumulated element by element - no rounding-noise rejections")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket every trial kernel with HIP events (roofline becomes null); "
@@ -301,7 +308,8 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
     d, c = make_inputs(n, seed=1 + rank, device="cuda")
     prob = DiagQuadL1(d, c, LAM, group=group)
     opts = dict(lr=LR, tol=0.0, tol_internal=1e-12, max_iter=max(W, 1), max_backtrack_iter=100, decay_rate=0.5,
-                nesterov=True, nesterov_ratio=(0, 0.25), deprecated=False, sub_iters=args.sub_iters)
+                nesterov=True, nesterov_ratio=(0, 0.25), deprecated=False, sub_iters=args.sub_iters,
+                acceptance=args.acceptance)
     x0 = torch.zeros(n, dtype=torch.float64, device="cuda")
     timing = not args.no_kernel_events
 
@@ -346,9 +354,12 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 m["part_n"] += pn
                 m["part_fresh"] += pf
                 m["part_lag"] += pl
-            ra = run.solver.runahead_counts()
-            m["ra_passes"] = m.get("ra_passes", 0) + ra[0]
-            m["ra_ahead"] = m.get("ra_ahead", 0) + ra[1]
+            rep_ = run.solver.ahead_report()
+            m["ra_passes"] = m.get("ra_passes", 0) + rep_["runahead"]
+            m["ra_ahead"] = m.get("ra_ahead", 0) + rep_["runahead_overlapped"]
+            for key in ("timeouts", "void", "ahead", "ahead_void"):
+                m["rep_" + key] = m.get("rep_" + key, 0) + rep_[key]
+            m["ra_off"] = m.get("ra_off", False) or rep_["runahead_off"]
             note_comm(run)
             dt = max_over_ranks(dt)
             m["blocks"].append(dt)
@@ -444,7 +455,15 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 "overrides": _lib.env_overrides(),
                 # consecutive full chains of a one-round grid (n <= ~2.5e7) on two streams, pass p + 1 running while pass p
                 # is finalised; at the headline size the grid is four rounds deep and none are launched
-                "runahead": {"passes": M.get("ra_passes", 0), "launched_behind_a_pass_in_flight": M.get("ra_ahead", 0)},
+                "runahead": {"passes": M.get("ra_passes", 0), "launched_behind_a_pass_in_flight": M.get("ra_ahead", 0),
+                             # what the device reported (zf_solver_launch_counts [6..10]): waits that gave up - the device
+                             # did not hold two passes at once - and passes that turned out void
+                             "waits_that_gave_up": M.get("rep_timeouts", 0), "void_passes": M.get("rep_void", 0),
+                             "switched_off": M.get("ra_off", False)},
+                # passes AHEAD of their predecessor's decision at kernel granularity (sharded solves through the library's
+                # communicator): trial kernels back to back, finalisation / all-gather / decide on a second stream
+                "passes_ahead": {"launched": M.get("rep_ahead", 0), "void": M.get("rep_ahead_void", 0)},
+                "acceptance": args.acceptance,
                 "parallelism": (f"DRY RUN: x sharded over {world} rank threads on ONE GPU (in-process communicator group of the "
                                 "library); the N > 1 step sequence, not a scaling measurement") if thread_ranks else
                                f"x sharded over {world} GPU(s); per-pass scalar pack all-gather (RCCL inside the library)"
@@ -471,7 +490,7 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
             pass_bytes = (PASS_BYTES_PER_ELEM if S > 1 else ALG_BYTES_PER_ELEM) * n
             mid = (not on_full) and S == 16 and abs(trials - round(trials)) < 1e-9 and MID_MIN <= round(trials) <= MID_MAX and replays == 0
             mid_len = int(round(trials)) if mid else 0
-            kp = kernel_profile(n, S, "full" if on_full else ("mid" if mid and mid_len == 10 else "general"))   # THIS kernel's counters
+            kp = kernel_profile(n, S, "full" if on_full else ("mid" if mid else "general"), mid_len)   # THIS kernel's counters (None: not profiled)
             traffic = kp.get("hbm_bytes_per_launch") if kp else measured_traffic(n, S)
             traffic_file = kp["file"] + " [" + kp["part"] + "]" if kp else "profiles/" + PMC_PROFILE.format(S=S)
             achieved = pass_bytes / (ker_ms * 1e-3) / 1e9
@@ -524,7 +543,9 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
                 "traffic": traffic,
                 "traffic_source": f"{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch "
                                   "of the kernel named below)" if traffic else None,
-                "kernel": f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (full-chain passes)" if on_full else
+                "kernel": ((f"zf_runahead_kernel<nesterov, nt> (full-chain passes of {S} trials, run-ahead)" if ra_line else
+                            f"zf_trial_kernel<grad inline, nesterov, nt, S={S}{', AHEAD' if M.get('rep_ahead', 0) else ''}> (full-chain passes)")
+                           + (" [ZF_ACCEPT_RESOLVED instantiation]" if args.acceptance == "resolved" else "")) if on_full else
                           (f"zf_trial_kernel<grad inline, nesterov, nt, S={S}, PART 3, L={mid_len}> (branch-free chain of {mid_len} trials: "
                            f"the K = {K} timed iterations are shared by passes of {mid_len}; no full chain runs)" if mid else
                            f"zf_trial_kernel<grad inline, nesterov, nt, S={S}> (general body: passes of {trials:.1f} fresh "

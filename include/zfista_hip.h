@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZF_ABI_VERSION 5
+#define ZF_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------ */
 #define ZF_OK 0
@@ -87,6 +87,8 @@ typedef struct zf_control {
     int32_t deprecated;   /* deprecated acceptance test (:300-302)                    */
     int32_t need_grad;    /* least squares: gradient at y_k must be (re)computed      */
     int32_t world;        /* ranks whose packs are summed by the decide step          */
+    int32_t accept_mode;  /* (ABI 6) ZF_ACCEPT_*: how the sufficient-decrease test (:303) is evaluated */
+    int32_t reserved0;
     double beta_next;     /* momentum factor of the next trial (:533), resolved from the
                              momentum ring by the decide step so that a trial kernel needs
                              ONE dependent scalar load (this block) before its first
@@ -108,6 +110,18 @@ typedef struct zf_control {
     int32_t pass_seq;     /* number of the step whose pass was decided inside its trial launch (0: none yet) */
     double lag_lr[ZF_MAX_LAG];
 } zf_control;
+
+/* zf_options.accept_mode / zf_control.accept_mode (ABI 6).  The reference accepts a trial when
+ *     F(x+) - F(x_k) <= fun + tol_internal,  fun = <grad f(y), x+ - y> + g(x+) + |x+ - y|^2 / 2 / lr + (f(y) - F(x_k))   (:149-155, :303)
+ * - two differences of O(|F|) numbers.  In exact arithmetic F(x_k) and g(x+) cancel and the test reads
+ *     [f(x+) - f(y)] - <grad f(y), x+ - y> - |x+ - y|^2 / 2 / lr <= tol_internal.
+ * ZF_ACCEPT_REFERENCE evaluates the reference's expression as it stands (default: same decisions as the reference, and
+ * below double-precision resolution once |x+ - y|^2 << ulp(F): at n = 1e8 trials are rejected by rounding noise from
+ * iteration ~90 on).  ZF_ACCEPT_RESOLVED (opt-in; separable problems) evaluates the second form with f(x+) - f(y)
+ * accumulated element by element (pack slot 7), so the test resolves ~1e-16 of the step, not of F; f(x+) is then reported
+ * as f(y) + [f(x+) - f(y)].  Iterates of accepted trials are the same arithmetic either way. */
+#define ZF_ACCEPT_REFERENCE 0
+#define ZF_ACCEPT_RESOLVED 1
 
 typedef struct zf_problem_desc {
     int32_t kind;      /* ZF_PROBLEM_*                                                */
@@ -149,7 +163,7 @@ typedef struct zf_options {  /* keyword arguments of proximal_gradient.py:317-33
                             problems (temporal blocking): 0 = library default (ZF_SUB_ITERS in the
                             environment, else ZF_DEFAULT_SUB_ITERS), 1 / 2 / 4 / 8 / 16 explicit.  Results do not depend on it;
                             lam >= 0, lr > 0, decay_rate > 0 are required by the fused kernels.     */
-    int32_t reserved;
+    int32_t accept_mode; /* (ABI 6; was reserved = 0) ZF_ACCEPT_REFERENCE or ZF_ACCEPT_RESOLVED (ZF_PROBLEM_DIAG_QUAD_L1 only) */
 } zf_options;
 
 typedef struct zf_solver zf_solver; /* opaque; owns x ring, partials, control, rings */
@@ -299,8 +313,6 @@ int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_bytes, double
 /* device address / host copy of the latest accepted iterate x_k (local shard) */
 int zf_solver_x_dev(zf_solver* s, const double** x_dev);
 int zf_solver_get_x(zf_solver* s, double* x_host, int64_t count /* capacity in doubles, >= n */);
-/* average duration (ms) of the trial kernel over the launches since the last
- * call, measured with HIP events on the solver's stream; resets the window */
 /* checkpoint / resume: zf_solver_poll + zf_solver_get_x + zf_solver_get_x_prev are the state of a
  * solve (x_k, x_{k-1}, control block); zf_solver_restore puts it into a freshly created solver
  * instead of zf_solver_enqueue_init(+_commit), after which the host re-uploads the momentum
@@ -308,18 +320,28 @@ int zf_solver_get_x(zf_solver* s, double* x_host, int64_t count /* capacity in d
 int zf_solver_get_x_prev(zf_solver* s, double* x_host, int64_t count /* >= n */);
 int zf_solver_restore(zf_solver* s, const double* xk_dev, const double* xprev_dev, const zf_control* saved,
                       int64_t saved_bytes /* == zf_sizeof_control(): a block of another layout is refused */);
+/* average duration (ms) of the trial kernel over the launches since the last
+ * call, measured with HIP events on the solver's stream; resets the window */
 int zf_solver_trial_kernel_ms(zf_solver* s, double* avg_ms, int64_t* launches);
-/* since creation: out[0] = trial steps issued, out[1] = trial kernels launched for them; with count >= 4 (ABI 5) also
- * out[2] = launches of the persistent multi-pass kernel, out[3] = steps those launches covered.  A chained pass has
+/* since creation: out[0] = trial steps issued, out[1] = trial kernels launched for them; with count >= 4 also
+ * out[2] = out[3] = 0 (ABI 5: the counts of a multi-pass kernel that round 5 withdrew).  A chained pass has
  * one of several shapes (full chain, short, general, a mid chain of 9 .. 15 trials) and needs one kernel; the host
  * launches the one it expects once a poll has shown it the control block - unsharded, and sharded through the
  * library's communicator; behind a chunk that saw rejections the general body rides along as the complement of the
  * expected kernel (on small grids: alone); with nothing known, the three kernels that between them run every shape.
- * With ZF_PERSIST=1, on grids the device holds at once, consecutive full chains share ONE launch (zf_persist_kernel).
  * With count >= 6 also out[4] = run-ahead passes launched, out[5] = those of them launched while their predecessor
- * was still in flight: on such grids consecutive full chains go alternately to the solver's stream and a second one
- * of its own, pass p + 1 running while pass p is finalised (zf_runahead_kernel; ZF_RUNAHEAD=0: off; six iterate
- * buffers instead of four).  zf_solver_enqueue_steps returns with the solver's stream made to wait for the second. */
+ * was still in flight: on grids the device holds at once consecutive full chains go alternately to the solver's stream and a
+ * second one of its own, pass p + 1 running while pass p is finalised (zf_runahead_kernel; ZF_RUNAHEAD=0: off; six iterate
+ * buffers instead of four).  zf_solver_enqueue_steps returns with the solver's stream made to wait for the second.
+ * (ABI 6) With count >= 8, as of the last zf_solver_poll: out[6] = waits of run-ahead passes that GAVE UP (a workgroup's
+ * for its predecessor workgroup, a deciding wave's for the decision before it: ZF_RUNAHEAD_SPIN_LIMIT polls, ~15 ms -
+ * the device did not hold two passes of this solver at once, i.e. it is shared), out[7] = run-ahead passes that turned
+ * out VOID (a prediction failed, or a wait gave up).  After the first wait that gave up the solver launches no further
+ * run-ahead passes (count >= 11: out[10] = 1) and runs one launch per pass - same results, no 15 ms stalls.
+ * With count >= 10: out[8] = passes launched AHEAD at kernel granularity, out[9] = those of them void: sharded solves through
+ * the library's communicator (and, ZF_AHEAD_UNSHARDED=1, unsharded grids the run-ahead kernel does not take) run the trial
+ * kernels of consecutive exactly predicted full / mid chains back to back on the solver's stream, each on the head the host
+ * expects, while finalisation, all-gather and decide of the pass before run on the second stream (ZF_AHEAD=0: off). */
 int zf_solver_launch_counts(zf_solver* s, int64_t* out, int64_t count /* >= 2 */);
 /* the same window split by the shape of the pass, which the kernel logs itself: out[0], out[1] = mean
  * ms and count of full chains (sub_iters fresh trials, nothing replayed); out[2], out[3] = every other
@@ -331,7 +353,8 @@ int zf_solver_pass_stats_ex(zf_solver* s, double* out, int64_t count /* >= 6 */)
  * call, each timed on this rank's stream from "my packs are ready" to "the gathered packs are here" */
 int zf_solver_exchange_stats(zf_solver* s, double* out, int64_t count /* >= 2 */);
 /* timing on (ABI 5): one (shape, milliseconds) pair per launch that ran a pass since the last call, oldest first; shape =
- * fresh trials | lagging iterations << 5 | passes of a persistent launch << 10; *count = pairs written (<= cap_pairs) */
+ * fresh trials | lagging iterations << 5; launches whose pass turned out void (it ran ahead on a head that did not come true)
+ * are left out; *count = pairs written (<= cap_pairs) */
 int zf_solver_pass_records(zf_solver* s, double* out, int64_t cap_pairs, int64_t* count);
 int zf_solver_set_timing(zf_solver* s, int32_t enabled);
 
@@ -418,7 +441,7 @@ int zf_mo_prepare(zf_mo* s, double* f_y_out /* m */);           /* J = jac_f(y),
  * formed and kept on the device for zf_mo_solve_dual_device, which hands it back with its result;
  * zf_mo_get_f_y fetches it otherwise (synchronises) */
 int zf_mo_prepare_async(zf_mo* s);
-/* Fused outer iteration (built-in problems, unsharded x, m <= 3), on / off: zf_mo_commit and
+/* Fused outer iteration (JOS1 / FDS, unsharded x), on / off: zf_mo_commit and
  * zf_mo_prepare_async only record what is due and the next zf_mo_solve_dual_device forms y = x_k +
  * beta (x_k - x_{k-1}) (:534), f(y) (:140) and J = jac_f(y) (:142) inside its one kernel: one launch and one
  * read-back per trial.  Every other entry point first brings the buffers up to date, so results do not change. */
@@ -431,7 +454,7 @@ int zf_mo_set_fused(zf_mo* s, int32_t on);
  * nothing: *skipped_out = 1; call zf_mo_uncommit, then retry with a smaller step) and takes F(x_k) from that
  * trial's F(x+) on the device (F_old may then be NULL); gated = 2: it also starts its search from that trial's
  * weights (warm_start, :286-288), likewise taken on the device.  At most one trial may be in flight ahead of the
- * one waited for.  *ticket_out = -1: not a device trial (sharded x, m > 3) - use the host loop. */
+ * one waited for.  *ticket_out = -1: not a device trial (sharded x, m > 8, the grid not co-resident) - use the host loop. */
 int zf_mo_trial_launch(zf_mo* s, double lr, const double* F_old /* m or NULL */, int32_t deprecated,
                        const double* w0 /* m or NULL */, double tol, int64_t max_iter, double accept_tol,
                        int32_t decay_is_one, int32_t gated, int32_t* ticket_out);
@@ -467,7 +490,7 @@ int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const double* F_old
  * evaluations run on register-resident (J, y), their sums are combined by a last-arriver reduction,
  * the solver's state machine advances on the device; f(x+), g(x+) (:295) come out of the same pass
  * (f_x_out[0] = NaN when f is a host callback); one launch and one read-back per trial.
- * *ok_out = 0: not attempted (non-finite start, x sharded over ranks, m > 3, grid not co-resident) - fall back to
+ * *ok_out = 0: not attempted (non-finite start, x sharded over ranks, m > 8, grid not co-resident) - fall back to
  * zf_mo_solve_dual / the reference's calls + zf_mo_recover.  *ok_out = -1: a grid-wide wait gave up (see
  * zf_mo_invalidate_prepare); same fall-back. */
 int zf_mo_solve_dual_device(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,

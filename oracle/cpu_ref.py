@@ -31,6 +31,12 @@ rate after each outer iteration) and ``alltrials`` (line-search trials used by
 each outer iteration).  ``verbose=True`` prints a five-column row; the
 reference's formatter raises IndexError there (five slots, four values,
 proximal_gradient.py:511-520), a documented deviation.
+
+NOT in the reference (an extension of the engine, restated here so that it has a checker too): ``f_diff``.  The
+reference's acceptance test ``F(x+) - F(x_k) <= fun + tol`` (:303) subtracts O(|F|) numbers; with F(x_k) and g(x+)
+cancelled it reads ``[f(x+) - f(y)] - <grad f(y), x+ - y> - |x+ - y|^2 / 2 / lr <= tol``.  When a callable
+``f_diff(x_new, y)`` is given - f(x_new) - f(y) formed without the cancellation - the line search uses that form
+(``acceptance="resolved"`` of zfista_amd.minimize_proximal_gradient); without it everything is the reference's.
 """
 from __future__ import annotations
 
@@ -161,7 +167,7 @@ def trial(f, g, jac_f, prox_wsum_g, lr, x_prev, y, w0, tol, max_iter, deprecated
 
 def line_search(
     f, g, jac_f, prox_wsum_g, lr, x_prev, y, w0, tol, tol_internal,
-    max_iter_internal, max_backtrack_iter, decay_rate, deprecated, warm_start, m,
+    max_iter_internal, max_backtrack_iter, decay_rate, deprecated, warm_start, m, f_diff=None,
 ):
     """Shrink lr until the sufficient-decrease test holds (:279-308).
 
@@ -183,6 +189,15 @@ def line_search(
             w0 = sub.weight
         if decay_rate == 1:
             accepted = True
+        elif f_diff is not None and m == 1:   # (extension, see the module docstring; not in the reference)
+            df = f_diff(x_new, y)
+            if deprecated:
+                accepted = bool(df <= sub.fun + tol)
+            else:
+                step = x_new - y
+                dot = float(jac_f(y).flatten() @ step)
+                nrm = np.linalg.norm(step)
+                accepted = bool((df - dot) - nrm * nrm / 2 / lr <= tol)
         elif deprecated:
             accepted = bool(np.all(f(x_new) - f(y) <= sub.fun + tol))
         else:
@@ -200,7 +215,7 @@ def minimize_proximal_gradient(
     lr=1, tol=1e-5, tol_internal=1e-12, max_iter=1000000,
     max_iter_internal=100000, max_backtrack_iter=100, warm_start=False,
     decay_rate=0.5, nesterov=False, nesterov_ratio=(0, 0.25),
-    return_all=False, verbose=False, deprecated=False,
+    return_all=False, verbose=False, deprecated=False, f_diff=None,
 ):
     """Oracle for zfista.minimize_proximal_gradient (proximal_gradient.py:311-555)."""
     if deprecated:
@@ -230,7 +245,7 @@ def minimize_proximal_gradient(
                 tol=tol_internal, tol_internal=tol_internal,
                 max_iter_internal=max_iter_internal,
                 max_backtrack_iter=max_backtrack_iter, decay_rate=decay_rate,
-                deprecated=deprecated, warm_start=warm_start, m=m,
+                deprecated=deprecated, warm_start=warm_start, m=m, f_diff=f_diff,
             )
         except Exception as exc:  # :493-509 - reported, not raised
             print(f"An error occurred: {exc}")

@@ -239,6 +239,13 @@ class DiagQuadL1Ref:
     def jac_f(self, x):
         return self.d * (x - self.c)
 
+    def f_diff(self, x_new, y):
+        """f(x_new) - f(y) element by element, as a difference of squares (no cancellation of O(|f|) sums):
+        1/2 d (rn^2 - r^2) = 1/2 (d dx)(rn + r).  For oracle.cpu_ref.minimize_proximal_gradient(..., f_diff=) - the
+        checker of the engine's acceptance="resolved" (not part of the reference)."""
+        r, rn = y - self.c, x_new - self.c
+        return 0.5 * np.sum((self.d * (x_new - y)) * (rn + r))
+
     def prox_wsum_g(self, weight, x):
         return soft_threshold(x, self.lam * weight)
 

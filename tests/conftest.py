@@ -18,7 +18,7 @@ def pytest_configure(config):
 # other processes (transport rehearsals: a rendezvous, a torchrun, a subprocess) last - a hiccup of the transport
 # can then never keep the hot path's own parity tests from running.  Files not named keep their alphabetical place
 # in between.
-_FIRST = ("test_gpu_parity_diag", "test_gpu_parity_lasso", "test_gpu_temporal", "test_gpu_runahead", "test_gpu_persist", "test_gpu_noise_floor",
+_FIRST = ("test_gpu_parity_diag", "test_gpu_parity_lasso", "test_gpu_temporal", "test_gpu_runahead", "test_gpu_noise_floor",
           "test_gpu_fullsize_golden", "test_gpu_fuzz_parity", "test_gpu_multiobjective", "test_gpu_mo_fullsize",
           "test_gpu_problem_library", "test_gpu_operator_lasso", "test_gpu_tensor_callbacks", "test_gpu_sharded",
           "test_gpu_checkpoint", "test_gpu_cfg5_fullsize", "test_gpu_huge_n")

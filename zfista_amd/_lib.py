@@ -27,6 +27,8 @@ ZF_MAX_LAG = 2 * ZF_MAX_SUB_ITERS - 2
 ZF_PEND_FLUSH = -1
 TR_ERR, TR_F, TR_LR, TR_FUN, TR_TRIALS, TR_FX, TR_GX, TR_FY = range(8)
 PK_FY, PK_DOT, PK_SS, PK_GX, PK_FX, PK_ERR = range(6)
+PK_DF = 7   # ZF_ACCEPT_RESOLVED: f(x+) - f(y), accumulated element by element
+ZF_ACCEPT_REFERENCE, ZF_ACCEPT_RESOLVED = 0, 1
 
 
 class HipUnavailable(RuntimeError):
@@ -48,6 +50,7 @@ class Control(C.Structure):
         ("max_backtrack", C.c_int64), ("total_trials", C.c_int64),
         ("status", C.c_int32), ("cur", C.c_int32), ("nesterov", C.c_int32),
         ("deprecated", C.c_int32), ("need_grad", C.c_int32), ("world", C.c_int32),
+        ("accept_mode", C.c_int32), ("reserved0", C.c_int32),
         ("beta_next", C.c_double),
         ("ring_size", C.c_int32), ("sub_iters", C.c_int32), ("prev", C.c_int32),
         ("lag", C.c_int32), ("pend_status", C.c_int32), ("pass_seq", C.c_int32),
@@ -69,7 +72,7 @@ class Options(C.Structure):
     _fields_ = [
         ("lr", C.c_double), ("tol", C.c_double), ("tol_internal", C.c_double),
         ("decay_rate", C.c_double), ("max_iter", C.c_int64), ("max_backtrack_iter", C.c_int64),
-        ("nesterov", C.c_int32), ("deprecated", C.c_int32), ("sub_iters", C.c_int32), ("reserved", C.c_int32),
+        ("nesterov", C.c_int32), ("deprecated", C.c_int32), ("sub_iters", C.c_int32), ("accept_mode", C.c_int32),
     ]
 
 
@@ -259,8 +262,9 @@ def require_gpu():
 # ``config.overrides``): numerics never change silently with the environment.
 ENV_SWITCHES = ("ZF_FIN_KERNEL", "ZF_SPECULATE", "ZF_NT", "ZF_LS_SMALL", "ZF_GEMV_MFMA", "ZF_TILES_PER_WG", "ZF_SUB_ITERS",
                 "ZF_COMM", "ZF_MO_COMM", "ZF_MO_LAUNCH_AHEAD", "ZF_MO_SPIN_LIMIT", "ZF_RCCL_LIB", "ZF_DUAL_SOLVER",
-                "ZF_FORCE_SPLIT", "ZF_LIB_PATH", "ZF_PERSIST", "ZF_PERSIST_SPIN_LIMIT", "ZF_MID_CHAINS", "ZF_BENCH_BACKEND",
-                "ZF_RUNAHEAD", "ZF_RUNAHEAD_SPIN_LIMIT", "ZF_SHORT_VIA_GENERAL", "ZF_PASS_SEQ_START")
+                "ZF_FORCE_SPLIT", "ZF_LIB_PATH", "ZF_MID_CHAINS", "ZF_BENCH_BACKEND",
+                "ZF_RUNAHEAD", "ZF_RUNAHEAD_SPIN_LIMIT", "ZF_SHORT_VIA_GENERAL", "ZF_PASS_SEQ_START", "ZF_AHEAD",
+                "ZF_AHEAD_UNSHARDED", "ZF_ACCEPT")
 
 
 def env_overrides() -> dict:

@@ -41,8 +41,9 @@
 
 // pack layout (per rank): sums are added over ranks in rank order, the max is
 // maxed.  [0] f(y)  [1] <grad f(y), x+ - y>  [2] |x+ - y|^2  [3] g(x+)
-//         [4] f(x+) [5] max|x+ - y|          [6],[7] spare
-enum { ZF_PK_FY = 0, ZF_PK_DOT = 1, ZF_PK_SS = 2, ZF_PK_GX = 3, ZF_PK_FX = 4, ZF_PK_ERR = 5 };
+//         [4] f(x+) [5] max|x+ - y|          [6] stamp of the block the pass read (sharded solves; zf_pack_stamp)
+//         [7] f(x+) - f(y), accumulated element by element (ZF_ACCEPT_RESOLVED only, else 0)
+enum { ZF_PK_FY = 0, ZF_PK_DOT = 1, ZF_PK_SS = 2, ZF_PK_GX = 3, ZF_PK_FX = 4, ZF_PK_ERR = 5, ZF_PK_DF = 7 };
 // trace row: [0] err [1] F(x+) [2] lr [3] model value [4] trials [5] f(x+) [6] g(x+) [7] f(y)
 enum { ZF_TR_ERR = 0, ZF_TR_F = 1, ZF_TR_LR = 2, ZF_TR_FUN = 3, ZF_TR_TRIALS = 4,
        ZF_TR_FX = 5, ZF_TR_GX = 6, ZF_TR_FY = 7 };
@@ -132,6 +133,15 @@ ZF_HD inline void zf_eval_trial(const zf_control* c, double F_old, double lr, co
     const double F_x = f_x + g_x;                      // :295
     bool accept;
     if (c->decay_rate == 1.0) accept = true;                                  // :298
+    else if (c->accept_mode == ZF_ACCEPT_RESOLVED) {
+        // The same inequalities with f(x+) - f(y) taken from the element-wise accumulation (pack slot 7) instead of the
+        // difference of two O(|F|) sums.  :303 reads, F_old and g(x+) cancelled (they do, exactly, in exact arithmetic):
+        //   [f(x+) - f(y)] - <grad f(y), x+ - y> - |x+ - y|^2 / 2 / lr <= tol_internal
+        // - every term of the size of the step.  :301 (deprecated) keeps g(x+) on its right-hand side: f(x+) - f(y) <= fun.
+        const double df = pk[ZF_PK_DF];
+        if (c->deprecated) accept = (df <= fun + c->tol_internal);
+        else accept = ((df - dot) - nrm * nrm / 2 / lr <= c->tol_internal);
+    }
     else if (c->deprecated) accept = (f_x - f_y <= fun + c->tol_internal);    // :301
     else accept = (F_x - F_old <= fun + c->tol_internal);                     // :303
     e->fun = fun;

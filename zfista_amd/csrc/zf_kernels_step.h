@@ -27,15 +27,6 @@ struct zf_elem_acc {
     double fy, dot, ss, l1, fx, mx;
 };
 
-// threadIdx.x; OPAQUE: through a volatile asm, so that what is computed from it is not loop-invariant to the compiler.
-// Inside the pass loop of zf_persist_kernel LICM hoisted every address and index derived from the thread id out of the
-// loop and kept them alive across the chain: 315 VGPRs (one wave per SIMD) against 240 for the same body per launch.
-template <bool OPAQUE> __device__ __forceinline__ unsigned zf_tid() {
-    unsigned t = threadIdx.x;
-    if (OPAQUE) asm volatile("" : "+v"(t));
-    return t;
-}
-
 // --- element bodies --------------------------------------------------------
 // The ITERATE arithmetic (y, grad, v, x+) is NumPy's, operation by operation, never contracted:
 // x+ is bit-identical to the reference expression.  The six REDUCTIONS feed only the scalar
@@ -45,7 +36,11 @@ template <bool OPAQUE> __device__ __forceinline__ unsigned zf_tid() {
 //   f(x+) = 1/2 sum (d rn) rn  - the same formula, so f(y_{k+1}) == f(x_{k+1}) bit for bit
 //           whenever y_{k+1} == x_{k+1} (no momentum), as with one f callback
 // 20 fp64 operations per element and trial (25 unfused).
-template <bool NESTEROV, bool BOX>
+// RES (ZF_ACCEPT_RESOLVED, include/zfista_hip.h): the fifth sum is not f(x+) but the DIFFERENCE f(x+) - f(y), element by
+// element as a difference of squares - 1/2 d (rn^2 - r^2) = 1/2 (d dx)(rn + r) with dx = x+ - y = rn - r - so that the
+// acceptance test (:303) is evaluated on numbers of the size of the step, not on the difference of two sums of the size
+// of F; f(x+) is reported as f(y) + that.  One more addition per element and trial; the iterate is the same arithmetic.
+template <bool NESTEROV, bool BOX, bool RES = false>
 __device__ __forceinline__ double zf_elem_diag(double xk, double xo, double d, double c, double beta,
                                                double lr, double tau, double lo, double hi,
                                                zf_elem_acc& a) {
@@ -62,7 +57,8 @@ __device__ __forceinline__ double zf_elem_diag(double xk, double xo, double d, d
     a.ss = __builtin_fma(dx, dx, a.ss);
     a.l1 += fabs(xn);
     const double rn = xn - c;
-    a.fx = __builtin_fma(d * rn, rn, a.fx);
+    if (RES) a.fx = __builtin_fma(d * dx, rn + r, a.fx);
+    else a.fx = __builtin_fma(d * rn, rn, a.fx);
     a.mx = zf_max_abs(a.mx, dx);
     return xn;
 }
@@ -295,8 +291,6 @@ struct zf_step_args {
     // the general body (PART 2) as a FALLBACK: it runs every shape that the kernel PART fb_part (mid chains: of fb_len
     // trials) launched beside it does not run; fb_part < 0: every shape.  (zf_predict_parts)
     int fb_on, fb_part, fb_len;
-    // the persistent kernel: pass descriptors, one 128-byte line per group of the finalisation (zf_pass_desc)
-    unsigned long long* pdesc;
     // run-ahead passes (zf_runahead_kernel): a pass launched on the OTHER of two streams while its predecessor
     // is still finalising - workgroup j waits for workgroup j of the predecessor only (ra_flags), runs on the control
     // block the host EXPECTS (ra_head), and its deciding wave accepts the pass only if every pass since the last
@@ -307,10 +301,19 @@ struct zf_step_args {
     int ra_need;                   // entry: good_seq must have reached this pass_seq (the pass whose inputs this one overwrites); 0: no condition
     unsigned ra_spin;              // polls before a wait gives up (the pass is then void)
     zf_pass_head ra_head;          // the head of this pass by the host's account (beta_next: unused - taken from the momentum ring)
+    unsigned* ra_stats;            // [0] waits of run-ahead workgroups that gave up, [1] void run-ahead passes, [2] void passes AHEAD (below); polled with the control block
+    // Passes AHEAD of their predecessor's decision at KERNEL granularity (zf_trial_kernel<..., AHEAD>; sharded solves and
+    // grids of more than one round): the trial kernel takes its head from ra_head - the control block may be being
+    // decided on the other stream - stores its row plainly (row-major, fin_mode 2) and retires; zf_tail_kernel on the
+    // second stream adds the rows in zf_pass_tail's order and (unsharded) decides; sharded: all-gather, zf_decide_ahead_kernel.
+    double head_stamp;             // zf_pack_stamp of the control block the host expects this pass to find
+    int head_nf;                   // its fresh trials (lag is 0): the shape the deciding kernel checks the block against
+    int fin_grid;                  // zf_tail_kernel: workgroups of the trial kernel whose rows it adds
+    int accept_mode;               // ZF_ACCEPT_RESOLVED: the fifth row value of a trial is f(x+) - f(y) (zf_elem_diag<..., RES>): packs carry it in slot 7
 };
 
 // pass_log entry (low 16 bits; the high 16 are the launch tag): fresh trials | lagging iterations << 5 | passes << 10
-// (passes: 0 for a per-pass kernel = one pass; the persistent kernel counts the passes its launch ran)
+// (passes: always 0 since round 5 - the field counted the passes of one launch of the withdrawn multi-pass kernel)
 ZF_HD inline int zf_log_shape(int lag, int nf, int passes) { return (nf & 31) | ((lag & 31) << 5) | ((passes & 63) << 10); }
 
 struct zf_finalize_args {
@@ -470,23 +473,55 @@ __global__ __launch_bounds__(ZF_FIN_THREADS) void zf_finalize_kernel(zf_finalize
 // and the fin_ng <= 64 group rows: 2 - 3 us, against a separate finalize launch of 15 - 26 us behind a kernel
 // boundary (round 2).  Every other workgroup has taken its ticket - has read the control block for the last time -
 // before the one that writes it gets there.
-// FETCH_CTL (the persistent kernel): the deciding wave first fetches the control block past the caches from A.ctl
-// (global) into A.ctl_rw (its workgroup's LDS copy) and decides on that copy.
-// RA (run-ahead passes, zf_runahead_kernel; implies FETCH_CTL): behind its row every workgroup also publishes
+// RA (run-ahead passes, zf_runahead_kernel): behind its row every workgroup also publishes
 // that its iterates are stored (ra_flags - what workgroup j of the NEXT pass waits for); the deciding wave waits until
 // the pass before this one has been decided, accepts this pass only if that one - and every pass since the last that
 // was checked against the real block - went as the host expected, decides on a copy of the block fetched past the
 // caches, writes it back through them and publishes done_seq / good_seq (ra_word) last.  A pass that is not accepted
 // is VOID: the block stays as it is, its iterates lie in buffers nobody reads.
-template <int SP, bool OPAQUE_TID = false, bool FETCH_CTL = false, bool RA = false>
+// rows[0 .. count) of one quantity (rows are NQ doubles apart), added in index order with a compensated sum; a maximum
+// for the sixth quantity of a trial.  ONE definition for the in-kernel finalisation (zf_pass_tail) and the stand-alone
+// one (zf_tail_kernel): both add the same values in the same order, bit for bit.
+template <int NQ>
+__device__ __forceinline__ double zf_sum_rows(const double* rows, int count, bool is_max) {
+    double acc = 0.0, comp = 0.0;
+    auto add = [&](double p) {
+        if (is_max) {
+            acc = fmax(acc, p);
+        } else {
+            const double tsum = acc + p;
+            comp += (fabs(acc) >= fabs(p)) ? (acc - tsum) + p : (p - tsum) + acc;
+            acc = tsum;
+        }
+    };
+    if (count > 32 && count <= 64) {
+        // the <= 64 group rows of the last level: ALL in flight at once - one round trip to memory (~2 us on the
+        // critical path of every pass) instead of two; same additions in the same order
+        double p[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) p[u] = (u < count) ? zf_consume(rows + (int64_t)u * NQ) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) add(p[u]);
+        return is_max ? acc : acc + comp;
+    }
+    for (int k0 = 0; k0 < count; k0 += 32) {
+        double p[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) p[u] = (k0 + u < count) ? zf_consume(rows + (int64_t)(k0 + u) * NQ) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) add(p[u]);
+    }
+    return is_max ? acc : acc + comp;
+}
+
+template <int SP, bool RA = false>
 __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double v) {
-    static_assert(!RA || FETCH_CTL, "a run-ahead pass decides on a fetched copy of the control block");
     constexpr int NQ = SP * ZF_NPART;
     __shared__ int s_role;
     __shared__ double s_tot[NQ];
     __shared__ double s_pack[ZF_MAX_SUB_ITERS * ZF_PACK_LEN];
     __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
-    const int t = (int)zf_tid<OPAQUE_TID>(), G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int t = (int)threadIdx.x, G = (int)gridDim.x, b = (int)blockIdx.x;
     const int gsz = A.fin_gsz, ng = A.fin_ng;
     const bool grouped = gsz > 1;
     const bool is_max = (t % ZF_NPART == ZF_NPART - 1);
@@ -522,6 +557,8 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     // n = 1e7 took 127 rejections and ended in "Backtracking failed", with the two-level tree of round 2 about 20,
     // the reference's NumPy sums 5 in 110 iterations.  Up to 32 loads are in flight at once (one round trip to memory per
     // 32 rows: the rows are read write-through / sc1, every load misses the caches by design).
+    // (the same statements as zf_sum_rows above, as a lambda: through the function template every kernel of the family
+    //  was allocated 232 VGPRs - the 8-trial bodies 176 before - although the text is the same)
     auto sum_rows = [&](const double* rows, int count) -> double {   // rows: quantity t of row 0; rows are NQ apart
         double acc = 0.0, comp = 0.0;
         auto add = [&](double p) {
@@ -583,8 +620,12 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     pk[ZF_PK_GX] = A.fin_scale_g * q[3];
     pk[ZF_PK_FX] = A.fin_scale_f * q[4];
     pk[ZF_PK_ERR] = q[5];
-    pk[6] = A.decide ? 0.0 : zf_pack_stamp(A.ctl_rw);   // sharded x: zf_decide_kernel checks whose packs it was given
     pk[7] = 0.0;
+    if (A.accept_mode != 0) {   // (ZF_ACCEPT_RESOLVED) f(x+) - f(y) travels in slot 7; f(x+) = f(y) + that
+        pk[7] = pk[ZF_PK_FX];
+        pk[ZF_PK_FX] = pk[ZF_PK_FY] + pk[7];
+    }
+    pk[6] = A.decide ? 0.0 : zf_pack_stamp(A.ctl_rw);   // sharded x: zf_decide_kernel checks whose packs it was given
     if (t % LSTR == 0) {
 #pragma unroll
         for (int k = 0; k < ZF_PACK_LEN; ++k) {
@@ -606,6 +647,8 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
                 W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             ok = ((int)(W >> 32) >= A.ra_wait && (int)(unsigned)W >= A.ra_wait) ? 1 : 0;
+            // (the predecessor was not decided within the limit: counted like a workgroup's wait that gave up)
+            if (t == 0 && (int)(W >> 32) < A.ra_wait) __hip_atomic_fetch_add(A.ra_stats + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // a workgroup of this pass gave up waiting for its predecessor (it contributed a row of zeros)
         if (__hip_atomic_load(A.ra_flags + G + (A.pass_seq & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.pass_seq) ok = 0;
@@ -628,19 +671,18 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
             if (c->status == ZF_RUNNING && c->pend_status == 0 && c->lag == 0 && c->nit == A.ra_head.nit + SP && c->lr == A.ra_head.lr)
                 good = (unsigned)A.pass_seq;
         }
+        if (t == 0) {
+            // the shape of the pass is logged HERE, by the one wave that knows whether the pass counted: a void pass
+            // (shape 0) is no full chain in the host's statistics; a void pass is counted for the poll as well
+            if (A.pass_log) A.pass_log[A.pass_slot] = A.pass_tag | (ok ? zf_log_shape(0, SP, 0) : 0);
+            if (!ok) __hip_atomic_fetch_add(A.ra_stats + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (t == 0)
             __hip_atomic_store(A.ra_word, ((unsigned long long)(unsigned)A.pass_seq << 32) | good, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (A.decide) {
-        if constexpr (FETCH_CTL) {
-            constexpr int CW = (int)(sizeof(zf_control) / 8);
-            const unsigned long long* gw = reinterpret_cast<const unsigned long long*>(A.ctl);
-            unsigned long long* lw = reinterpret_cast<unsigned long long*>(A.ctl_rw);
-            if (t < CW) lw[t] = __hip_atomic_load(gw + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_wave_barrier();
-        }
         zf_decide_pass_wave(A.ctl_rw, s_pack, pk, A.trace, A.beta_ring, t, LSTR, s_pre);
         // this step has had its pass: the other shape kernels of the same step find the control block already
         // decided - describing the NEXT pass - and must not run it (zf_trial_kernel)
@@ -648,9 +690,116 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
     }
 }
 
+// The decide step of a pass that ran AHEAD of its predecessor's decision at kernel granularity (zf_trial_kernel<..., AHEAD>),
+// by ONE wave: in the stand-alone finalisation of an unsharded solve (zf_tail_kernel) and behind the all-gather of a
+// sharded one (zf_decide_ahead_kernel).  The trial kernel ran on the head the host expected; here - every decide step
+// runs on the second stream, in pass order - the block is what the decisions so far made of it.  It matches that head:
+// the pass counts and is decided as every pass is (zf_decide_pass_wave).  It does not (a chain before it broke, a
+// termination, and so this pass's kernel ran on iterates that are not x_k, or left at once on ra_need): the pass is
+// VOID - the block stays as it is, its iterates lie in buffers nobody reads (six buffers in ring order), and every
+// later pass of the chunk is void as well; the host finds the block unchanged at its next poll and goes on from there.
+// `packs_ok`: the gathered packs of ALL ranks carry the stamp of the block (sharded; unsharded: true).
+// ra_word = done_seq << 32 | good_seq is what the trial kernel two passes on reads (ra_need).
+struct zf_ahead_check {
+    zf_pass_head head;   // what the pass's kernel ran on
+    int nf;              // its fresh trials
+    int seq;             // its step number
+};
+__device__ __forceinline__ void zf_decide_ahead(zf_control* ctl, const double* packs, const double (&pk)[ZF_PACK_LEN], double* trace,
+                                                const double* beta_ring, int lane, int lstr, zf_trial_eval* lds_pre,
+                                                const zf_ahead_check& H, bool packs_ok, unsigned long long* ra_word,
+                                                unsigned* ra_stats, int* pass_log, int pass_slot, int pass_tag) {
+    const unsigned long long W = __hip_atomic_load(ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned good = (unsigned)W;
+    const bool ok = packs_ok && ctl->status == ZF_RUNNING && ctl->pend_status == 0 && ctl->lag == 0 && ctl->nit == H.head.nit &&
+                    ctl->lr == H.head.lr && ctl->cur == H.head.cur && ctl->prev == H.head.prev && zf_fresh_len(ctl) == H.nf;
+    if (ok) {
+        zf_decide_pass_wave(ctl, packs, pk, trace, beta_ring, lane, lstr, lds_pre);
+        if (lane == 0) ctl->pass_seq = H.seq;
+        __builtin_amdgcn_wave_barrier();
+        // as expected: every trial accepted, nothing terminated - the head of the next pass is the one the host predicted
+        if (ctl->status == ZF_RUNNING && ctl->pend_status == 0 && ctl->lag == 0 && ctl->nit == H.head.nit + H.nf && ctl->lr == H.head.lr)
+            good = (unsigned)H.seq;
+    } else if (lane == 0) {
+        __hip_atomic_fetch_add(ra_stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pass_log) pass_log[pass_slot] = pass_tag;   // (shape 0: the launch ran, its pass does not count - zf_collect_timing)
+    }
+    if (lane == 0)
+        __hip_atomic_store(ra_word, ((unsigned long long)(unsigned)H.seq << 32) | good, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Stand-alone finalisation of a pass whose trial kernel stored its rows plainly (fin_mode 2: passes ahead): the SAME
+// sums in the SAME order as zf_pass_tail - workgroup g of this launch is "the last arriver of group g" (the group's rows
+// in index order, compensated), the last of them adds the group rows, builds the packs (stamped with the state the host
+// expected) and - unsharded x - decides (zf_decide_ahead).  Grids of up to ZF_FIN_GROUPS workgroups: one workgroup adds
+// all rows, as the in-kernel finalisation does.  Launched with fin_ng workgroups (1 when not grouped) of 128 threads.
+template <int SP>
+__global__ __launch_bounds__(128) void zf_tail_kernel(zf_step_args A) {
+    constexpr int NQ = SP * ZF_NPART;
+    static_assert(NQ <= 128, "one thread per row value");
+    __shared__ int s_last;
+    __shared__ double s_tot[NQ];
+    __shared__ double s_pack[ZF_MAX_SUB_ITERS * ZF_PACK_LEN];
+    __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
+    const int t = (int)threadIdx.x, G = A.fin_grid, g = (int)blockIdx.x;
+    const int gsz = A.fin_gsz, ng = A.fin_ng;
+    const bool grouped = gsz > 1;
+    const bool is_max = (t % ZF_NPART == ZF_NPART - 1);
+    if (grouped) {
+        const int b0 = g * gsz;
+        const int b1 = b0 + gsz <= G ? b0 + gsz : G;
+        if (t < NQ) zf_publish(A.grp_part + (int64_t)g * NQ + t, zf_sum_rows<NQ>(A.blk_part + (int64_t)b0 * NQ + t, b1 - b0, is_max));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            const unsigned tk = __hip_atomic_fetch_add(A.fin_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (tk == (unsigned)(ng - 1));
+            if (last) __hip_atomic_store(A.fin_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+    }
+    if (t < NQ) s_tot[t] = grouped ? zf_sum_rows<NQ>(A.grp_part + t, ng, is_max) : zf_sum_rows<NQ>(A.blk_part + t, G, is_max);
+    __syncthreads();
+    if (t >= 64) return;
+    constexpr int SH = zf_chain_h(SP);
+    constexpr int LSTR = 64 >> SH;
+    const int trial = t / LSTR;
+    const double* q = s_tot + trial * ZF_NPART;
+    double pk[ZF_PACK_LEN];
+    pk[ZF_PK_FY] = A.fin_scale_f * q[0];
+    pk[ZF_PK_DOT] = q[1];
+    pk[ZF_PK_SS] = q[2];
+    pk[ZF_PK_GX] = A.fin_scale_g * q[3];
+    pk[ZF_PK_FX] = A.fin_scale_f * q[4];
+    pk[ZF_PK_ERR] = q[5];
+    pk[7] = 0.0;
+    if (A.accept_mode != 0) {   // (ZF_ACCEPT_RESOLVED) f(x+) - f(y) travels in slot 7; f(x+) = f(y) + that
+        pk[7] = pk[ZF_PK_FX];
+        pk[ZF_PK_FX] = pk[ZF_PK_FY] + pk[7];
+    }
+    pk[6] = A.decide ? 0.0 : A.head_stamp;   // sharded x: zf_decide_ahead_kernel checks whose packs it was given
+    if (t % LSTR == 0) {
+#pragma unroll
+        for (int k = 0; k < ZF_PACK_LEN; ++k) {
+            A.pack[trial * ZF_PACK_LEN + k] = pk[k];
+            s_pack[trial * ZF_PACK_LEN + k] = pk[k];
+        }
+    }
+    if (A.decide) {
+        zf_ahead_check H;
+        H.head = A.ra_head;
+        H.nf = A.head_nf;
+        H.seq = A.pass_seq;
+        zf_decide_ahead(A.ctl_rw, s_pack, pk, A.trace, A.beta_ring, t, LSTR, s_pre, H, true, A.ra_word, A.ra_stats, A.pass_log,
+                        A.pass_slot, A.pass_tag);
+    }
+}
+
 // What a pass reads of the control block before its first vector load.  The per-pass kernels fill it with plain
-// (scalar) loads - the block was written by an earlier launch; the persistent multi-pass kernel (zf_persist_kernel)
-// from its own copy of the block, fetched past the caches after every in-kernel decide.
+// (scalar) loads - the block was written by an earlier launch; run-ahead passes take it from the host's prediction.
 // a wave-uniform 64-bit value into scalar registers
 __device__ __forceinline__ unsigned long long zf_uniform_u64(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -704,14 +853,14 @@ __device__ __forceinline__ zf_pass_head zf_head_of(const zf_control* c) {
 // Returns the workgroup's row: thread t < 6 S holds quantity t % 6 of fresh trial t / 6 (0 for the other threads).
 // COH: the iterates are loaded and stored agent-coherently (sc1, zf_st2_coh) - a run-ahead pass reads what a kernel
 // still running on another XCD has just stored (full chains through the DMA pipeline only; +0.7-1 % per pass, measured)
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST, int SP = S, bool OPAQUE_TID = false,
-          bool COH = false>
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, int MODE, bool HIST, int SP = S, bool COH = false, bool RES = false>
 __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* lds, const zf_pass_head& HD, const int lag,
                                                 const int nf, zf_d2* stage = nullptr) {
     constexpr bool FULL = (MODE == 0);          // nothing replayed, S fresh trials
+    static_assert(!RES || GRAD_INLINE, "resolved differences f(x+) - f(y): the separable problem");
     static_assert(!COH || (FULL && !HIST && GRAD_INLINE && zf_uses_glds<S, MODE, HIST, GRAD_INLINE, SP>()),
                   "coherent iterate traffic: the full chain through the DMA pipeline");
-    const unsigned tidx = zf_tid<OPAQUE_TID>();   // threadIdx.x (opaque per call inside the persistent kernel's pass loop)
+    const unsigned tidx = threadIdx.x;
     constexpr bool FRESH_FULL = (MODE <= 1);    // S fresh trials
     const int cur = HD.cur;
     const int prev = HD.prev;
@@ -771,8 +920,8 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
             if (FRESH_FULL || j < nf) {
                 zf_d2 r;
                 if (GRAD_INLINE) {
-                    r.x = zf_elem_diag<NESTEROV, BOX>(a.x, o.x, q.x, cc.x, beta[j], lr, tau, A.lo, A.hi, acc[j]);
-                    r.y = zf_elem_diag<NESTEROV, BOX>(a.y, o.y, q.y, cc.y, beta[j], lr, tau, A.lo, A.hi, acc[j]);
+                    r.x = zf_elem_diag<NESTEROV, BOX, RES>(a.x, o.x, q.x, cc.x, beta[j], lr, tau, A.lo, A.hi, acc[j]);
+                    r.y = zf_elem_diag<NESTEROV, BOX, RES>(a.y, o.y, q.y, cc.y, beta[j], lr, tau, A.lo, A.hi, acc[j]);
                 } else {
                     r.x = zf_elem_vec<NESTEROV, BOX>(a.x, o.x, q.x, beta[j], lr, tau, A.lo, A.hi, acc[j]);
                     r.y = zf_elem_vec<NESTEROV, BOX>(a.y, o.y, q.y, beta[j], lr, tau, A.lo, A.hi, acc[j]);
@@ -1053,7 +1202,7 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
                 if (FRESH_FULL || j < nf) {
                     double r;
                     if (GRAD_INLINE)
-                        r = zf_elem_diag<NESTEROV, BOX>(a, o, q, cc, beta[j], lr, tau, A.lo, A.hi, acc[j]);
+                        r = zf_elem_diag<NESTEROV, BOX, RES>(a, o, q, cc, beta[j], lr, tau, A.lo, A.hi, acc[j]);
                     else r = zf_elem_vec<NESTEROV, BOX>(a, o, q, beta[j], lr, tau, A.lo, A.hi, acc[j]);
                     o = a;
                     a = r;
@@ -1143,26 +1292,38 @@ __device__ __forceinline__ void zf_pass_finish(const zf_step_args& A, const doub
 // the branches (S = 16: 274 VGPRs for parts 0 + 1, ~400 for parts 1 + 2 - one wave per SIMD instead of two;
 // S = 8: 207 instead of 190); every further launch costs a kernel boundary (~1.5-4 us) per pass - so the host
 // launches the ONE kernel it predicts (zf_predict_parts) and all of 0, 1, 2 only when it cannot know.
-// (debug builds with phase stamps: the stamps cost registers - 258 instead of 240 for the full chain, ONE wave per SIMD
-//  instead of two, and every conclusion drawn from them would be about another kernel; hold the allocator to the product's
-//  occupancy there)
-#ifndef ZF_TRIAL_ATTR
-#ifdef ZF_PERSIST_DEBUG
-#define ZF_TRIAL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
-#else
-#define ZF_TRIAL_ATTR
-#endif
-#endif
-template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false, int PART = 0, int L = 0>
-__global__ __launch_bounds__(ZF_BLOCK) ZF_TRIAL_ATTR void zf_trial_kernel(zf_step_args A) {
+// AHEAD (PART 0 and 3 of chains of 16): the pass runs AHEAD of its predecessor's decision, at kernel granularity.  Its
+// head is the one the host expects (A.ra_head; nothing lagging, exactly the kernel's chain length) - the control block
+// is not read at all: the decide step of the pass before may be writing it on the other stream right now.  It leaves at
+// once when the pass two before it - whose inputs it would overwrite - did not go as expected (ra_need against the good
+// word), stores its row plainly (row-major) and retires: zf_tail_kernel on the second stream adds the rows, and the
+// deciding wave there checks the block against this head before it decides (a pass on a wrong head is VOID).
+// RES: the kernels of a solver with ZF_ACCEPT_RESOLVED (zf_elem_diag<..., RES>).
+template <bool GRAD_INLINE, bool NESTEROV, bool BOX, bool NT, int S, bool HIST = false, int PART = 0, int L = 0, bool AHEAD = false,
+          bool RES = false>
+__global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
     static_assert(GRAD_INLINE || S == 1, "temporal blocking needs an elementwise gradient");
     static_assert(PART <= 1 || S >= 16, "the third and fourth kernels exist for chains of 16 only");
     static_assert(PART != 3 || (L >= ZF_MID_MIN && L <= ZF_MID_MAX), "mid chains: ZF_MID_MIN .. ZF_MID_MAX trials");
+    static_assert(!AHEAD || (S >= 16 && !HIST && (PART == 0 || PART == 3)), "passes ahead: full and mid chains of a 16-chain solver");
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
     constexpr bool GLDS = PART == 3 ? zf_uses_glds<(PART == 3 ? L : S), 0, HIST, GRAD_INLINE, S>()
                           : PART != 1 ? zf_uses_glds<S, PART == 0 ? 0 : 2, HIST, GRAD_INLINE>()
                                       : (S >= 16 && zf_uses_glds<S / 2, 1, HIST, GRAD_INLINE, S>());
     __shared__ zf_d2 stage[GLDS ? ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS : 1];   // the stages of the LDS-DMA pipeline (16 KiB each)
+    if constexpr (AHEAD) {
+        if (A.ra_need != 0) {
+            const unsigned long long W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(unsigned)W < A.ra_need) return;   // (decided long ago: the launch came behind an event of that decide step)
+        }
+        zf_pass_head HA = A.ra_head;
+        HA.beta_next = NESTEROV ? A.beta_ring[HA.nit % ZF_RING] : 0.0;   // (zf_resolve_beta with nothing lagging)
+        constexpr int LEN = PART == 3 ? L : S;
+        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(0, LEN, 0);
+        const double va = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, LEN, 0, HIST, S, false, RES>(A, lds, HA, 0, LEN, stage);
+        if (threadIdx.x < S * ZF_NPART) A.blk_part[(int64_t)blockIdx.x * (S * ZF_NPART) + threadIdx.x] = va;
+        return;
+    }
     // wave-uniform control reads (scalar loads); written by the previous step's decide
     if (A.ctl->status != ZF_RUNNING) return;
     // an earlier kernel of THIS step ran the pass and decided it in its own launch: the control block now describes
@@ -1172,7 +1333,7 @@ __global__ __launch_bounds__(ZF_BLOCK) ZF_TRIAL_ATTR void zf_trial_kernel(zf_ste
     const zf_pass_head HD = zf_head_of(A.ctl);
     if constexpr (S == 1) {
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(0, 1, 0);
-        zf_pass_finish<S>(A, zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, HD, 0, 1));
+        zf_pass_finish<S>(A, zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST, S, false, RES>(A, lds, HD, 0, 1));
     } else {
         const int lag = A.ctl->lag;
         const int nf = zf_fresh_len(A.ctl);   // fresh trials of this chain (0: materialise only)
@@ -1183,50 +1344,28 @@ __global__ __launch_bounds__(ZF_BLOCK) ZF_TRIAL_ATTR void zf_trial_kernel(zf_ste
         }
         if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(lag, nf, 0);
         double v;
-#ifdef ZF_PERSIST_DEBUG   // (the same phase stamps as zf_persist_kernel, for the per-pass full chain: slot = pass_seq % 8)
-        long long* dbg = nullptr;
-        if constexpr (PART == 0 && !HIST) {
-            if (A.hist && threadIdx.x == 0) {
-                dbg = reinterpret_cast<long long*>(A.hist) + ((int64_t)(A.pass_seq % 8) * gridDim.x + blockIdx.x) * 8;
-                dbg[0] = wall_clock64();
-                dbg[6] = gridDim.x;
-                // where this workgroup runs: XCC_ID (hwreg 20) above HW_ID (hwreg 4: cu_id [11:8], sh_id [12], se_id [15:13])
-                dbg[7] = ((long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) |
-                         (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
-            }
-        }
-#endif
         if constexpr (PART == 0) {
-            v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST>(A, lds, HD, 0, S, stage);
-#ifdef ZF_PERSIST_DEBUG
-            if (dbg) dbg[2] = wall_clock64();
-#endif
+            v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 0, HIST, S, false, RES>(A, lds, HD, 0, S, stage);
         } else if constexpr (PART == 3) {
             // a branch-free chain of L trials: the passes of a tail shared by two passes (the driver's K = 20 blocks:
             // 10 + 10) and the tail itself
-            v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, L, 0, HIST, S>(A, lds, HD, 0, L, stage);
+            v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, L, 0, HIST, S, false, RES>(A, lds, HD, 0, L, stage);
         } else if constexpr (PART == 2) {
             // (nf is laundered through readfirstlane: knowing nf > S / 2 the compiler made the first
             //  trials unconditional, scheduled across them and needed 379 VGPRs instead of 227; an empty
             //  asm as the barrier gave 260)
             const int nf_opaque = __builtin_amdgcn_readfirstlane(nf);
-            v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, HD, lag, nf_opaque, stage);
+            v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST, S, false, RES>(A, lds, HD, lag, nf_opaque, stage);
         } else if constexpr (S >= 16) {
             constexpr int SS = S / 2;
-            if (lag == 0 && nf == SS) v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 0, HIST, S>(A, lds, HD, 0, SS, stage);
-            else if (nf == SS) v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 1, HIST, S>(A, lds, HD, lag, SS, stage);
-            else v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 2, HIST, S>(A, lds, HD, lag, nf, stage);
+            if (lag == 0 && nf == SS) v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 0, HIST, S, false, RES>(A, lds, HD, 0, SS, stage);
+            else if (nf == SS) v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 1, HIST, S, false, RES>(A, lds, HD, lag, SS, stage);
+            else v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, SS, 2, HIST, S, false, RES>(A, lds, HD, lag, nf, stage);
         } else {
-            if (nf == S) v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1, HIST>(A, lds, HD, lag, S);
-            else v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST>(A, lds, HD, lag, nf);
+            if (nf == S) v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 1, HIST, S, false, RES>(A, lds, HD, lag, S);
+            else v = zf_trial_body<GRAD_INLINE, NESTEROV, BOX, NT, S, 2, HIST, S, false, RES>(A, lds, HD, lag, nf);
         }
         zf_pass_finish<S>(A, v);
-#ifdef ZF_PERSIST_DEBUG
-        if constexpr (PART == 0 && !HIST) {
-            __syncthreads();
-            if (dbg) dbg[3] = wall_clock64();
-        }
-#endif
     }
 }
 
@@ -1241,7 +1380,7 @@ __global__ __launch_bounds__(ZF_BLOCK) ZF_TRIAL_ATTR void zf_trial_kernel(zf_ste
 // (ra_need) if that went wrong.  Results are those of one launch per pass, bit for bit (tests/test_gpu_runahead.py).
 // (Held to two waves per SIMD like the full chain it is: with the entry logic in front of the chain the allocator
 //  otherwise takes 258 registers; capped it parks one 8-byte value in scratch across the tile loop, stored and loaded once.)
-template <bool NESTEROV, bool BOX, bool NT>
+template <bool NESTEROV, bool BOX, bool NT, bool RES = false>
 __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void zf_runahead_kernel(zf_step_args A) {
     constexpr int S = ZF_MAX_SUB;
     static_assert(S == 16, "run-ahead passes are full chains of 16");
@@ -1260,6 +1399,7 @@ __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (b == 0 && threadIdx.x == 0) {
                 const unsigned long long W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(A.ra_word, ((unsigned long long)(unsigned)A.pass_seq << 32) | (unsigned)W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(A.ra_stats + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
         }
@@ -1285,6 +1425,7 @@ __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if (++k > A.ra_spin) {   // gave up: this pass is void (its deciding wave reads the poison word)
                         // (a word per pass in flight - this one, the one behind it: the slot of pass_seq & 3)
                         __hip_atomic_store(A.ra_flags + G + (A.pass_seq & 3), (unsigned)A.pass_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(A.ra_stats + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the host reads it with its next poll and stops launching run-ahead passes)
                         go = 2;
                         break;
                     }
@@ -1297,156 +1438,18 @@ __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     // (wave-uniform, in a scalar register: as a value out of LDS it made the chain's control flow divergent)
     const int go = A.ra_wait == 0 ? 1 : __builtin_amdgcn_readfirstlane(s_go);
-    if (go == 0) return;
+    if (go == 0) {   // the whole pass leaves: void
+        if (b == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(A.ra_stats + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const bool run = go == 1;
-    if (A.pass_log && b == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(0, S, 0);
     HD.beta_next = NESTEROV ? A.beta_ring[HD.nit % ZF_RING] : 0.0;   // (zf_resolve_beta with nothing lagging)
     double v = 0.0;
-    if (run) v = zf_trial_body<true, NESTEROV, BOX, NT, S, 0, false, S, false, true>(A, lds, HD, 0, S, stage);
+    if (run) v = zf_trial_body<true, NESTEROV, BOX, NT, S, 0, false, S, true, RES>(A, lds, HD, 0, S, stage);
     zf_step_args T = A;   // decided on the deciding workgroup's own copy of the block
     T.ctl = A.ctl_rw;
     T.ctl_rw = &s_ctl;
-    zf_pass_tail<S, false, true, true>(T, v);
-}
-
-// ---------------------------------------------------------------------------
-// Several passes in ONE launch (grids whose workgroups are all resident at once: n up to ~2.5e7).
-// A per-pass launch costs what lies between two dependent kernels of a stream (8 - 10 us) and the ramp of its one
-// round of workgroups; at n = 1e7 that is a quarter of a 0.15 ms pass, at n <= 1e6 most of it.  This kernel runs up
-// to `npass` FULL-CHAIN passes back to back: every workgroup keeps its tiles, the last arriver of a pass decides it as
-// zf_pass_tail always does, and instead of ending the launch it publishes the new control block; the others wait for
-// its sequence number and go on.  It leaves - before touching anything - as soon as the next pass is not a full chain
-// (a chain broke, the tail before max_iter, a final status): the per-pass kernels the host enqueues behind it take over,
-// so it needs no other body than the hot one (all bodies in one kernel: 274+ VGPRs, one wave per SIMD).
-//
-// Memory model.  The L2s of the 8 XCDs are not coherent with each other and a launch is no longer a boundary, so
-// inside this kernel the control block is only ever read and written PAST the caches: every workgroup fetches its own
-// copy (52 words, one agent-scope load per lane) at the start of a pass; the deciding wave runs zf_decide_pass on its
-// copy in LDS and publishes it word by word, the word that carries pass_seq last, behind a counted wait.  The
-// iterates a workgroup reads in pass p + 1 are those it wrote itself in pass p (same tiles, same CU, same L2); its
-// L1 is invalidated after every wait (acquire).  Rows and tickets were write-through / atomic already.  Every wait is
-// bounded (spin_limit polls): if the grid is not co-resident after all - another process took CUs - the waiting
-// workgroups leave; the control block is only ever advanced by a complete pass, so what the host finds at its next
-// poll is a consistent state and the per-pass path goes on from it.
-// Bit-identical to per-pass launches: same geometry, same sums in the same order, same decide code.
-// Registers: the chain needs 240 VGPRs per launch and, inside the pass loop, 274 - one wave per SIMD - although nothing
-// of a pass outlives it but a few addresses.  amdgpu_waves_per_eu(2, 2) holds the allocator to 256: it then parks ~25
-// pass-loop invariants in scratch, stored once per launch and loaded once per PASS, outside the tile loops
-// (tests/test_abi.py checks exactly that: a bounded private segment, no scratch instruction at loop depth >= 2).
-// What the workgroups need of the control block to run the next pass: THREE words in one cache line, published by
-// the deciding wave; word 0 is written last and doubles as the barrier.  (Measured with the phase stamps of
-// tools/persist_phases.py: 489 workgroups fetching the 52 words of the block itself behind every barrier - 25 000
-// loads of four cache lines, all served by one memory channel - took 12 us per pass; one descriptor line per group of
-// workgroups took as long, because 62 scattered write-through stores leave the deciding wave one after the other.)
-//   [0] pass_seq | go << 32 | cur << 40 | prev << 44 | ring << 48     [1] lr     [2] nit
-// The momentum factor of the next trial is beta_ring[nit % ZF_RING] (zf_resolve_beta with nothing lagging).
-constexpr int ZF_PDESC_WORDS = 3;
-template <bool NESTEROV, bool BOX, bool NT>
-__global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void zf_persist_kernel(zf_step_args A, int npass, unsigned spin_limit) {
-    constexpr int S = ZF_MAX_SUB;
-    constexpr int CW = (int)(sizeof(zf_control) / 8);
-    static_assert(sizeof(zf_control) % 8 == 0 && CW <= 64, "one lane per word of the control block");
-    static_assert(S == 16, "the persistent kernel holds the 16-trial full chain");
-    __shared__ double lds[ZF_WAVES * S * ZF_NPART];
-    __shared__ zf_d2 stage[ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS];
-    __shared__ zf_control s_ctl;                      // the deciding workgroup's copy of the control block
-    __shared__ unsigned long long s_desc[ZF_PDESC_WORDS];
-    __shared__ int s_go;
-    unsigned long long* gw = reinterpret_cast<unsigned long long*>(A.ctl_rw);
-    unsigned long long* lw = reinterpret_cast<unsigned long long*>(&s_ctl);
-    unsigned long long* my_desc = A.pdesc;
-    if (threadIdx.x == 0) s_ctl.pass_seq = 0;
-    // the first pass reads the block as every per-pass kernel does (written by an earlier launch)
-    zf_pass_head HD = zf_head_of(A.ctl);
-    if (A.ctl->status != ZF_RUNNING || A.ctl->lag != 0 || zf_fresh_len(A.ctl) != S) return;
-#pragma unroll 1
-    for (int p = 0; p < npass; ++p) {
-        const int seq = A.pass_seq + p;
-#ifdef ZF_PERSIST_DEBUG   // (timestamps of the phases of every pass and workgroup: tools/persist_phases.py)
-        long long* dbg = reinterpret_cast<long long*>(A.hist) + ((int64_t)p * gridDim.x + blockIdx.x) * 8;
-        if (A.hist && threadIdx.x == 0) {
-            dbg[0] = wall_clock64();
-            dbg[6] = gridDim.x;
-        }
-#endif
-        if (A.pass_log && blockIdx.x == 0 && threadIdx.x == 0) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(0, S, p + 1);
-        const double v = zf_trial_body<true, NESTEROV, BOX, NT, S, 0, false, S, true>(A, lds, HD, 0, S, stage);
-#ifdef ZF_PERSIST_DEBUG
-        if (A.hist && threadIdx.x == 0) dbg[2] = wall_clock64();
-#endif
-        zf_step_args T = A;           // this pass: decided on the deciding workgroup's own copy of the block
-        T.ctl = A.ctl_rw;
-        T.ctl_rw = &s_ctl;
-        T.pass_seq = seq;
-        T.decide = 1;
-        zf_pass_tail<S, true, true>(T, v);
-        __syncthreads();
-#ifdef ZF_PERSIST_DEBUG
-        if (A.hist && threadIdx.x == 0) {
-            dbg[3] = wall_clock64();
-            dbg[5] = (s_ctl.pass_seq == seq) ? 1 : 0;
-        }
-#endif
-        if (s_ctl.pass_seq == seq) {
-            // this workgroup decided the pass (zf_pass_tail left its number in the copy): publish the block for the
-            // host and for later launches, then one descriptor per group, its word 0 last
-            if (threadIdx.x < 64) {
-                const int lane = threadIdx.x;
-                if (lane < CW) __hip_atomic_store(gw + lane, lw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int go = (s_ctl.status == ZF_RUNNING && s_ctl.lag == 0 && zf_fresh_len(&s_ctl) == S) ? 1 : 0;
-                unsigned long long w[ZF_PDESC_WORDS];
-                w[0] = (unsigned long long)(unsigned)seq | ((unsigned long long)go << 32) | ((unsigned long long)(s_ctl.cur & 15) << 40) |
-                       ((unsigned long long)(s_ctl.prev & 15) << 44) | ((unsigned long long)(s_ctl.ring_size & 15) << 48);
-                w[1] = (unsigned long long)__double_as_longlong(s_ctl.lr);
-                w[2] = (unsigned long long)s_ctl.nit;
-                if (lane >= 1 && lane < ZF_PDESC_WORDS) __hip_atomic_store(A.pdesc + lane, w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) {
-                    __hip_atomic_store(A.pdesc, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int k = 0; k < ZF_PDESC_WORDS; ++k) s_desc[k] = w[k];
-                    s_go = 1;
-                }
-            }
-        } else if (threadIdx.x == 0) {
-            int ok = 0;
-            for (unsigned k = 0; k < spin_limit; ++k) {
-                const unsigned long long w0 = __hip_atomic_load(my_desc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(unsigned)w0 == seq) {
-                    s_desc[0] = w0;
-                    ok = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            if (ok) {
-#pragma unroll
-                for (int k = 1; k < ZF_PDESC_WORDS; ++k) s_desc[k] = __hip_atomic_load(my_desc + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s_go = ok;
-        }
-        __syncthreads();
-#ifdef ZF_PERSIST_DEBUG
-        if (A.hist && threadIdx.x == 0) dbg[4] = wall_clock64();
-#endif
-        if (!s_go || ((s_desc[0] >> 32) & 1) == 0) return;   // gave up waiting / the next pass is not a full chain
-        // No agent-scope acquire here: its buffer_inv sc1 walks the L2, and 2000 waves issuing one behind every barrier
-        // cost 11 us per pass (phase stamps).  What this workgroup reads next and somebody else wrote - rows, tickets,
-        // the descriptor - is read past the caches anyway; the iterates it reads are those it stored itself, through
-        // the L1 it reads them from.  The L1 of this CU alone is dropped all the same (sc0: a CU-local operation).
-#ifndef ZF_PERSIST_NO_INV
-        asm volatile("buffer_inv sc0" ::: "memory");
-#endif
-        // (wave-uniform values out of LDS into scalar registers: left in vector registers, lr, nit and the sixteen
-        //  momentum factors loaded through them cost the chain its second wave per SIMD)
-        const unsigned cp = __builtin_amdgcn_readfirstlane((unsigned)(s_desc[0] >> 40));
-        HD.cur = (int)(cp & 15);
-        HD.prev = (int)((cp >> 4) & 15);
-        HD.ring = (int)((cp >> 8) & 15);
-        HD.lr = zf_uniform_f64(__longlong_as_double((long long)s_desc[1]));
-        HD.nit = (int64_t)zf_uniform_u64(s_desc[2]);
-        HD.beta_next = NESTEROV ? A.beta_ring[HD.nit % ZF_RING] : 0.0;
-    }
+    zf_pass_tail<S, true>(T, v);
 }
 
 // --- f(x), g(x) at a point (initial F(x0), proximal_gradient.py:466,472) -------

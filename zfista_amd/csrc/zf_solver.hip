@@ -67,6 +67,28 @@ __global__ __launch_bounds__(64) void zf_decide_kernel(zf_control* ctl, const do
     zf_decide_pass_wave(ctl, packs, pk, trace, beta_ring, lane, 1, s_pre);
 }
 
+// The decide step of a SHARDED pass that ran ahead of its predecessor's decision (zf_decide_ahead, zf_kernels_step.h):
+// as zf_decide_kernel, but the control block is first checked against the head the pass's trial kernel ran on - a
+// pass on a head that did not come true is void - and the done / good word is published for the trial kernel two
+// passes on.  All ranks hold the same block and the same gathered packs: all of them decide, or void, together.
+__global__ __launch_bounds__(64) void zf_decide_ahead_kernel(zf_control* ctl, const double* packs, double* trace, const double* beta_ring,
+                                                             int sub, zf_ahead_check H, unsigned long long* ra_word, unsigned* ra_stats,
+                                                             int* pass_log, int pass_slot, int pass_tag) {
+    __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    bool packs_ok = true;
+    {
+        const double want = zf_pack_stamp(ctl);
+        const int world = ctl->world;
+        for (int r = 0; r < world; ++r)
+            if (packs[(int64_t)r * sub * ZF_PACK_LEN + 6] != want) packs_ok = false;
+    }
+    double pk[ZF_PACK_LEN] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (lane < sub) zf_reduce_packs(packs + lane * ZF_PACK_LEN, ctl->world, sub * ZF_PACK_LEN, pk);   // rank order
+    zf_decide_ahead(ctl, packs, pk, trace, beta_ring, lane, 1, s_pre, H, packs_ok, ra_word, ra_stats, pass_log, pass_slot, pass_tag);
+}
+
 __global__ void zf_set_max_iter_kernel(zf_control* ctl, int64_t max_iter) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     ctl->max_iter = max_iter;
@@ -135,6 +157,7 @@ struct zf_solver {
     hipStream_t stream;
     int grid;                 // trial kernel grid
     bool box;
+    bool res = false;         // ZF_ACCEPT_RESOLVED: the kernels accumulate f(x+) - f(y) element by element (zf_elem_diag<..., RES>)
     // device memory owned by the solver
     double* xbuf = nullptr;   // ring * n_pad
     double* xb[ZF_MAX_RING] = {};
@@ -145,7 +168,6 @@ struct zf_solver {
     double* slice_part = nullptr; // ZF_NPART x ZF_FIN_WGS
     unsigned* fin_cnt = nullptr;  // arrival counters: of the finalize workgroups / of the in-kernel finalisation (zf_pass_tail)
     double* grp_part = nullptr;   // ZF_NPART x S x ZF_FIN_GROUPS group rows of the in-kernel finalisation
-    unsigned long long* pdesc = nullptr;   // pass descriptors of the persistent kernel: one 128-byte line per group
     bool nt = true;               // nontemporal policy for once-touched streams
     char* ctl_trace = nullptr;    // one allocation: the control block (ZF_CTL_SLOT bytes) and the trace ring behind it
     char* mail = nullptr;         // pinned host mirror of ctl_trace: what a poll copies into
@@ -201,13 +223,8 @@ struct zf_solver {
     int part_mask = 7;                    // ZF_K_* bits (ZF_K_ALL until a prediction says otherwise)
     int mid_len = 0;                      // ZF_K_MID: trials of the mid chain
     int fb_part = -1, fb_len = 0;         // ZF_K_FALLBACK: the general body runs what this kernel does not (-1: everything)
-    // several full-chain passes per launch (zf_persist_kernel): grids the device holds at once
-    int persist_cap = -1;                 // co-resident workgroups of the persistent kernel (-1: not asked yet)
-    bool persist = false;                 // ZF_PERSIST=1 at creation: consecutive full chains share a launch (measured: no gain)
     bool mid_chains = true;               // ZF_MID_CHAINS=0 at creation: tails of 9 .. 15 trials through the general body (A/B)
     bool short_general = false;           // ZF_SHORT_VIA_GENERAL=1 at creation: the shapes of PART 1 through the general body (A/B)
-    unsigned persist_spin = 1u << 20;     // polls a workgroup waits for a pass to be decided before it gives up
-    int64_t persist_launches = 0, persist_passes = 0;
     bool speculate = true;                // ZF_SPECULATE=0 at creation: always launch every shape
     int64_t steps_issued = 0, kernels_issued = 0;   // trial steps and the shape kernels launched for them (zf_solver_launch_counts)
     int pass_seq = 0;                     // step counter (zf_step_args.pass_seq)
@@ -220,7 +237,7 @@ struct zf_solver {
     // to `stream` and `stream2`; stream k has its own rows / group rows / counters / packs (two passes are in flight)
     bool ra = false;                      // eligible (separable f, chains of 16, one rank, a one-round grid) and not switched off (ZF_RUNAHEAD=0)
     int ra_cap = -1;                      // co-resident workgroups of the run-ahead kernel (-1: not asked yet)
-    unsigned ra_spin = 1u << 17;          // polls before a wait gives up (ZF_RUNAHEAD_SPIN_LIMIT): ~0.3 s, a thousand passes' worth
+    unsigned ra_spin = 1u << 13;          // polls before a wait gives up (ZF_RUNAHEAD_SPIN_LIMIT): ~15 ms, some tens of passes' worth
     hipStream_t stream2 = nullptr;
     hipEvent_t ra_join = nullptr;         // stream2 -> stream at the end of a run of run-ahead passes
     hipEvent_t ra_fork = nullptr;         // stream -> stream2 in front of a run
@@ -236,23 +253,49 @@ struct zf_solver {
     unsigned* fin_cnt2 = nullptr;
     double* pack2 = nullptr;
     int64_t ra_passes = 0, ra_ahead = 0;  // run-ahead kernels launched / of them behind a pass still in flight (zf_solver_launch_counts)
+    // What the device reports about passes that ran ahead: three counters in the slack of the control block's slot,
+    // copied with every poll - [0] waits that gave up (a run-ahead workgroup's, or a deciding wave's), [1] void run-ahead
+    // passes, [2] void passes AHEAD (below).  After the first wait that gave up the solver launches no further run-ahead
+    // passes (ra_off): the device is being shared, and every such wait costs its whole limit.
+    unsigned* ra_stats = nullptr;         // = ctl_trace + ZF_STATS_OFF
+    int64_t ra_timeouts = 0, ra_voids = 0, ah_voids = 0;   // as of the last poll
+    bool ra_off = false;
+    // Passes AHEAD at kernel granularity (zf_trial_kernel<..., AHEAD>, zf_tail_kernel, zf_decide_ahead_kernel): sharded
+    // solves through the library's communicator, and (ZF_AHEAD_UNSHARDED) unsharded grids of more than one round.  The
+    // trial kernels of consecutive exactly predicted full / mid chains go back to back to `stream`, each on the head the
+    // host expects; rows -> packs (-> all-gather) -> decide of pass p run on `stream2` behind an event, beside the
+    // trial kernel of pass p + 1; the trial kernel of pass p + 2 is launched behind an event of decide p.
+    bool ah = false;                      // eligible (separable f, chains of 16, nontemporal policy, six buffers) and not switched off (ZF_AHEAD=0)
+    bool ah_unsharded = false;            // ... also without a communicator
+    hipEvent_t ah_evT[4] = {}, ah_evD[4] = {};   // trial kernel done (stream) / decided (stream2), by pass number of the run % 4
+    int ah_run = 0;                       // passes of the current run so far
+    int ah_last_nf = 0;                   // fresh trials of the last one
+    int64_t ah_passes = 0;                // passes launched ahead since creation
     // streaming return_all: caller-owned ring of iterates in HBM (zf_solver_set_history)
     double* hist = nullptr;
     int64_t hist_cap = 0, hist_stride = 0;
 };
 constexpr int ZF_PASS_LOG = 4096;
 constexpr size_t ZF_CTL_SLOT = (sizeof(zf_control) + 255) / 256 * 256;   // bytes in front of the trace ring (zf_solver::ctl_trace)
+constexpr size_t ZF_STATS_OFF = ZF_CTL_SLOT - 32;                         // the run-ahead counters (zf_solver::ra_stats): 8 words in the slot's slack
+static_assert(sizeof(zf_control) <= ZF_STATS_OFF, "the run-ahead counters live behind the control block, inside its slot");
 constexpr size_t ZF_TRACE_BYTES = sizeof(double) * ZF_RING * ZF_TRACE_COLS;
 constexpr size_t ZF_MAIL_BYTES = ZF_CTL_SLOT + ZF_TRACE_BYTES + sizeof(int) * ZF_PASS_LOG;
 
 static int zf_tiles_for(int64_t ntiles);
 static bool zf_fin_kernel_mode();
+// passes ahead at kernel granularity for UNSHARDED grids of more than one round (ZF_AHEAD_UNSHARDED overrides)
+constexpr bool ZF_AHEAD_UNSHARDED_DEFAULT = false;
 
 static int zf_solver_free_all(zf_solver* s) {
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
+    for (int k = 0; k < 4; ++k) {
+        if (s->ah_evT[k]) (void)hipEventDestroy(s->ah_evT[k]);
+        if (s->ah_evD[k]) (void)hipEventDestroy(s->ah_evD[k]);
+    }
     if (s->ra_join) (void)hipEventDestroy(s->ra_join);
     if (s->ra_fork) (void)hipEventDestroy(s->ra_fork);
-    void* ptrs[] = {s->row_part, s->ls_cnt, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->pdesc, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
+    void* ptrs[] = {s->row_part, s->ls_cnt, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
                     s->ra_word, s->ra_flags, s->blk_part2, s->grp_part2, s->fin_cnt2, s->pack2,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
@@ -307,6 +350,40 @@ static void zf_launch_apply_A(zf_solver* s, const zf_control* ctl, zf_ring3 xr, 
         hipLaunchKernelGGL(zf_gemv_rows_kernel<1>, dim3(gr), dim3(ZF_BLOCK), 0, s->stream, ctl, d.A, xr, sout, slot, m, n);
 }
 
+// What two passes in flight need: the second stream (non-blocking, at the highest priority: what runs there - a waiting
+// pass, or the small kernels that finalise and decide a pass beside the next pass's trial kernel - must not queue behind
+// that kernel's workgroups), the events, the done / good word and the per-workgroup flags, a second set of rows / group
+// rows / counters / packs.  Idempotent.
+static hipError_t zf_second_stream(zf_solver* s) {
+    if (s->stream2) return hipSuccess;
+    hipError_t e;
+#define ZF_E(expr)                  \
+    do {                            \
+        e = (expr);                 \
+        if (e != hipSuccess) return e; \
+    } while (0)
+    int lo = 0, hi = 0;
+    ZF_E(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    ZF_E(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, hi));
+    ZF_E(hipEventCreateWithFlags(&s->ra_join, hipEventDisableTiming));
+    ZF_E(hipEventCreateWithFlags(&s->ra_fork, hipEventDisableTiming));
+    for (int k = 0; k < 4; ++k) {
+        ZF_E(hipEventCreateWithFlags(&s->ah_evT[k], hipEventDisableTiming));
+        ZF_E(hipEventCreateWithFlags(&s->ah_evD[k], hipEventDisableTiming));
+    }
+    ZF_E(hipMalloc(&s->ra_word, 128));
+    ZF_E(hipMemsetAsync(s->ra_word, 0, 128, s->stream));
+    ZF_E(hipMalloc(&s->ra_flags, sizeof(unsigned) * (s->max_grid + 32)));
+    ZF_E(hipMemsetAsync(s->ra_flags, 0, sizeof(unsigned) * (s->max_grid + 32), s->stream));
+    ZF_E(hipMalloc(&s->blk_part2, sizeof(double) * ZF_NPART * s->sub * s->max_grid));
+    ZF_E(hipMalloc(&s->grp_part2, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_GROUPS));
+    ZF_E(hipMalloc(&s->fin_cnt2, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2)));
+    ZF_E(hipMemsetAsync(s->fin_cnt2, 0, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2), s->stream));
+    ZF_E(hipMalloc(&s->pack2, sizeof(double) * ZF_PACK_LEN * s->sub));
+#undef ZF_E
+    return hipSuccess;
+}
+
 extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, const zf_options* opt,
                                 void* stream) {
     ZF_REQUIRE(out && desc && opt, "zf_solver_create: null argument");
@@ -342,13 +419,21 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     s->desc = *desc;
     s->opt = *opt;
     if (const char* e = getenv("ZF_SPECULATE")) s->speculate = atoi(e) != 0;
-    if (const char* e = getenv("ZF_PERSIST")) s->persist = atoi(e) != 0;
     if (const char* e = getenv("ZF_MID_CHAINS")) s->mid_chains = atoi(e) != 0;
     if (const char* e = getenv("ZF_SHORT_VIA_GENERAL")) s->short_general = atoi(e) != 0;
-    if (const char* e = getenv("ZF_PERSIST_SPIN_LIMIT")) s->persist_spin = (unsigned)strtoul(e, nullptr, 10);
-    if (const char* e = getenv("ZF_PASS_SEQ_START")) s->pass_seq = atoi(e);   // (tests: the step counter wraps at 0x7ffffff0)
+    if (const char* e = getenv("ZF_PASS_SEQ_START"))   // (tests: the step counter wraps at 0x7ffffff0)
+        s->pass_seq = (int)std::min<long long>(std::max<long long>(atoll(e), 0), 0x7ffffff0LL);
     s->stream = reinterpret_cast<hipStream_t>(stream);
     s->box = !(desc->box_lo == -INFINITY && desc->box_hi == INFINITY);
+    if (opt->accept_mode != ZF_ACCEPT_REFERENCE) {
+        const bool ok = opt->accept_mode == ZF_ACCEPT_RESOLVED && desc->kind == ZF_PROBLEM_DIAG_QUAD_L1;
+        if (!ok) {
+            delete s;
+            return zf_fail(ZF_ERR_ARG, "zf_solver_create: accept_mode must be ZF_ACCEPT_REFERENCE, or ZF_ACCEPT_RESOLVED for "
+                                       "ZF_PROBLEM_DIAG_QUAD_L1 (the element-wise difference f(x+) - f(y) exists for the separable problem only)%s");
+        }
+        s->res = true;
+    }
     const int64_t n = desc->n;
     const int64_t n_pad = (n + 63) & ~int64_t(63);   // keep every ring buffer 512-B aligned
     {   // one workgroup per tile of ZF_TILE_UNITS 16-byte units (zf_kernels_step.h)
@@ -382,34 +467,44 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         if (sub <= 0) sub = ZF_DEFAULT_SUB_ITERS;
         if (sub > ZF_MAX_SUB) sub = ZF_MAX_SUB;
         s->sub = sub >= 16 ? 16 : sub >= 8 ? 8 : sub >= 4 ? 4 : sub >= 2 ? 2 : 1;
+        // (the kernels of ZF_ACCEPT_RESOLVED exist for chains of 16 and single trials, nontemporal policy)
+        if (s->res && s->sub != 16) s->sub = 1;
+        if (s->res) s->nt = true;
     }
     s->ring = s->sub > 1 ? 4 : 3;   // x_k, x_{k-1} + the one or two iterates a pass stores
-    {   // run-ahead passes: chains of 16 on one rank whose grid the device holds at once (the geometry is a function of n)
+    {   // passes that run ahead of their predecessor's decision (chains of 16 of the separable problem), two ways:
+        // * run-ahead passes at WORKGROUP granularity (zf_runahead_kernel): one rank, a grid the device holds at once
+        //   (the geometry is a function of n; what the device holds of the kernel is asked of the runtime), no box (clipping
+        //   costs the chain the registers the entry logic needs - held to two waves per SIMD that variant reloads a spilled
+        //   value inside the tile loop);
+        // * passes AHEAD at KERNEL granularity: every grid, boxes too; for sharded solves through the library's
+        //   communicator (zf_solver_set_comm) and - ZF_AHEAD_UNSHARDED - unsharded grids the other scheme does not take.
         const char* e = getenv("ZF_RUNAHEAD");
         const bool on = e ? atoi(e) != 0 : true;
         const char* te = getenv("ZF_TILES_PER_WG");
         const int t = te ? std::max(1, atoi(te)) : zf_tiles_for(s->ntiles);
         const int64_t grid = (s->ntiles + t - 1) / t;
         if (const char* l = getenv("ZF_RUNAHEAD_SPIN_LIMIT")) s->ra_spin = (unsigned)strtoul(l, nullptr, 10);
-        // (not with a box: clipping costs the chain the registers the entry logic needs - held to two waves per SIMD that
-        //  variant reloads a spilled value inside the tile loop)
-        s->ra = on && desc->kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->sub >= 16 && desc->world == 1 && grid <= 512 && !s->box &&
-                !zf_fin_kernel_mode();
+        const bool chains16 = desc->kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->sub >= 16 && !zf_fin_kernel_mode();
+        s->ra = on && chains16 && desc->world == 1 && !s->box;
+        if (s->ra) {
+            const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt, s->res};
+            s->ra_cap = zf_runahead_capacity(v);
+            s->ra = grid <= s->ra_cap;
+        }
+        const char* ae = getenv("ZF_AHEAD");
+        s->ah = (ae ? atoi(ae) != 0 : true) && chains16 && s->nt;
+        const char* ue = getenv("ZF_AHEAD_UNSHARDED");
+        s->ah_unsharded = s->ah && desc->world == 1 && !s->ra && (ue ? atoi(ue) != 0 : ZF_AHEAD_UNSHARDED_DEFAULT);
     }
-    if (s->ra) {
+    if (s->ra || (s->ah && (desc->world > 1 || s->ah_unsharded))) {
         s->ring = 6;   // a pass never writes what its predecessor reads (zf_free_bufs)
-        ZF_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
-        ZF_TRY(hipEventCreateWithFlags(&s->ra_join, hipEventDisableTiming));
-        ZF_TRY(hipEventCreateWithFlags(&s->ra_fork, hipEventDisableTiming));
-        ZF_TRY(hipMalloc(&s->ra_word, 128));
-        ZF_TRY(hipMemsetAsync(s->ra_word, 0, 128, s->stream));
-        ZF_TRY(hipMalloc(&s->ra_flags, sizeof(unsigned) * (s->max_grid + 32)));
-        ZF_TRY(hipMemsetAsync(s->ra_flags, 0, sizeof(unsigned) * (s->max_grid + 32), s->stream));
-        ZF_TRY(hipMalloc(&s->blk_part2, sizeof(double) * ZF_NPART * s->sub * s->max_grid));
-        ZF_TRY(hipMalloc(&s->grp_part2, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_GROUPS));
-        ZF_TRY(hipMalloc(&s->fin_cnt2, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2)));
-        ZF_TRY(hipMemsetAsync(s->fin_cnt2, 0, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2), s->stream));
-        ZF_TRY(hipMalloc(&s->pack2, sizeof(double) * ZF_PACK_LEN * s->sub));
+        hipError_t e2 = zf_second_stream(s);
+        if (e2 != hipSuccess) {
+            zf_solver_free_all(s);
+            delete s;
+            return zf_fail(ZF_ERR_HIP, "zf_solver_create (second stream): %s", hipGetErrorString(e2));
+        }
     }
     ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * s->ring * n_pad));
     for (int k = 0; k < s->ring; ++k) s->xb[k] = s->xbuf + k * n_pad;
@@ -422,8 +517,6 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     ZF_TRY(hipMalloc(&s->fin_cnt, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2)));
     ZF_TRY(hipMemsetAsync(s->fin_cnt, 0, sizeof(unsigned) * ZF_FIN_CNT_STRIDE * (ZF_FIN_GROUPS + 2), s->stream));
     ZF_TRY(hipMalloc(&s->grp_part, sizeof(double) * ZF_NPART * s->sub * ZF_FIN_GROUPS));
-    ZF_TRY(hipMalloc(&s->pdesc, sizeof(unsigned long long) * 16));
-    ZF_TRY(hipMemsetAsync(s->pdesc, 0, sizeof(unsigned long long) * 16, s->stream));
     // the control block and the trace ring side by side, and a pinned host mirror of both: a poll is ONE DMA into
     // pinned memory (two copies into the caller's pageable arrays cost 34 us on an idle stream, this costs a third)
     //  - and, behind them, the log of pass shapes the kernels keep when timing is on)
@@ -431,6 +524,8 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     s->ctl = reinterpret_cast<zf_control*>(s->ctl_trace);
     s->trace = reinterpret_cast<double*>(s->ctl_trace + ZF_CTL_SLOT);
     s->pass_log = reinterpret_cast<int*>(s->ctl_trace + ZF_CTL_SLOT + ZF_TRACE_BYTES);
+    s->ra_stats = reinterpret_cast<unsigned*>(s->ctl_trace + ZF_STATS_OFF);
+    ZF_TRY(hipMemsetAsync(s->ctl_trace, 0, ZF_CTL_SLOT, s->stream));
     ZF_TRY(hipMemsetAsync(s->pass_log, 0xff, sizeof(int) * ZF_PASS_LOG, s->stream));   // (no launch carries tag 0x7fff + negative sign)
     ZF_TRY(hipHostMalloc(&s->mail, ZF_MAIL_BYTES, hipHostMallocDefault));
     ZF_TRY(hipMalloc(&s->beta_ring, sizeof(double) * ZF_RING));
@@ -512,7 +607,7 @@ enum {
 };
 
 static void zf_launch_trial_kernels(zf_solver* s, const zf_step_args& a, bool grad_inline) {
-    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt, s->res};
     const int mask = s->part_mask;
     const int grid = s->grid;
     hipStream_t st = s->stream;
@@ -608,6 +703,7 @@ static void zf_fill_step_args(const zf_solver* s, zf_step_args& a) {
     a.hist_cap = s->hist_cap > 0 ? s->hist_cap : 1;
     a.hist_stride = s->hist_stride;
     a.fin_mode = 0;
+    a.accept_mode = s->res ? ZF_ACCEPT_RESOLVED : ZF_ACCEPT_REFERENCE;
 }
 
 // Groups of the in-kernel finalisation: up to ZF_FIN_GROUPS workgroups reduce as ONE level (every workgroup its
@@ -644,6 +740,7 @@ static void zf_shadow_advance(zf_control& c) {
     }
     const int nf = zf_fresh_len(&c);
     c.nit += nf;
+    c.total_trials += nf;   // (every trial accepted: zf_pack_stamp of a pass ahead is computed from the shadow)
     if (c.lag + nf > 0) zf_commit_chain(&c, c.cur, c.prev, ring, c.lag + nf);   // (the buffers too: a run-ahead pass is told where to read)
     c.lag = 0;
     if (c.nit >= c.max_iter) c.status = ZF_MAXITER;
@@ -687,7 +784,7 @@ static int zf_predict_parts(zf_solver* s) {
     const int lag = c.lag;
     const int nf = zf_fresh_len(&c);
     int part = zf_pass_part(S, lag, nf);
-    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt, s->res};
     if (part == 3 && (!s->mid_chains || !zf_have_s16_mid(v, nf))) part = 2;
     int mask = part == 3 ? ZF_K_MID : (1 << part);
     s->mid_len = nf;
@@ -722,27 +819,6 @@ static int zf_predict_parts(zf_solver* s) {
     return mask;
 }
 
-// How many of the next `max_steps` steps can run as ONE launch of the persistent kernel: consecutive full chains by
-// the shadow's account, on a grid the device holds at once.  < 2: launch per pass.
-static int zf_persist_run(zf_solver* s, int64_t max_steps) {
-    if (!s->persist || !s->speculate || s->careful || !s->shadow_valid || s->sub < 16 || s->hist || s->comm ||
-        s->desc.world != 1 || s->desc.kind != ZF_PROBLEM_DIAG_QUAD_L1 || zf_fin_kernel_mode() || max_steps < 2)
-        return 0;
-    if (s->persist_cap < 0) {
-        const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
-        s->persist_cap = zf_persist_capacity(v);
-    }
-    if (s->grid > s->persist_cap) return 0;
-    zf_control c = s->shadow;
-    int run = 0;
-    while (run < max_steps && run < 60 && c.status == ZF_RUNNING && c.lag == 0 && c.pend_status == 0 &&
-           zf_fresh_len(&c) == s->sub) {
-        zf_shadow_advance(c);
-        run += 1;
-    }
-    return run;
-}
-
 // `stream` waits for what stream2 holds; the next run-ahead pass starts a new run (it reads the real control block)
 static int zf_ra_join(zf_solver* s) {
     if (s->ra_b_pending) {
@@ -758,7 +834,7 @@ static int zf_ra_join(zf_solver* s) {
 // run it goes to the other stream and starts while that one is still finalising.  `before`: the shadow control block
 // in front of this pass.
 static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& before, hipEvent_t e0, hipEvent_t e1) {
-    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
+    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt, s->res};
     zf_pass_head h;
     h.cur = before.cur;
     h.prev = before.prev;
@@ -792,6 +868,7 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
     }
     a.ra_word = s->ra_word;
     a.ra_flags = s->ra_flags;
+    a.ra_stats = s->ra_stats;
     a.ra_wait = chain ? s->ra_last : 0;
     a.ra_need = chain ? s->ra_last2 : 0;
     a.ra_spin = s->ra_spin;
@@ -816,10 +893,85 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
     return ZF_OK;
 }
 
-static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false) {
+static int zf_gather_packs(zf_solver* s, int64_t packs, hipStream_t st);
+
+// A full or mid chain the shadow predicts exactly, as a pass AHEAD of its predecessor's decision at kernel granularity:
+//   stream  : ... T(p) | T(p+1) | [wait decided(p)] T(p+2) ...        trial kernels back to back, each on the head the
+//                                                                     host expects (zf_trial_kernel<..., AHEAD>)
+//   stream2 : [wait T(p) done] rows -> packs (-> all-gather) -> decide(p) | ...   beside T(p+1)
+// T(p+2) writes the buffers T(p) read; it is launched behind the event of decide(p) and leaves at once unless pass p went
+// as expected (ra_need).  decide(p) checks the control block against the head T(p) ran on: a pass on a head that did not
+// come true is VOID (zf_decide_ahead).  Nothing waits inside a kernel: every grid size, every sharing of the device.
+// `before`: the shadow control block in front of this pass; nf: its fresh trials; part: 0 full chain, 3 mid chain.
+static int zf_launch_ahead(zf_solver* s, zf_step_args a, const zf_control& before, int part, int nf, hipEvent_t e0, hipEvent_t e1) {
+    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt, s->res};
+    zf_pass_head h;
+    h.cur = before.cur;
+    h.prev = before.prev;
+    h.ring = before.ring_size;
+    h.lr = before.lr;
+    h.beta_next = 0.0;
+    h.nit = before.nit;
+    bool chain = s->ra_last != 0 && a.pass_seq > s->ra_last;
+    if (chain) {   // what this pass writes, the pass before it must not be reading (six buffers in ring order: it never is)
+        int f0, f1;
+        zf_free_bufs(h.cur, h.prev, h.ring, &f0, &f1);
+        const zf_pass_head& q = s->ra_last_head;
+        if (f0 == q.cur || f0 == q.prev || f1 == q.cur || f1 == q.prev || h.nit != q.nit + s->ah_last_nf) chain = false;
+    }
+    if (!chain) {
+        int rc = zf_ra_join(s);   // (the solver's stream now comes behind every decide step so far: the block is what this head was read from)
+        if (rc) return rc;
+        s->ah_run = 0;
+    }
+    const int k = s->ah_run;
+    // the pass two before this one has been decided (its inputs are this pass's outputs): kernel-granularity dependency
+    if (k >= 2) ZF_HIP(hipStreamWaitEvent(s->stream, s->ah_evD[(k - 2) & 3], 0));
+    a.ra_word = s->ra_word;
+    a.ra_stats = s->ra_stats;
+    a.ra_need = chain ? s->ra_last2 : 0;
+    a.ra_head = h;
+    a.head_nf = nf;
+    a.head_stamp = zf_pack_stamp(&before);
+    a.fin_mode = 2;
+    a.fin_grid = s->grid;
+    a.blk_part = (k & 1) ? s->blk_part2 : s->blk_part;   // rows of pass p are read on stream2 while T(p+1) writes its own
+    if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
+    if (part == 0) zf_launch_s16_ahead_full(v, s->grid, s->stream, a);
+    else if (!zf_launch_s16_ahead_mid(v, nf, s->grid, s->stream, a)) return zf_fail(ZF_ERR_STATE, "zf_launch_ahead: no mid chain of that length%s");
+    if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+    ZF_HIP(hipEventRecord(s->ah_evT[k & 3], s->stream));
+    ZF_HIP(hipStreamWaitEvent(s->stream2, s->ah_evT[k & 3], 0));
+    // rows -> packs; unsharded: the deciding wave of the same launch decides
+    a.decide = s->comm ? 0 : 1;
+    zf_launch_s16_tail(s->stream2, a);
+    if (s->comm) {
+        int rc = zf_gather_packs(s, s->sub, s->stream2);
+        if (rc) return rc;
+        zf_ahead_check H;
+        H.head = h;
+        H.nf = nf;
+        H.seq = a.pass_seq;
+        hipLaunchKernelGGL(zf_decide_ahead_kernel, dim3(1), dim3(64), 0, s->stream2, s->ctl, s->pack_all, s->trace, s->beta_ring, s->sub, H,
+                           s->ra_word, s->ra_stats, a.pass_log, a.pass_slot, a.pass_tag);
+    }
+    ZF_HIP(hipEventRecord(s->ah_evD[k & 3], s->stream2));
+    s->ra_b_pending = true;
+    s->ra_last2 = chain ? s->ra_last : 0;
+    s->ra_last = a.pass_seq;
+    s->ra_last_head = h;
+    s->ah_last_nf = nf;
+    s->ah_run = k + 1;
+    s->ah_passes += 1;
+    return ZF_OK;
+}
+
+// returns in *done_ahead (if given) whether the step was a pass ahead: tail, exchange and decide are then enqueued too
+static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false, bool* done_ahead = nullptr) {
     const zf_problem_desc& d = s->desc;
     zf_step_args a;
     zf_fill_step_args(s, a);
+    if (done_ahead) *done_ahead = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing && !dry) {
         a.pass_log = s->pass_log;
@@ -860,20 +1012,23 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             a.pass_seq = s->pass_seq;
         }
         zf_control before;
-        const bool have_before = s->ra && !dry && decide_in_launch && !s->comm && s->shadow_valid && !fin_kernel && !s->hist;
+        // passes that run ahead of their predecessor's decision: at workgroup granularity (unsharded one-round grids), or
+        // at kernel granularity (through the library's communicator; ZF_AHEAD_UNSHARDED: other unsharded grids)
+        const bool two_streams = s->stream2 != nullptr && !dry && !fin_kernel && !s->hist && s->shadow_valid;
+        const bool ra_can = two_streams && s->ra && !s->ra_off && decide_in_launch && !s->comm;
+        const bool ah_can = two_streams && s->ah && !ra_can && s->ring >= 6 &&
+                            (s->comm ? !decide_in_launch : (decide_in_launch && s->ah_unsharded && d.world == 1));
+        const bool have_before = ra_can || ah_can;
         if (have_before) before = s->shadow;
         s->part_mask = (dry || !(decide_in_launch || s->comm)) ? ZF_K_ALL : zf_predict_parts(s);
-        // run-ahead: the ONE kernel the shadow predicts is the full chain (not a pair behind a chunk that saw rejections)
-        bool ra_ok = have_before && s->part_mask == ZF_K_FULL && before.status == ZF_RUNNING && before.lag == 0 &&
-                     before.pend_status == 0 && zf_fresh_len(&before) == s->sub && before.ring_size == s->ring;
-        if (ra_ok) {
-            if (s->ra_cap < 0) {
-                const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
-                s->ra_cap = zf_runahead_capacity(v);
-            }
-            ra_ok = s->grid <= s->ra_cap;
-        }
-        if (s->ra && a.pass_seq == 1 && !dry) {   // (the step counter started or wrapped: sequence numbers are compared)
+        // the ONE kernel the shadow predicts (not a pair behind a chunk that saw rejections), nothing lagging
+        const bool exact = have_before && before.status == ZF_RUNNING && before.lag == 0 && before.pend_status == 0 &&
+                           before.ring_size == s->ring;
+        const int nf_before = exact ? zf_fresh_len(&before) : 0;
+        const bool ra_ok = ra_can && exact && s->part_mask == ZF_K_FULL && nf_before == s->sub && s->grid <= s->ra_cap;
+        const bool ah_ok = ah_can && exact && ((s->part_mask == ZF_K_FULL && nf_before == s->sub) ||
+                                               (s->part_mask == ZF_K_MID && nf_before == s->mid_len));
+        if (s->stream2 && a.pass_seq == 1 && !dry) {   // (the step counter started or wrapped: sequence numbers are compared)
             int rc = zf_ra_join(s);
             if (rc) return rc;
             ZF_HIP(hipMemsetAsync(s->ra_word, 0, 128, s->stream));
@@ -888,16 +1043,15 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             s->steps_issued += 1;
             s->kernels_issued += __builtin_popcount(shapes);
         }
-#ifdef ZF_PERSIST_DEBUG
-        if (const char* e = getenv("ZF_PERSIST_DBG")) {
-            if (!s->hist) a.hist = reinterpret_cast<double*>(strtoull(e, nullptr, 0));
-        }
-#endif
         if (ra_ok) {
             int rc = zf_launch_runahead(s, a, before, e0, e1);
             if (rc) return rc;
+        } else if (ah_ok) {
+            int rc = zf_launch_ahead(s, a, before, s->part_mask == ZF_K_FULL ? 0 : 3, nf_before, e0, e1);
+            if (rc) return rc;
+            if (done_ahead) *done_ahead = true;
         } else {
-            if (s->ra) {
+            if (s->stream2) {
                 int rc = zf_ra_join(s);
                 if (rc) return rc;
             }
@@ -1052,64 +1206,6 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
     return ZF_OK;
 }
 
-// `run` >= 2 consecutive full-chain passes (zf_persist_run) as ONE launch of the persistent kernel; the shadow control
-// block moves past all of them.  One event pair and one log slot for the launch: the kernel logs how many passes it ran.
-static int zf_launch_persist(zf_solver* s, int run) {
-    const zf_problem_desc& d = s->desc;
-    zf_step_args a;
-    zf_fill_step_args(s, a);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (s->timing) {
-        a.pass_log = s->pass_log;
-        a.pass_slot = (int)(s->launches % ZF_PASS_LOG);
-        a.pass_tag = (int)(s->launches & 0x7fff) << 16;
-        s->launches += 1;
-        if (s->ev_used == s->ev_pool.size()) {
-            hipEvent_t x, y;
-            ZF_HIP(hipEventCreate(&x));
-            ZF_HIP(hipEventCreate(&y));
-            s->ev_pool.emplace_back(x, y);
-        }
-        e0 = s->ev_pool[s->ev_used].first;
-        e1 = s->ev_pool[s->ev_used].second;
-        s->ev_used++;
-    }
-    a.p0 = d.d;
-    a.p1 = d.c;
-    a.fin_mode = 1;
-    zf_fin_groups(s->grid, &a.fin_gsz, &a.fin_ng);
-    a.grp_part = s->grp_part;
-    a.fin_cnt = s->fin_cnt;
-    a.fin_scale_f = 0.5;
-    a.fin_scale_g = d.lam;
-    a.pack = s->pack_local;
-    a.ctl_rw = s->ctl;
-    a.decide = 1;
-    a.trace = s->trace;
-    if (s->pass_seq >= 0x7ffffff0 - run) {   // (step numbers start over: no descriptor of the old numbering may match a new one)
-        s->pass_seq = 0;
-        ZF_HIP(hipMemsetAsync(s->pdesc, 0, sizeof(unsigned long long) * 16, s->stream));
-    }
-    a.pdesc = s->pdesc;
-    a.pass_seq = s->pass_seq + 1;    // pass p of the launch is step pass_seq + 1 + p
-    s->pass_seq += run;
-    for (int k = 0; k < run; ++k) zf_shadow_advance(s->shadow);
-    s->steps_since_poll += run;
-    s->steps_issued += run;
-    s->kernels_issued += 1;
-    s->persist_launches += 1;
-    s->persist_passes += run;
-    const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt};
-#ifdef ZF_PERSIST_DEBUG
-    if (const char* e = getenv("ZF_PERSIST_DBG")) a.hist = reinterpret_cast<double*>(strtoull(e, nullptr, 0));
-#endif
-    if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
-    zf_launch_s16_persist(v, s->grid, s->stream, a, run, s->persist_spin);
-    if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
-    ZF_HIP(hipGetLastError());
-    return ZF_OK;
-}
-
 // sharded least squares, second half of a trial: s+ = sum over ranks of A_p x_p+ (rank
 // order), f(x+), local pack (f values contributed by rank 0 only: they are replicated)
 extern "C" int zf_solver_enqueue_trial_finish(zf_solver* s) {
@@ -1228,6 +1324,7 @@ extern "C" int zf_solver_enqueue_init(zf_solver* s, const double* x0_dev) {
     c.cur = 0;
     c.nesterov = s->opt.nesterov;
     c.deprecated = s->opt.deprecated;
+    c.accept_mode = s->res ? ZF_ACCEPT_RESOLVED : ZF_ACCEPT_REFERENCE;
     c.need_grad = 1;
     c.world = d.world;
     c.ring_size = s->ring;
@@ -1301,6 +1398,7 @@ extern "C" int zf_solver_restore(zf_solver* s, const double* xk_dev, const doubl
     c.max_backtrack = s->opt.max_backtrack_iter;
     c.nesterov = s->opt.nesterov;
     c.deprecated = s->opt.deprecated;
+    c.accept_mode = s->res ? ZF_ACCEPT_RESOLVED : ZF_ACCEPT_REFERENCE;   // (this solver's: the test a resumed solve runs is the resuming caller's choice)
     c.cur = 0;
     c.prev = s->ring - 1;
     c.ring_size = s->ring;
@@ -1414,6 +1512,7 @@ extern "C" int zf_solver_set_history(zf_solver* s, double* hist_dev, int64_t cap
     ZF_REQUIRE(stride >= s->desc.n && stride % 64 == 0 && zf_aligned16(hist_dev),
                "zf_solver_set_history: stride must be >= n and a multiple of 64 doubles, the ring 16-byte aligned");
     ZF_REQUIRE(s->sub == 1 || s->sub == 8, "zf_solver_set_history: chain length must be 1 or 8");
+    ZF_REQUIRE(!s->res || s->sub == 1, "zf_solver_set_history: with ZF_ACCEPT_RESOLVED the recording kernels exist for single trials only (sub_iters 1)");
     ZF_REQUIRE(cap_slots > 2 * s->sub, "zf_solver_set_history: the ring must hold more than two chains");
     s->hist = hist_dev;
     s->hist_cap = cap_slots;
@@ -1426,14 +1525,20 @@ extern "C" int zf_solver_launch_counts(zf_solver* s, int64_t* out, int64_t count
     ZF_REQUIRE(count >= 2, "zf_solver_launch_counts: the output holds fewer than 2 values");
     out[0] = s->steps_issued;
     out[1] = s->kernels_issued;
-    if (count >= 4) {   // (ABI 5) launches of the persistent multi-pass kernel and the steps they covered
-        out[2] = s->persist_launches;
-        out[3] = s->persist_passes;
-    }
+    if (count >= 4) out[2] = out[3] = 0;   // (ABI 5: the withdrawn multi-pass kernel's counts)
     if (count >= 6) {   // run-ahead passes launched, and those of them launched behind a pass still in flight
         out[4] = s->ra_passes;
         out[5] = s->ra_ahead;
     }
+    if (count >= 8) {   // (ABI 6) as of the last poll: waits of run-ahead passes that gave up; void run-ahead passes
+        out[6] = s->ra_timeouts;
+        out[7] = s->ra_voids;
+    }
+    if (count >= 10) {  // (ABI 6) passes launched ahead at kernel granularity; of them void, as of the last poll
+        out[8] = s->ah_passes;
+        out[9] = s->ah_voids;
+    }
+    if (count >= 11) out[10] = s->ra_off ? 1 : 0;   // run-ahead passes were switched off for this solver after a wait gave up
     return ZF_OK;
 }
 
@@ -1482,11 +1587,30 @@ extern "C" int zf_solver_set_comm(zf_solver* s, zf_comm* comm) {
     if (rc) return rc;
     ZF_REQUIRE(rank == s->desc.rank && world == s->desc.world, "zf_solver_set_comm: rank / world differ from the problem descriptor");
     s->comm = comm;
+    // passes ahead of their predecessor's decision (zf_launch_ahead) need six iterate buffers and the second stream: a
+    // one-rank solver was created without knowing that a communicator would follow (before the initialisation only)
+    if (s->ah && !s->initialised && (s->ring < 6 || !s->stream2)) {
+        ZF_HIP(hipStreamSynchronize(s->stream));
+        if (s->ring < 6) {
+            const int64_t n_pad = (s->desc.n + 63) & ~int64_t(63);
+            double* nb = nullptr;
+            if (hipMalloc(&nb, sizeof(double) * 6 * n_pad) == hipSuccess) {
+                (void)hipFree(s->xbuf);
+                s->xbuf = nb;
+                s->ring = 6;
+                for (int k = 0; k < s->ring; ++k) s->xb[k] = s->xbuf + k * n_pad;
+            } else {
+                (void)hipGetLastError();   // (no room for two more iterates: the solve runs one pass at a time)
+            }
+        }
+        if (s->ring >= 6) ZF_HIP(zf_second_stream(s));
+    }
     return ZF_OK;
 }
 
-static int zf_gather_packs(zf_solver* s, int64_t packs) {
-    if (!s->timing) return zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, s->stream);
+static int zf_gather_packs(zf_solver* s, int64_t packs, hipStream_t st) {
+    if (!st) st = s->stream;
+    if (!s->timing) return zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, st);
     // timed: from "this rank's packs are ready" to "the gathered packs are here" on this rank's stream - the
     // collective itself plus the wait for the slowest rank (zf_solver_exchange_stats)
     if (s->xev_used == s->xev_pool.size()) {
@@ -1496,9 +1620,9 @@ static int zf_gather_packs(zf_solver* s, int64_t packs) {
         s->xev_pool.emplace_back(x, y);
     }
     const auto& ev = s->xev_pool[s->xev_used++];
-    ZF_HIP(hipEventRecord(ev.first, s->stream));
-    const int rc = zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, s->stream);
-    ZF_HIP(hipEventRecord(ev.second, s->stream));
+    ZF_HIP(hipEventRecord(ev.first, st));
+    const int rc = zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, st);
+    ZF_HIP(hipEventRecord(ev.second, st));
     return rc;
 }
 static int zf_gather_svec(zf_solver* s, bool at_init = false) {
@@ -1520,7 +1644,7 @@ extern "C" int zf_solver_enqueue_init_all(zf_solver* s, const double* x0_dev) {
         if ((rc = zf_solver_enqueue_init_finish(s))) return rc;
         // the init pack sits at the head of this rank's pack buffer; ranks are sub x ZF_PACK_LEN apart in
         // pack_all (zf_init_commit_kernel's stride), so the whole buffer is gathered
-        if ((rc = zf_gather_packs(s, s->sub))) return rc;
+        if ((rc = zf_gather_packs(s, s->sub, nullptr))) return rc;
     } else {
         ZF_REQUIRE(s->desc.world == 1, "zf_solver_enqueue_init_all: world > 1 needs zf_solver_set_comm");
     }
@@ -1535,28 +1659,23 @@ extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
     for (int64_t k = 0; k < steps; ++k) {
         int rc;
         if (!s->comm) {
-            // full chains ahead on a grid the device holds at once: several passes in one launch
-            const int run = zf_persist_run(s, steps - k);
-            if (run >= 2) {
-                if (s->ra && (rc = zf_ra_join(s))) return rc;
-                if ((rc = zf_launch_persist(s, run))) return rc;
-                k += run - 1;
-                continue;
-            }
             if ((rc = zf_launch_trial(s, true))) return rc;
             continue;
         }
         // sharded step: trial -> (C2) -> finish -> C1 -> decide; every rank runs the same decide on the
-        // same gathered packs, so nothing else is exchanged
-        if ((rc = zf_launch_trial(s, false))) return rc;
+        // same gathered packs, so nothing else is exchanged.  A pass AHEAD (zf_launch_ahead) has enqueued all of it
+        // already: finalisation, exchange and decide on the second stream, beside the next pass's trial kernel.
+        bool ahead = false;
+        if ((rc = zf_launch_trial(s, false, false, &ahead))) return rc;
+        if (ahead) continue;
         if ((rc = zf_gather_svec(s))) return rc;
         if ((rc = zf_solver_enqueue_trial_finish(s))) return rc;
-        if ((rc = zf_gather_packs(s, s->sub))) return rc;
+        if ((rc = zf_gather_packs(s, s->sub, nullptr))) return rc;
         if ((rc = zf_solver_enqueue_decide(s))) return rc;
     }
     // everything enqueued on the solver's stream after this call (a poll's copy, a snapshot, another solver's work on
     // the caller's stream) comes behind the passes on the second stream as well
-    if (s->ra) return zf_ra_join(s);
+    if (s->stream2) return zf_ra_join(s);
     return ZF_OK;
 }
 
@@ -1652,6 +1771,7 @@ static int zf_collect_timing(zf_solver* s, bool log_in_mail = false) {
             // the launch found the solve finished and exited: the slot still holds what an earlier launch wrote
             if (entry < 0 || (entry >> 16) != (int)(launch & 0x7fff)) continue;
             const int shape = entry & 0xffff;   // zf_log_shape: fresh trials | lagging iterations << 5 | passes << 10
+            if (shape == 0) continue;           // a pass that ran ahead and turned out VOID: the launch ran, its pass does not count
             if (s->records.size() < 65536) s->records.emplace_back(shape, ms);
             const int nf = shape & 31, lag = (shape >> 5) & 31, cnt = (shape >> 10) & 63;
             if (lag == 0 && nf == s->sub) {
@@ -1723,7 +1843,7 @@ extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_by
                "zf_solver_poll: trace_bytes is smaller than ZF_RING * ZF_TRACE_COLS doubles");
     const size_t trace_len = ZF_TRACE_BYTES;
     const bool with_log = s->ev_used > 0;   // (events were recorded: the kernels logged their pass shapes)
-    const size_t want = with_log ? ZF_MAIL_BYTES : trace_host ? ZF_CTL_SLOT + trace_len : sizeof(zf_control);
+    const size_t want = with_log ? ZF_MAIL_BYTES : trace_host ? ZF_CTL_SLOT + trace_len : ZF_CTL_SLOT;
     ZF_HIP(hipMemcpyAsync(s->mail, s->ctl_trace, want, hipMemcpyDeviceToHost, s->stream));
     ZF_HIP(hipStreamSynchronize(s->stream));
     memcpy(ctl_host, s->mail, sizeof(zf_control));
@@ -1735,6 +1855,14 @@ extern "C" int zf_solver_poll(zf_solver* s, zf_control* ctl_host, int64_t ctl_by
         s->shadow = *ctl_host;
         s->shadow_valid = true;
         s->steps_since_poll = 0;
+        // what the passes that ran ahead report (zf_solver::ra_stats).  A wait that gave up means the device does not hold
+        // two passes of this solver at once - it is being shared - and every further one would cost its whole limit again:
+        // no more run-ahead passes for this solver (passes ahead at kernel granularity never wait and go on)
+        const unsigned* st = reinterpret_cast<const unsigned*>(s->mail + ZF_STATS_OFF);
+        s->ra_timeouts = st[0];
+        s->ra_voids = st[1];
+        s->ah_voids = st[2];
+        if (s->ra_timeouts > 0) s->ra_off = true;
     }
     return zf_collect_timing(s, with_log);
 }

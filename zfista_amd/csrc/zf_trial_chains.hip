@@ -2,6 +2,10 @@
 #include "zf_trial_launch.h"
 
 void zf_launch_chain(const zf_trial_sel& v, int S, int part, int grid, hipStream_t st, const zf_step_args& a) {
+    if (v.res) {   // (single trials only: zf_solver_create)
+        if (S == 1 && part == 0) zf_launch_res_single(v, false, grid, st, a);
+        return;
+    }
 #define CALL8_0(N, B, T) ZF_LAUNCH_TRIAL(true, N, B, T, 8, false, 0, 0)
 #define CALL8_1(N, B, T) ZF_LAUNCH_TRIAL(true, N, B, T, 8, false, 1, 0)
 #define CALL4_0(N, B, T) ZF_LAUNCH_TRIAL(true, N, B, T, 4, false, 0, 0)

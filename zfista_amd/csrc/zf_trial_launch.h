@@ -8,19 +8,23 @@
 
 struct zf_trial_sel {
     bool nest, box, nt;
+    bool res = false;   // ZF_ACCEPT_RESOLVED: the kernels that accumulate f(x+) - f(y) (zf_elem_diag<..., RES>; nontemporal
+                        // policy, chains of 16 and single trials only - zf_solver_create holds such a solver to that)
 };
 
 // chains of 16 (the default): the full chain (PART 0), the short bodies (PART 1), the general body (PART 2),
 // the branch-free mid chains (PART 3, `len` trials; false: no such kernel for this variant - the caller launches the
-// general body instead) and the persistent multi-pass kernel of the full chain
+// general body instead)
 void zf_launch_s16_full(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
 void zf_launch_s16_short(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
 void zf_launch_s16_general(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
 bool zf_launch_s16_mid(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a);
 bool zf_have_s16_mid(const zf_trial_sel& v, int len);
-void zf_launch_s16_persist(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a, int npass, unsigned spin_limit);
-// workgroups of the persistent kernel the device holds at once (0: could not be determined)
-int zf_persist_capacity(const zf_trial_sel& v);
+// passes AHEAD at kernel granularity (nontemporal policy): the full chain and the mid chains on the head the host expects,
+// rows stored plainly; zf_launch_s16_tail = rows -> packs (-> decide) of such a pass (zf_tail_kernel)
+void zf_launch_s16_ahead_full(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
+bool zf_launch_s16_ahead_mid(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a);
+void zf_launch_s16_tail(hipStream_t st, const zf_step_args& a);
 // the run-ahead full chain (zf_runahead_kernel) and the workgroups of it the device holds at once
 void zf_launch_s16_runahead(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
 int zf_runahead_capacity(const zf_trial_sel& v);
@@ -45,3 +49,22 @@ void zf_launch_vec(const zf_trial_sel& v, int grid, hipStream_t st, const zf_ste
     } while (0)
 #define ZF_LAUNCH_TRIAL(GI, N, B, T, S, HIST, PART, L) \
     hipLaunchKernelGGL((zf_trial_kernel<GI, N, B, T, S, HIST, PART, L>), dim3(grid), dim3(ZF_BLOCK), 0, st, a)
+// the same kernel of a ZF_ACCEPT_RESOLVED solver (separable problem, nontemporal policy); AH: the pass-ahead variant
+#define ZF_LAUNCH_TRIAL_RES(N, B, S, HIST, PART, L, AH) \
+    hipLaunchKernelGGL((zf_trial_kernel<true, N, B, true, S, HIST, PART, L, AH, true>), dim3(grid), dim3(ZF_BLOCK), 0, st, a)
+#define ZF_SEL_NB(v, CALL)                                \
+    do {                                                  \
+        if ((v).nest && (v).box) { CALL(true, true); }    \
+        else if ((v).nest) { CALL(true, false); }         \
+        else if ((v).box) { CALL(false, true); }          \
+        else { CALL(false, false); }                      \
+    } while (0)
+
+// ZF_ACCEPT_RESOLVED solvers (v.res): every launcher above forwards to these (zf_trial_res_*.hip)
+void zf_launch_res_full(const zf_trial_sel& v, bool ahead, int grid, hipStream_t st, const zf_step_args& a);
+void zf_launch_res_runahead(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
+int zf_res_runahead_capacity(const zf_trial_sel& v);
+void zf_launch_res_short(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
+void zf_launch_res_general(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
+bool zf_launch_res_mid(const zf_trial_sel& v, bool ahead, int len, int grid, hipStream_t st, const zf_step_args& a);
+void zf_launch_res_single(const zf_trial_sel& v, bool hist, int grid, hipStream_t st, const zf_step_args& a);

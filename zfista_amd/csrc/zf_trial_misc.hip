@@ -2,6 +2,10 @@
 #include "zf_trial_launch.h"
 
 void zf_launch_hist(const zf_trial_sel& v, bool grad_inline, int S, int part, int grid, hipStream_t st, const zf_step_args& a) {
+    if (v.res) {   // (separable problem, single trials only: zf_solver_create)
+        if (grad_inline && S == 1 && part == 0) zf_launch_res_single(v, true, grid, st, a);
+        return;
+    }
 #define H(GI, SS, PART)                                                          \
     do {                                                                         \
         if (v.nest && v.box) ZF_LAUNCH_TRIAL(GI, true, true, true, SS, true, PART, 0);        \

@@ -2,6 +2,7 @@
 #include "zf_trial_launch.h"
 
 void zf_launch_s16_general(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a) {
+    if (v.res) return zf_launch_res_general(v, grid, st, a);
 #define CALL(N, B, T) ZF_LAUNCH_TRIAL(true, N, B, T, 16, false, 2, 0)
     ZF_SEL_NBT(v, CALL);
 #undef CALL

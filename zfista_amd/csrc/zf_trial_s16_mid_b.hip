@@ -9,6 +9,7 @@ bool zf_have_s16_mid(const zf_trial_sel& v, int len) {
 
 bool zf_launch_s16_mid(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a) {
     if (!zf_have_s16_mid(v, len)) return false;
+    if (v.res) return zf_launch_res_mid(v, false, len, grid, st, a);
     if (len <= 12) return zf_launch_s16_mid_a(v.nest, len, grid, st, a);
 #define MID(LEN)                                                          \
     case LEN:                                                             \

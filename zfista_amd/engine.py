@@ -273,18 +273,24 @@ class DeviceSolver:
         _lib.check(self.lib.zf_solver_launch_counts(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
         return int(out[0]), int(out[1])
 
-    def persist_counts(self):
-        """(launches of the persistent multi-pass kernel, steps those launches covered) since the solver was created."""
-        out = np.zeros(4, dtype=np.int64)
-        _lib.check(self.lib.zf_solver_launch_counts(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
-        return int(out[2]), int(out[3])
-
     def runahead_counts(self):
         """(run-ahead passes launched, those of them launched while their predecessor was still in flight) since the
         solver was created (zf_runahead_kernel: consecutive full chains on two streams)."""
         out = np.zeros(6, dtype=np.int64)
         _lib.check(self.lib.zf_solver_launch_counts(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
         return int(out[4]), int(out[5])
+
+    def ahead_report(self):
+        """What the passes that ran ahead of their predecessor's decision report, as of the last poll: a dict with
+        ``runahead`` (run-ahead passes launched), ``runahead_overlapped`` (of them behind a pass still in flight),
+        ``timeouts`` (waits that gave up: the device did not hold two passes of this solver at once), ``void`` (run-ahead
+        passes that did not count), ``runahead_off`` (the solver stopped launching them after a wait gave up),
+        ``ahead`` / ``ahead_void`` (passes ahead at kernel granularity: sharded solves through the library's
+        communicator)."""
+        out = np.zeros(11, dtype=np.int64)
+        _lib.check(self.lib.zf_solver_launch_counts(self.handle, C.c_void_p(_lib.ptr(out)), out.size))
+        return dict(runahead=int(out[4]), runahead_overlapped=int(out[5]), timeouts=int(out[6]), void=int(out[7]),
+                    ahead=int(out[8]), ahead_void=int(out[9]), runahead_off=bool(out[10]))
 
     def pass_stats_ex(self):
         """pass_stats() plus (fresh trials, replayed iterations) the other passes carried in total."""
@@ -293,8 +299,8 @@ class DeviceSolver:
         return (out[0], int(out[1])), (out[2], int(out[3])), (int(out[4]), int(out[5]))
 
     def pass_records(self, cap=65536):
-        """[(lagging iterations, fresh trials, passes of a persistent launch, ms)] of every timed launch that ran a pass
-        since the last call (timing on)."""
+        """[(lagging iterations, fresh trials, 0, ms)] of every timed launch that ran a pass since the last call (timing on;
+        passes that ran ahead and turned out void are left out)."""
         out = np.zeros(2 * cap)
         cnt = C.c_int64(0)
         _lib.check(self.lib.zf_solver_pass_records(self.handle, C.c_void_p(_lib.ptr(out)), cap, C.byref(cnt)))

@@ -228,7 +228,7 @@ class MoEngine:
         (zf_mo_solve_dual_device, dual_solver="device").  ``f_y`` None: take f(y) from the device
         (after prepare_async()).  Returns (weight, fun, nit, err, f_x, g_x, f_y)
         with x+ left in its buffer (f_x is None when f is a host callback), or None when it was not attempted (non-finite start, sharded x,
-        m > 3): the caller continues with solve_dual() / the reference's calls and recover()."""
+        m > 8): the caller continues with solve_dual() / the reference's calls and recover()."""
         # (once per trial on the solver's critical path: buffers and their ctypes pointers are kept)
         st = self.__dict__.get("_solve_bufs")
         if st is None:
@@ -276,7 +276,7 @@ class MoEngine:
     # -- trials launched ahead of their predecessor's result (zf_mo_trial_launch / _wait) -------------
     def trial_launch(self, lr, F_old, deprecated, w0, tol, max_iter, accept_tol, decay_is_one, gated):
         """Enqueue one trial (after prepare_async()); returns a ticket, or None when this problem has no
-        device trial (sharded x, m > 3).  ``gated``: the trial runs only if the one launched before it
+        device trial (sharded x, m > 8).  ``gated``: the trial runs only if the one launched before it
         turns out accepted, and takes F(x_k) from that trial's F(x+) on the device (``F_old`` None)."""
         st = self.__dict__.get("_launch_bufs")
         if st is None:

@@ -84,6 +84,7 @@ class DiagQuadL1(NativeProblem):
     """
 
     kind = _lib.ZF_PROBLEM_DIAG_QUAD_L1
+    separable = True   # f is a sum over elements: chains of trials per pass, and acceptance="resolved"
 
     def __init__(self, d, c, lam, bounds=None, group=None):
         self.d = _to_device(d, "d")

@@ -93,7 +93,7 @@ def minimize_proximal_gradient(
     lr=1, tol=1e-5, tol_internal=1e-12, max_iter=1000000, max_iter_internal=100000,
     max_backtrack_iter=100, warm_start=False, decay_rate=0.5, nesterov=False,
     nesterov_ratio=(0, 0.25), return_all=False, verbose=False, deprecated=False,
-    *, dual_solver=None, sub_iters=None,
+    *, dual_solver=None, sub_iters=None, acceptance=None,
 ):
     """Minimise F = f + g by the (accelerated) proximal gradient method on MI355X.
 
@@ -113,6 +113,16 @@ def minimize_proximal_gradient(
     sub_iters : {1, 2, 4, 8, 16}, separable single-objective problems only: iterations chained per
         pass over the data (temporal blocking).  Results do not depend on it.  Default 16 (8 with
         ``return_all``).
+    acceptance : {"reference", "resolved"}.  "reference" (default) evaluates the sufficient-decrease test as
+        zfista/proximal_gradient.py:303 writes it, ``F(x+) - F(x_k) <= fun + tol_internal`` - two differences of
+        O(|F|) numbers, below double-precision resolution once ``|x+ - y|^2 << ulp(F)``: at n = 1e8 trials are then
+        rejected by rounding noise (and a long solve ends in "Backtracking failed") exactly as the reference's would.
+        "resolved" (separable single-objective problems, ``DiagQuadL1``; other problems raise) evaluates the same
+        inequality with F(x_k) and g(x+) cancelled and ``f(x+) - f(y)`` accumulated element by element:
+        ``[f(x+) - f(y)] - <grad f(y), x+ - y> - |x+ - y|^2 / 2 / lr <= tol_internal``.  Where the reference's
+        evaluation resolves the test both take the same decisions; iterates of accepted trials are the same
+        arithmetic.  The result says which one ran (field ``acceptance``).  Only when the keyword is not given,
+        ZF_ACCEPT in the environment may override the default.
     """
     if deprecated:
         warn(_MSG_DEPRECATED, stacklevel=2)
@@ -125,8 +135,17 @@ def minimize_proximal_gradient(
         dual_solver = dual_solver or "scipy"
     if dual_solver not in ("scipy", "native", "device"):
         raise ValueError(f"dual_solver must be 'scipy', 'native' or 'device', got {dual_solver!r}")
+    accept_from_env = False
+    if acceptance is None:
+        import os
+
+        acceptance = os.environ.get("ZF_ACCEPT")
+        accept_from_env = acceptance is not None
+        acceptance = acceptance or "reference"
+    if acceptance not in ("reference", "resolved"):
+        raise ValueError(f"acceptance must be 'reference' or 'resolved', got {acceptance!r}")
     opts = dict(
-        dual_solver=dual_solver, sub_iters=int(sub_iters or 0),
+        dual_solver=dual_solver, sub_iters=int(sub_iters or 0), acceptance=acceptance,
         lr=lr, tol=tol, tol_internal=tol_internal, max_iter=max_iter,
         max_iter_internal=max_iter_internal, max_backtrack_iter=max_backtrack_iter,
         warm_start=warm_start, decay_rate=decay_rate, nesterov=nesterov,
@@ -137,6 +156,12 @@ def minimize_proximal_gradient(
     if native is not None and not (lr > 0 and decay_rate > 0 and native.lam >= 0):
         native = None   # the fused kernels assume a threshold lam * lr >= 0; the callback path does not
     native_multi = match_native_multi(f, g, jac_f, prox_wsum_g)
+    if acceptance == "resolved" and not (native is not None and getattr(native, "separable", False)):
+        if accept_from_env:
+            opts["acceptance"] = acceptance = "reference"   # (the environment asks for what this problem has not: the reference's test runs)
+        else:
+            raise ValueError("acceptance='resolved' needs a separable native problem (zfista_amd.problems.DiagQuadL1): the "
+                             "element-wise difference f(x+) - f(y) is formed inside its fused kernels")
     if native is not None:
         res, status = _solve_native(native, x0, opts)
     elif _is_device_tensor(x0) and native_multi is None:
@@ -149,6 +174,8 @@ def minimize_proximal_gradient(
         res, status = _solve_generic(f, g, jac_f, prox_wsum_g, x0, opts)
     if from_env:
         res["dual_solver"] = f"{dual_solver} (from the environment: ZF_DUAL_SOLVER)"
+    if acceptance != "reference":
+        res["acceptance"] = acceptance + (" (from the environment: ZF_ACCEPT)" if accept_from_env else "")
     overrides = _lib.env_overrides()
     if overrides:
         # run-time switches that select other kernels, launch geometries or numerics paths: a result produced under
@@ -175,10 +202,12 @@ class NativeRun:
             decay_rate=float(opts["decay_rate"]), max_iter=int(opts["max_iter"]),
             max_backtrack_iter=int(opts["max_backtrack_iter"]),
             nesterov=int(bool(opts["nesterov"])), deprecated=int(bool(opts["deprecated"])),
+            accept_mode=(_lib.ZF_ACCEPT_RESOLVED if opts.get("acceptance") == "resolved" else _lib.ZF_ACCEPT_REFERENCE),
             # return_all records every iterate into a ring in HBM as the trial computes it
             # (zf_solver_set_history): recording kernels exist for chains of 8 and of 1
             sub_iters=(int(opts.get("sub_iters", 0) or 0) if not opts.get("return_all")
-                       else (1 if (int(opts.get("sub_iters", 0) or 0) in (1, 2, 4) or solver_factory is not None)
+                       else (1 if (int(opts.get("sub_iters", 0) or 0) in (1, 2, 4) or solver_factory is not None
+                                   or opts.get("acceptance") == "resolved")   # (its recording kernels: single trials)
                              else 8)),   # (test stand-ins have no history ring: one iterate per pass)
         )
         if solver_factory is not None:
@@ -404,6 +433,14 @@ def _solve_native(problem, x0, opts, solver_factory=None):
         res.status, res.message, res.success = 0, _MSG_MAXITER, False
     res.update(x=x, fun=F, nit=int(ctl.nit), allvecs=allvecs, allfuns=allfuns, allerrs=allerrs,
                time=time.time() - t0)
+    report = getattr(run.solver, "ahead_report", None)
+    if report is not None:
+        rep = report()
+        if rep["timeouts"]:
+            # passes that ran ahead of their predecessor's decision waited in vain (the device was shared): the solver
+            # went back to one launch per pass - same result, and the result says so
+            res["runahead"] = (f"switched off after {rep['timeouts']} wait(s) of run-ahead passes gave up "
+                               f"({rep['void']} void passes)")
     run.solver.close()
     return res, run.status
 
