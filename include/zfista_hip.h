@@ -119,7 +119,9 @@ typedef struct zf_control {
  * below double-precision resolution once |x+ - y|^2 << ulp(F): at n = 1e8 trials are rejected by rounding noise from
  * iteration ~90 on).  ZF_ACCEPT_RESOLVED (opt-in; separable problems) evaluates the second form with f(x+) - f(y)
  * accumulated element by element (pack slot 7), so the test resolves ~1e-16 of the step, not of F; f(x+) is then reported
- * as f(y) + [f(x+) - f(y)].  Iterates of accepted trials are the same arithmetic either way. */
+ * as f(y) + [f(x+) - f(y)].  Iterates of accepted trials are the same arithmetic either way.  One difference by design:
+ * with F(x_k) = inf (x_k outside the box) the reference's expression accepts every trial (-inf <= -inf); the resolved form
+ * still tests the smooth part. */
 #define ZF_ACCEPT_REFERENCE 0
 #define ZF_ACCEPT_RESOLVED 1
 

@@ -93,3 +93,19 @@ extern "C" double dual_native_min_eig(int m, const double* Q) {
         for (int j = 0; j < m; ++j) A[i][j] = Q[i * m + j];
     return zf_dual::min_eigenvalue(m, A);
 }
+
+// The line-search acceptance rule alone (zf_dual::machine<3>::ls_accept) on a hand-built state: value `fun` and slope
+// along `d` at the base point, value f_t and gradient g_t at step length t.  For the test of the value guard.
+extern "C" int dual_native_ls_accept(double fun, double slope, const double* d, double f_t, const double* g_t, double t) {
+    zf_dual::machine<3> S;
+    const double w0[3] = {1.0 / 3, 1.0 / 3, 1.0 / 3};
+    S.start(w0, 1e-12, 10);
+    S.fun = fun;
+    S.slope = slope;
+    double g[3];
+    for (int i = 0; i < 3; ++i) {
+        S.d[i] = d[i];
+        g[i] = g_t[i];
+    }
+    return S.ls_accept(f_t, g, t) ? 1 : 0;
+}

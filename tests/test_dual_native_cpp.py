@@ -102,3 +102,28 @@ def test_exact_hessian_mode_reaches_the_same_optimum_in_fewer_evaluations(lib, m
     np.testing.assert_allclose(w, w_probe, rtol=0, atol=1e-8)
     assert abs(fun.value - f_probe) <= 1e-12 * max(1.0, abs(f_probe))
     assert evals.value < evals_probe and batches.value <= evals.value
+
+
+def test_the_value_guard_of_the_slope_branch_binds(lib):
+    """The advisor's finding of round 4: as first written the guard of the approximate-Wolfe branch held for every
+    input.  Now: a rise of the value that the convexity of the dual allows (df <= 2 t max(phi'(t), 0): an overshoot
+    across a kink, which the slope window alone lets pass) is REJECTED; a rise the gradients cannot explain (the
+    reference's composed prox: value up, slope still negative) is waived, as SciPy's gradient-driven search does;
+    rounding-size rises leave the decision to the slopes; Armijo steps pass as ever."""
+    lib.dual_native_ls_accept.restype = C.c_int
+    lib.dual_native_ls_accept.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_double]
+    d = np.array([1.0, -0.5, -0.5])
+
+    def accept(fun, slope, f_t, dphi, t=1.0):
+        g = dphi * d / (d @ d)          # (mean-free already: (g - mean g) . d = dphi)
+        return bool(lib.dual_native_ls_accept(fun, slope, d.ctypes.data_as(C.c_void_p), f_t, np.ascontiguousarray(g).ctypes.data_as(C.c_void_p), t))
+
+    fun, slope = 100.0, -1.0
+    assert accept(fun, slope, fun - 0.3, -0.2)                 # Armijo: the value fell by more than 1e-4 t |slope|
+    assert accept(fun, slope, fun + 1e-9, -0.5)                # within the noise of the values: the slopes decide (window holds)
+    assert not accept(fun, slope, fun + 1e-9, -0.95)           # ... and the window does not hold (slope has hardly shrunk)
+    assert not accept(fun, slope, fun + 0.3, 0.6)              # a genuine overshoot: 0.3 <= 2 * 0.6 - rejected although the window holds
+    assert not accept(fun, slope, fun + 1.0, 0.9)
+    assert accept(fun, slope, fun + 0.3, -0.5)                 # the value rises, the slope is still negative: contradiction - waived
+    assert accept(fun, slope, fun + 3.0, 0.6)                  # a rise no convex function with these slopes can show: waived
+    assert not accept(fun, slope, fun + 3.0, 1.5)              # (waived, but the slope overshot the window)

@@ -9,42 +9,53 @@
 // (zf_kernels_gemv.h); everything else of a trial - the residual at y by linearity from the cached A x_k,
 // A x_{k-1}, the fused prox step with the gradient vector in HBM, the decide pass - is that path's.
 //
-// Both kernels work on 32 x 8 output tiles (one per workgroup: 256 workgroups at 256 x 256) staged in LDS
-// with a halo of K / 2; the inverse Haar level is folded into the tile load of zf_op_apply_kernel and the
-// forward level into the epilogue of zf_op_adjoint_kernel, so the image never exists in memory.
-// Arithmetic: the Haar sums in NumPy's left-to-right order ((a + b) + c) + d, then / 2; the correlation
-// accumulates its K^2 products row by row with plain multiply-adds (-ffp-contract=off: no FMA) - SciPy's
-// own summation order is not specified, parity is to the solver's 1e-10, not bit for bit.
+// Round 5 rewrite.  Round 4's kernels computed one output pixel per thread with 2 K^2 scalar LDS reads (tile value AND
+// tap) - 162 ds_read_b64 per 16 bytes of HBM traffic at 9 x 9: at 4096 x 4096 an iteration took 2.6 ms where its bytes
+// need 0.2 (profiles/r05_operator_*).  Now:
+//   * a workgroup owns a 64 x TY output tile (TY = 32; 8 for images of few tiles) staged in LDS with its halo; the
+//     inverse Haar level is folded into the tile load of the apply kernel - one 2 x 2 block per thread: four coefficient
+//     loads, four pixels - and the forward level into the epilogue of the adjoint kernel: the image never exists in memory;
+//   * a thread computes R = TY / 4 vertically adjacent outputs of one column from a sliding window in REGISTERS:
+//     lanes run along x, so every LDS read is conflict-free, and each value read serves up to R outputs;
+//   * SEPARABLE kernels (rank 1: k = u v^T - the notebook's Gaussian window is one; detected when the solver is
+//     created): a horizontal pass (8 outputs per thread from a window of 8 + K - 1 values) into a second LDS array,
+//     then the vertical pass: 2 K multiply-adds per pixel instead of K^2;
+//   * general kernels: K (R + K - 1) LDS reads for R K^2 multiply-adds per thread, the taps come through the scalar
+//     cache (uniform addresses: s_load), not from LDS;
+//   * K is a template parameter (3 .. 15, odd; other sizes are zero-padded by the host): every window index is a constant.
+// Arithmetic: the Haar sums in NumPy's left-to-right order ((a + b) + c) + d, then / 2; the correlation accumulates with
+// fused multiply-adds in this kernel's own order (separable: rows of the window first) - SciPy's summation order is not
+// specified either; parity is to the solver's 1e-10 (measured: 1e-15), not bit for bit.
 #pragma once
 #include "zf_common.h"
 #include "zf_decide.h"
 
-constexpr int ZF_OP_TX = 32, ZF_OP_TY = 8;      // output tile of a workgroup
+constexpr int ZF_OP_TX = 64;                    // output tile width of a workgroup (lanes run along x)
 constexpr int ZF_OP_MAXK = 15;                  // largest supported kernel size (odd)
-constexpr int ZF_OP_HALO = ZF_OP_MAXK / 2;
-constexpr int ZF_OP_LW = ZF_OP_TX + 2 * ZF_OP_HALO, ZF_OP_LH = ZF_OP_TY + 2 * ZF_OP_HALO;
 
 struct zf_op_args {
     const zf_control* ctl;   // NULL: no early exit, slot ignored (evaluation outside the solver loop)
-    int H, W, K;             // image size (even), kernel size (odd, <= ZF_OP_MAXK)
+    int H, W, K;             // image size (even), kernel size as launched (odd, 3 .. ZF_OP_MAXK; zero-padded from the caller's)
     const double* taps;      // K x K, row-major
+    const double* sep;       // NULL: general kernel; else u[ZF_OP_MAXK + 1] (rows) then v[ZF_OP_MAXK + 1] (columns): taps[i][j] = u[i] v[j]
 };
 
-// The fused forms (inside the solver loop: three launches per trial instead of six).
-// zf_op_adjoint_kernel<true>: the residual at y is formed in the tile load - r = (s_k + beta (s_k - s_{k-1})) - b by
-// linearity from the cached B W^-1 x_k, B W^-1 x_{k-1} - and the workgroup's share of |r|^2 (its own tile, no halo)
-// goes to part_y.  zf_op_apply_kernel<true>: the workgroup's share of |s+ - b|^2 goes to part_x, and the LAST workgroup
-// to arrive adds both in workgroup order, adds the partials of the prox step, builds the pack and runs the decide
-// pass (model value, acceptance, lr decay, termination, buffer hand-over, trace row:
-// proximal_gradient.py:149-155,:298-307,:510,:525,:539) - the tail of zf_ls_small_rows_kernel for this operator.
+// The fused forms (inside the solver loop: three launches per trial instead of six; F.on != 0).
+// adjoint kernel: the residual at y is formed in the tile load - r = (s_k + beta (s_k - s_{k-1})) - b by linearity from
+// the cached B W^-1 x_k, B W^-1 x_{k-1} - and the workgroup's share of |r|^2 (its own tile, no halo) goes to part_y.
+// apply kernel: the workgroup's share of |s+ - b|^2 goes to part_x, and the LAST workgroup to arrive adds both in
+// workgroup order, adds the partials of the prox step, builds the pack and runs the decide pass (model value,
+// acceptance, lr decay, termination, buffer hand-over, trace row: proximal_gradient.py:149-155,:298-307,:510,:525,:539)
+// - the tail of zf_ls_small_rows_kernel for this operator.
 struct zf_op_fuse {
+    int on;                   // 0: plain operator application (F's other fields unused)
     const double* b;          // observed image
     const double* sk[3];      // ring of B W^-1 x (zf_solver::sring)
     double scale, lam;
     int nesterov;
     double* part_y;           // [workgroups] shares of |r(y)|^2   (written when need_grad)
     double* part_x;           // [workgroups] shares of |s+ - b|^2
-    unsigned* cnt;            // arrival counter of zf_op_apply_kernel<true> (zero between launches)
+    unsigned* cnt;            // arrival counter of the fused apply kernel (zero between launches)
     const double* blk_part;   // the prox step's partials, quantity-major [6][grid_step]
     int grid_step;
     double* ls_scal;          // [0] f(y) [1] f(x+)
@@ -54,43 +65,109 @@ struct zf_op_fuse {
     const double* beta_ring;
 };
 
-// scipy.signal.correlate2d(..., boundary="symm"): the image mirrored about its edges, edge sample included
+// scipy.signal.correlate2d(..., boundary="symm"): the image mirrored about its edges, edge sample included.  Indices
+// further out than one mirror image (tile rows below / right of a partial tile: they feed outputs outside the image
+// only) are clamped into range.
 __device__ __forceinline__ int zf_op_reflect(int i, int n) {
     if (i < 0) i = -i - 1;
     if (i >= n) i = 2 * n - 1 - i;
-    return i;
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-// pixel (iy, ix) of W^-1 x
-__device__ __forceinline__ double zf_op_idwt_pixel(const double* __restrict__ x, int iy, int ix, int h, int w) {
-    const int64_t q = (int64_t)h * w, at = (int64_t)(iy >> 1) * w + (ix >> 1);
-    const double cA = x[at], cH = x[q + at], cV = x[2 * q + at], cD = x[3 * q + at];
-    double v;
-    if ((iy & 1) == 0) v = (ix & 1) == 0 ? ((cA + cH) + cV) + cD : ((cA + cH) - cV) - cD;
-    else v = (ix & 1) == 0 ? ((cA - cH) + cV) - cD : ((cA - cH) - cV) + cD;
-    return v / 2;
-}
+// geometry of a K x K kernel on 64 x TY tiles
+template <int K, int TY>
+struct zf_op_geo {
+    static constexpr int HALF = K / 2;
+    static constexpr int HP = (HALF + 1) & ~1;            // halo rounded up to even: the apply kernel loads whole 2 x 2 Haar blocks
+    static constexpr int LW = ZF_OP_TX + 2 * HP, LH = TY + 2 * HP;
+    static constexpr int PITCH = LW + 2;                  // doubles between tile rows
+    static constexpr int R = TY / 4;                      // outputs per thread (a column strip): 256 threads = 64 columns x 4 strips
+    static constexpr int TROWS = TY + 2 * HALF;           // rows the correlation reads
+    static constexpr int TMP_PITCH = ZF_OP_TX + 2;
+    static constexpr int TILE_DOUBLES = LH * PITCH;
+    static constexpr int TMP_DOUBLES = TROWS * TMP_PITCH;
+};
 
-// K x K correlation of the LDS tile at output (ty, tx): rows top to bottom, taps left to right
-__device__ __forceinline__ double zf_op_correlate(const double* tile, const double* taps_lds, int K, int ty, int tx) {
-    const int off = ZF_OP_HALO - K / 2;
-    double acc = 0.0;
-    for (int u = 0; u < K; ++u) {
-        const double* row = tile + (ty + off + u) * ZF_OP_LW + tx + off;
-        for (int v = 0; v < K; ++v) acc = acc + row[v] * taps_lds[u * K + v];
+// The correlation of the staged tile: thread (c, rg) produces out[o] = (B tile)(row rg R + o, column c), o < R.
+// tile[row][col] holds image pixel (oy0 - HP + row, ox0 - HP + col).  SEP: tmp is the second LDS array; the function
+// contains a workgroup barrier.
+template <int K, int TY, bool SEP>
+__device__ __forceinline__ void zf_op_correlate(const zf_op_args& P, const double* tile, double* tmp, double (&out)[zf_op_geo<K, TY>::R]) {
+    using G = zf_op_geo<K, TY>;
+    constexpr int R = G::R, OFF = G::HP - G::HALF;
+    const int t = (int)threadIdx.x, c = t & (ZF_OP_TX - 1), rg = t >> 6;
+#pragma unroll
+    for (int o = 0; o < R; ++o) out[o] = 0.0;
+    if constexpr (SEP) {
+        double u[K], v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u[k] = P.sep[k];
+            v[k] = P.sep[ZF_OP_MAXK + 1 + k];
+        }
+        // horizontal pass: task (row, segment of 8 columns): a window of 8 + K - 1 values in registers
+        constexpr int SEGS = ZF_OP_TX / 8, TASKS = G::TROWS * SEGS;
+        for (int task = t; task < TASKS; task += ZF_BLOCK) {
+            const int row = task / SEGS, seg = task % SEGS;
+            const double* src = tile + (OFF + row) * G::PITCH + OFF + seg * 8;
+            double win[8 + K - 1];
+#pragma unroll
+            for (int q = 0; q < 8 + K - 1; ++q) win[q] = src[q];
+            double* dst = tmp + row * G::TMP_PITCH + seg * 8;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc = __builtin_fma(win[o + j], v[j], acc);
+                dst[o] = acc;
+            }
+        }
+        __syncthreads();
+        // vertical pass: the column strip of this thread
+        double col[R + K - 1];
+#pragma unroll
+        for (int q = 0; q < R + K - 1; ++q) col[q] = tmp[(rg * R + q) * G::TMP_PITCH + c];
+#pragma unroll
+        for (int o = 0; o < R; ++o)
+#pragma unroll
+            for (int i = 0; i < K; ++i) out[o] = __builtin_fma(col[o + i], u[i], out[o]);
+    } else {
+        const double* __restrict__ taps = P.taps;   // uniform addresses: scalar loads
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            double col[R + K - 1];
+#pragma unroll
+            for (int q = 0; q < R + K - 1; ++q) col[q] = tile[(OFF + rg * R + q) * G::PITCH + OFF + c + j];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const double w = taps[i * K + j];
+#pragma unroll
+                for (int o = 0; o < R; ++o) out[o] = __builtin_fma(col[o + i], w, out[o]);
+            }
+        }
     }
-    return acc;
+}
+
+// block total of one value per thread, in wave order (fixed shuffle tree inside a wave)
+__device__ __forceinline__ double zf_op_block_sum(double v, double* s_w) {
+    v = zf_wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = s_w[0];
+    for (int w = 1; w < ZF_WAVES; ++w) t += s_w[w];
+    return t;
 }
 
 // s = B W^-1 x.   Inside the loop (ctl given): x = ring buffer (cur + slot) % 3 and s likewise (the trial's x+: slot 1);
-// else x / s as given.  FUSED: see zf_op_fuse.
-template <bool FUSED>
+// else x / s as given.  F.on: see zf_op_fuse.
+template <int K, int TY, bool SEP>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, const double* __restrict__ x0,
                                                                const double* __restrict__ x1,
                                                                const double* __restrict__ x2, double* s0, double* s1,
                                                                double* s2, int slot, zf_op_fuse F) {
-    __shared__ double tile[ZF_OP_LH * ZF_OP_LW];
-    __shared__ double taps[ZF_OP_MAXK * ZF_OP_MAXK];
+    using G = zf_op_geo<K, TY>;
+    __shared__ double tile[G::TILE_DOUBLES];
+    __shared__ double tmp[SEP ? G::TMP_DOUBLES : 1];
     __shared__ double s_w[ZF_WAVES];
     __shared__ double s_pack[ZF_PACK_LEN];
     __shared__ zf_trial_eval s_pre[ZF_MAX_SUB_ITERS];
@@ -102,36 +179,54 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
     }
     const double* __restrict__ x = idx == 0 ? x0 : idx == 1 ? x1 : x2;
     double* __restrict__ s = idx == 0 ? s0 : idx == 1 ? s1 : s2;
-    const int K = P.K, half = K / 2, off = ZF_OP_HALO - half;
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
-    const int oy0 = ((int)blockIdx.x / tiles_x) * ZF_OP_TY, ox0 = ((int)blockIdx.x % tiles_x) * ZF_OP_TX;
-    for (int k = threadIdx.x; k < K * K; k += ZF_BLOCK) taps[k] = P.taps[k];
-    const int lw = ZF_OP_TX + 2 * half, lh = ZF_OP_TY + 2 * half;
-    for (int k = threadIdx.x; k < lw * lh; k += ZF_BLOCK) {
-        const int ly = k / lw, lx = k % lw;
-        const int iy = zf_op_reflect(oy0 + ly - half, P.H), ix = zf_op_reflect(ox0 + lx - half, P.W);
-        tile[(ly + off) * ZF_OP_LW + lx + off] = zf_op_idwt_pixel(x, iy, ix, P.H / 2, P.W / 2);
-    }
-    __syncthreads();
-    const int ty = threadIdx.x / ZF_OP_TX, tx = threadIdx.x % ZF_OP_TX;
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    double sq = 0.0;
-    if (oy < P.H && ox < P.W) {
-        const double v = zf_op_correlate(tile, taps, K, ty, tx);
-        s[(int64_t)oy * P.W + ox] = v;
-        if constexpr (FUSED) {
-            const double rv = v - F.b[(int64_t)oy * P.W + ox];
-            sq = rv * rv;
+    const int oy0 = ((int)blockIdx.x / tiles_x) * TY, ox0 = ((int)blockIdx.x % tiles_x) * ZF_OP_TX;
+    // tile load: one 2 x 2 block of W^-1 x per thread and round (tile origin and halo are even: blocks are whole)
+    {
+        const int h = P.H / 2, w = P.W / 2;
+        const int64_t q = (int64_t)h * w;
+        constexpr int BW = G::LW / 2, BH = G::LH / 2;
+        for (int k = threadIdx.x; k < BW * BH; k += ZF_BLOCK) {
+            const int by = k / BW, bx = k % BW;
+            const int r0 = zf_op_reflect(oy0 - G::HP + 2 * by, P.H), r1 = zf_op_reflect(oy0 - G::HP + 2 * by + 1, P.H);
+            const int c0 = zf_op_reflect(ox0 - G::HP + 2 * bx, P.W), c1 = zf_op_reflect(ox0 - G::HP + 2 * bx + 1, P.W);
+            // (mirrored blocks are whole blocks with their parities swapped; clamped ones - far outside - feed no output inside)
+            const int64_t at = (int64_t)(r0 >> 1) * w + (c0 >> 1);
+            const double cA = x[at], cH = x[q + at], cV = x[2 * q + at], cD = x[3 * q + at];
+            double px[2][2];
+            px[0][0] = (((cA + cH) + cV) + cD) / 2;
+            px[0][1] = (((cA + cH) - cV) - cD) / 2;
+            px[1][0] = (((cA - cH) + cV) - cD) / 2;
+            px[1][1] = (((cA - cH) - cV) + cD) / 2;
+            double* dst = tile + (2 * by) * G::PITCH + 2 * bx;
+            dst[0] = px[r0 & 1][c0 & 1];
+            dst[1] = px[r0 & 1][c1 & 1];
+            dst[G::PITCH] = px[r1 & 1][c0 & 1];
+            dst[G::PITCH + 1] = px[r1 & 1][c1 & 1];
         }
     }
-    if constexpr (FUSED) {
+    __syncthreads();
+    double out[G::R];
+    zf_op_correlate<K, TY, SEP>(P, tile, tmp, out);
+    const int c = threadIdx.x & (ZF_OP_TX - 1), rg = threadIdx.x >> 6;
+    const int ox = ox0 + c;
+    double sq = 0.0;
+#pragma unroll
+    for (int o = 0; o < G::R; ++o) {
+        const int oy = oy0 + rg * G::R + o;
+        if (oy < P.H && ox < P.W) {
+            s[(int64_t)oy * P.W + ox] = out[o];
+            if (F.on) {
+                const double rv = out[o] - F.b[(int64_t)oy * P.W + ox];
+                sq = __builtin_fma(rv, rv, sq);
+            }
+        }
+    }
+    if (!F.on) return;
+    {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        sq = zf_wave_sum(sq);
-        if (lane == 0) s_w[wave] = sq;
-        __syncthreads();
+        const double t = zf_op_block_sum(sq, s_w);
         if (tid == 0) {
-            double t = s_w[0];
-            for (int w = 1; w < ZF_WAVES; ++w) t += s_w[w];
             zf_publish(F.part_x + blockIdx.x, t);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned tk = __hip_atomic_fetch_add(F.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -156,14 +251,14 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
         const double nx = sqrt(fx), ny = sqrt(fy);
         const double f_x = F.scale * (nx * nx), f_y = F.scale * (ny * ny);     // np.linalg.norm(.) ** 2
         double dot = 0.0, ss = 0.0, l1 = 0.0, mx = 0.0;
-        const int64_t G = F.grid_step;
-        for (int64_t g0 = 0; g0 < G; g0 += 64) {
+        const int64_t GS = F.grid_step;
+        for (int64_t g0 = 0; g0 < GS; g0 += 64) {
             const int64_t g = g0 + lane;
-            const bool in = g < G;
-            dot += zf_wave_sum(in ? F.blk_part[1 * G + g] : 0.0);
-            ss += zf_wave_sum(in ? F.blk_part[2 * G + g] : 0.0);
-            l1 += zf_wave_sum(in ? F.blk_part[3 * G + g] : 0.0);
-            mx = fmax(mx, zf_wave_max(in ? F.blk_part[5 * G + g] : 0.0));
+            const bool in = g < GS;
+            dot += zf_wave_sum(in ? F.blk_part[1 * GS + g] : 0.0);
+            ss += zf_wave_sum(in ? F.blk_part[2 * GS + g] : 0.0);
+            l1 += zf_wave_sum(in ? F.blk_part[3 * GS + g] : 0.0);
+            mx = fmax(mx, zf_wave_max(in ? F.blk_part[5 * GS + g] : 0.0));
         }
         double pk[ZF_PACK_LEN];
         // (a rejected trial leaves y as it is: the shares of |r(y)|^2 - and f(y) - are those of the trial before)
@@ -188,77 +283,98 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
     }
 }
 
-// grad = 2 scale W (B r):  r an H x W image (the residual at y); skipped unless ctl->need_grad.  FUSED: r is formed in
+// grad = 2 scale W (B r):  r an H x W image (the residual at y); skipped unless ctl->need_grad.  F.on: r is formed in
 // the tile load from the ring of B W^-1 x (zf_op_fuse), `r` is not read.
-template <bool FUSED>
+template <int K, int TY, bool SEP>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, const double* __restrict__ r,
                                                                  double* __restrict__ grad, double two_scale, zf_op_fuse F) {
-    __shared__ double tile[ZF_OP_LH * ZF_OP_LW];
-    __shared__ double taps[ZF_OP_MAXK * ZF_OP_MAXK];
-    __shared__ double blurred[ZF_OP_TY * ZF_OP_TX];
+    using G = zf_op_geo<K, TY>;
+    __shared__ double tile[G::TILE_DOUBLES > TY * ZF_OP_TX ? G::TILE_DOUBLES : TY * ZF_OP_TX];   // later: the blurred tile
+    __shared__ double tmp[SEP ? G::TMP_DOUBLES : 1];
     __shared__ double s_w[ZF_WAVES];
     if (P.ctl && (P.ctl->status != ZF_RUNNING || !P.ctl->need_grad)) return;
     const double* __restrict__ sk = nullptr;
     const double* __restrict__ so = nullptr;
     double beta = 0.0;
-    if constexpr (FUSED) {
+    if (F.on) {
         const int cur = P.ctl->cur;
         sk = F.sk[cur];
         so = F.sk[(cur + 2) % 3];
         beta = F.nesterov ? P.ctl->beta_next : 0.0;
     }
-    const int K = P.K, half = K / 2, off = ZF_OP_HALO - half;
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
-    const int oy0 = ((int)blockIdx.x / tiles_x) * ZF_OP_TY, ox0 = ((int)blockIdx.x % tiles_x) * ZF_OP_TX;
-    for (int k = threadIdx.x; k < K * K; k += ZF_BLOCK) taps[k] = P.taps[k];
-    const int lw = ZF_OP_TX + 2 * half, lh = ZF_OP_TY + 2 * half;
-    for (int k = threadIdx.x; k < lw * lh; k += ZF_BLOCK) {
-        const int ly = k / lw, lx = k % lw;
-        const int iy = zf_op_reflect(oy0 + ly - half, P.H), ix = zf_op_reflect(ox0 + lx - half, P.W);
-        const int64_t at = (int64_t)iy * P.W + ix;
-        double rv;
-        if constexpr (FUSED) {
-            double ay = sk[at];
-            if (F.nesterov) ay = ay + beta * (ay - so[at]);   // B W^-1 y by linearity (zf_resid_y_kernel's expression)
-            rv = ay - F.b[at];
-        } else {
-            rv = r[at];
+    const int oy0 = ((int)blockIdx.x / tiles_x) * TY, ox0 = ((int)blockIdx.x % tiles_x) * ZF_OP_TX;
+    // tile load: the rows and columns the correlation reads (lanes along x: coalesced but for the mirrored edges)
+    {
+        constexpr int OFF = G::HP - G::HALF, CW = ZF_OP_TX + 2 * G::HALF;
+        for (int k = threadIdx.x; k < G::TROWS * CW; k += ZF_BLOCK) {
+            const int ly = k / CW, lx = k % CW;
+            const int iy = zf_op_reflect(oy0 - G::HALF + ly, P.H), ix = zf_op_reflect(ox0 - G::HALF + lx, P.W);
+            const int64_t at = (int64_t)iy * P.W + ix;
+            double rv;
+            if (F.on) {
+                double ay = sk[at];
+                if (F.nesterov) ay = ay + beta * (ay - so[at]);   // B W^-1 y by linearity (zf_resid_y_kernel's expression)
+                rv = ay - F.b[at];
+            } else {
+                rv = r[at];
+            }
+            tile[(OFF + ly) * G::PITCH + OFF + lx] = rv;
         }
-        tile[(ly + off) * ZF_OP_LW + lx + off] = rv;
     }
     __syncthreads();
-    const int ty = threadIdx.x / ZF_OP_TX, tx = threadIdx.x % ZF_OP_TX;
-    blurred[ty * ZF_OP_TX + tx] = (oy0 + ty < P.H && ox0 + tx < P.W) ? zf_op_correlate(tile, taps, K, ty, tx) : 0.0;
-    if constexpr (FUSED) {   // this workgroup's share of |r|^2: its own pixels (the halo belongs to the neighbours)
+    const int c = threadIdx.x & (ZF_OP_TX - 1), rg = threadIdx.x >> 6;
+    if (F.on) {   // this workgroup's share of |r|^2: its own pixels (the halo belongs to the neighbours)
         double sq = 0.0;
-        if (oy0 + ty < P.H && ox0 + tx < P.W) {
-            const double rv = tile[(ty + ZF_OP_HALO) * ZF_OP_LW + tx + ZF_OP_HALO];
-            sq = rv * rv;
+#pragma unroll
+        for (int o = 0; o < G::R; ++o) {
+            if (oy0 + rg * G::R + o < P.H && ox0 + c < P.W) {
+                const double rv = tile[(G::HP + rg * G::R + o) * G::PITCH + G::HP + c];
+                sq = __builtin_fma(rv, rv, sq);
+            }
         }
-        sq = zf_wave_sum(sq);
-        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sq;
+        const double t = zf_op_block_sum(sq, s_w);
+        if (threadIdx.x == 0) F.part_y[blockIdx.x] = t;
     }
+    double out[G::R];
+    zf_op_correlate<K, TY, SEP>(P, tile, tmp, out);
+    __syncthreads();   // every read of the tile is done: it becomes the blurred tile
+    double* blurred = tile;
+#pragma unroll
+    for (int o = 0; o < G::R; ++o)
+        blurred[(rg * G::R + o) * ZF_OP_TX + c] = (oy0 + rg * G::R + o < P.H && ox0 + c < P.W) ? out[o] : 0.0;
     __syncthreads();
-    if constexpr (FUSED) {
-        if (threadIdx.x == 0) {
-            double t = s_w[0];
-            for (int w = 1; w < ZF_WAVES; ++w) t += s_w[w];
-            F.part_y[blockIdx.x] = t;
-        }
-    }
-    // one Haar level of the tile: thread t < 64 owns the 2 x 2 block (t / 16, t % 16)
-    if (threadIdx.x < (ZF_OP_TY / 2) * (ZF_OP_TX / 2)) {
-        const int by = threadIdx.x / (ZF_OP_TX / 2), bx = threadIdx.x % (ZF_OP_TX / 2);
+    // one Haar level of the tile: a thread owns 2 x 2 blocks (by, bx), bx along the lanes
+    constexpr int BW = ZF_OP_TX / 2, BH = TY / 2;
+    for (int k = threadIdx.x; k < BW * BH; k += ZF_BLOCK) {
+        const int by = k / BW, bx = k % BW;
         const int py = oy0 + 2 * by, px = ox0 + 2 * bx;
         if (py < P.H && px < P.W) {
             const double a = blurred[(2 * by) * ZF_OP_TX + 2 * bx], b = blurred[(2 * by) * ZF_OP_TX + 2 * bx + 1];
-            const double c = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx], d = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx + 1];
+            const double cc = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx], d = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx + 1];
             const int h = P.H / 2, w = P.W / 2;
             const int64_t q = (int64_t)h * w, at = (int64_t)(py >> 1) * w + (px >> 1);
-            grad[at] = two_scale * ((((a + b) + c) + d) / 2);
-            grad[q + at] = two_scale * ((((a + b) - c) - d) / 2);
-            grad[2 * q + at] = two_scale * ((((a - b) + c) - d) / 2);
-            grad[3 * q + at] = two_scale * ((((a - b) - c) + d) / 2);
+            grad[at] = two_scale * ((((a + b) + cc) + d) / 2);
+            grad[q + at] = two_scale * ((((a + b) - cc) - d) / 2);
+            grad[2 * q + at] = two_scale * ((((a - b) + cc) - d) / 2);
+            grad[3 * q + at] = two_scale * ((((a - b) - cc) + d) / 2);
         }
     }
 }
+
+// ---- host side: which instantiation runs a problem (zf_op.hip) ----------------------------------------------------
+// K as launched: the caller's odd size (3 .. 15: each has its kernels; 1 is zero-padded to 3); ty = 32 (64 x 32 tiles)
+// when that still makes a thousand tiles or more, else 8 (images of few tiles: more workgroups, shorter strips)
+struct zf_op_plan {
+    int K;          // 3 .. 15, odd
+    int ty;         // 32 or 8
+    bool sep;
+    int grid;
+};
+zf_op_plan zf_op_make_plan(int64_t h, int64_t w, int k, bool separable);
+void zf_launch_op_apply(const zf_op_plan& pl, hipStream_t st, const zf_op_args& P, const double* x0, const double* x1, const double* x2,
+                        double* s0, double* s1, double* s2, int slot, const zf_op_fuse& F);
+void zf_launch_op_adjoint(const zf_op_plan& pl, hipStream_t st, const zf_op_args& P, const double* r, double* grad, double two_scale,
+                          const zf_op_fuse& F);
+// rank-1 test of a K x K kernel (host arrays): on success u[K], v[K] with |k[i][j] - u[i] v[j]| <= 1e-14 max |k|
+bool zf_op_factor_rank1(const double* taps, int k, double* u, double* v);

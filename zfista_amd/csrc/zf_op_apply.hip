@@ -1,0 +1,59 @@
+// zf_op_apply.hip - instantiations of zf_op_apply_kernel (B W^-1 x) and the plan of an operator problem
+#include <math.h>
+
+#include "zf_kernels_op.h"
+
+zf_op_plan zf_op_make_plan(int64_t h, int64_t w, int k, bool separable) {
+    zf_op_plan pl;
+    pl.K = k < 3 ? 3 : k;
+    const int64_t tx = (w + ZF_OP_TX - 1) / ZF_OP_TX;
+    const int64_t tall = tx * ((h + 31) / 32);
+    pl.ty = tall >= 1024 ? 32 : 8;
+    pl.sep = separable;
+    pl.grid = (int)(tx * ((h + pl.ty - 1) / pl.ty));
+    return pl;
+}
+
+// k = u v^T ?  Pivot on the largest entry: u = its column, v = its row / the pivot.
+bool zf_op_factor_rank1(const double* taps, int k, double* u, double* v) {
+    int pi = 0, pj = 0;
+    double big = 0.0;
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+            if (fabs(taps[i * k + j]) > big) {
+                big = fabs(taps[i * k + j]);
+                pi = i;
+                pj = j;
+            }
+    if (!(big > 0.0) || !isfinite(big)) return false;
+    for (int i = 0; i < k; ++i) u[i] = taps[i * k + pj];
+    for (int j = 0; j < k; ++j) v[j] = taps[pi * k + j] / taps[pi * k + pj];
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+            if (!(fabs(taps[i * k + j] - u[i] * v[j]) <= 1e-14 * big)) return false;
+    return true;
+}
+
+template <int K>
+static void launch_apply_k(const zf_op_plan& pl, hipStream_t st, const zf_op_args& P, const double* x0, const double* x1, const double* x2,
+                           double* s0, double* s1, double* s2, int slot, const zf_op_fuse& F) {
+#define GO(TY, SEP) hipLaunchKernelGGL((zf_op_apply_kernel<K, TY, SEP>), dim3(pl.grid), dim3(ZF_BLOCK), 0, st, P, x0, x1, x2, s0, s1, s2, slot, F)
+    if (pl.ty == 32 && pl.sep) GO(32, true);
+    else if (pl.ty == 32) GO(32, false);
+    else if (pl.sep) GO(8, true);
+    else GO(8, false);
+#undef GO
+}
+
+void zf_launch_op_apply(const zf_op_plan& pl, hipStream_t st, const zf_op_args& P, const double* x0, const double* x1, const double* x2,
+                        double* s0, double* s1, double* s2, int slot, const zf_op_fuse& F) {
+    switch (pl.K) {
+        case 3: return launch_apply_k<3>(pl, st, P, x0, x1, x2, s0, s1, s2, slot, F);
+        case 5: return launch_apply_k<5>(pl, st, P, x0, x1, x2, s0, s1, s2, slot, F);
+        case 7: return launch_apply_k<7>(pl, st, P, x0, x1, x2, s0, s1, s2, slot, F);
+        case 9: return launch_apply_k<9>(pl, st, P, x0, x1, x2, s0, s1, s2, slot, F);
+        case 11: return launch_apply_k<11>(pl, st, P, x0, x1, x2, s0, s1, s2, slot, F);
+        case 13: return launch_apply_k<13>(pl, st, P, x0, x1, x2, s0, s1, s2, slot, F);
+        default: return launch_apply_k<15>(pl, st, P, x0, x1, x2, s0, s1, s2, slot, F);
+    }
+}

@@ -544,11 +544,12 @@ def solve_dual_native(dual, m, w0, tol, max_iter):
             # where the values no longer resolve the decrease (~1e-12 |D| of rounding noise near the optimum) the
             # derivative along d decides: the approximate Wolfe conditions of Hager & Zhang (zf_dual::machine::ls_accept)
             dphi = (g_try - g_try.mean()) @ d
-            # (the value guard is waived where the values contradict the gradients - the reference's composed prox is
-            #  not the exact prox of several shifted l1 terms, so its dual value and gradient are not consistent there;
-            #  SciPy follows the gradient field: zf_dual::machine::ls_accept)
-            df, pred = f_try - fun, 0.5 * t * (slope + dphi)
-            value_ok = df <= 1e-10 * abs(fun) or abs(df - pred) > 0.5 * abs(df)
+            # (the value guard: within the noise of the values the slopes decide; a rise the convexity of the dual allows -
+            #  df <= 2 t max(phi'(t), 0) - is an overshoot and is rejected; a rise beyond that CONTRADICTS the gradients -
+            #  the reference's composed prox is not the exact prox of several shifted l1 terms, so its dual value and
+            #  gradient are not consistent there - and the slopes decide, as they do for SciPy: zf_dual::machine::ls_accept)
+            df, noise = f_try - fun, 1e-10 * abs(fun)
+            value_ok = df <= noise or df > 2.0 * t * max(dphi, 0.0) + noise
             if value_ok and 0.9 * slope <= dphi <= -(1.0 - 2e-4) * slope:
                 break
             t *= 0.5
