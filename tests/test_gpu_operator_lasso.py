@@ -88,3 +88,76 @@ def test_with_a_line_search_a_box_and_other_kernel_sizes():
         assert res.nit == exp.nit and res.status == exp.status, (ksize, res.nit, exp.nit)
         assert rel_err(res.x, exp.x) <= TOL
         np.testing.assert_allclose(np.asarray(res.fun), np.asarray(exp.fun), rtol=TOL)
+
+
+@pytest.mark.parametrize("variant", ["separable", "general_same_kernel", "general_rank_two", "k1", "k3_tall_image"])
+def test_beyond_the_notebook_size_and_every_kernel_path(variant, monkeypatch):
+    """Round 5: the correlation kernels were rewritten (64 x 32 tiles, register sliding windows, a separable path for
+    rank-1 kernels, 64 x 8 tiles for images of few tiles).  Every path against the oracle on the same callbacks at
+    sizes where the 64 x 32 tiles run (1024 x 1024: the verdict's "parity test at 1024^2"), with partial tiles at the
+    right and bottom edges, a kernel that is NOT separable, the separable kernel forced through the general path
+    (ZF_OP_SEPARABLE=0), and the degenerate 1 x 1 kernel (zero-padded to 3 x 3)."""
+    from oracle import cpu_ref, operator_ref as O
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.problems import BlurHaarL1
+
+    rng = np.random.default_rng(11)
+    iters = 4
+    if variant in ("separable", "general_same_kernel"):
+        kernel, observed, x0, L = O.make_deblur(1024)
+        lam = O.L1_RATIO
+        if variant == "general_same_kernel":
+            monkeypatch.setenv("ZF_OP_SEPARABLE", "0")
+    elif variant == "general_rank_two":
+        shape = (1056, 1000)          # partial tiles in both directions, 64 x 32 tiles (33 x 16 = 528 ... x 2 rows)
+        k1 = O.gaussian_kernel(7, 1.5)
+        kernel = k1 / k1.sum() + 0.05 * np.outer(np.arange(7) - 3, np.ones(7)) / 49     # rank 2: no separable path
+        observed = rng.standard_normal(shape)
+        x0, lam = O.dwt(observed), 0.02
+        L = O.lipschitz(kernel)
+    elif variant == "k1":
+        kernel = np.array([[0.7]])
+        observed = rng.standard_normal((64, 192))
+        x0, lam, L = O.dwt(observed), 0.05, 2 * 0.7 ** 2
+    else:
+        kernel = O.gaussian_kernel(3, 1.0)
+        kernel = kernel / kernel.sum()
+        observed = rng.standard_normal((2048, 96))     # tall and narrow: two tile columns, the second partial
+        x0, lam = O.dwt(observed), 0.02
+        L = O.lipschitz(kernel)
+    ref = O.BlurHaarL1Ref(kernel, observed, l1_ratio=lam)
+    prob = BlurHaarL1(kernel, observed, lam)
+    kw = dict(lr=1 / L, decay_rate=1, nesterov=True, tol=0.0, max_iter=iters, return_all=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize_proximal_gradient(*prob.callbacks(), x0, **kw)
+        exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, **kw)
+    assert res.nit == exp.nit == iters
+    for k in range(1, iters + 1):
+        assert rel_err(np.asarray(res.allvecs[k]), exp.allvecs[k]) <= TOL, k
+    np.testing.assert_allclose(np.concatenate([np.asarray(v).reshape(-1) for v in res.allfuns]),
+                               np.concatenate([np.asarray(v).reshape(-1) for v in exp.allfuns]), rtol=TOL)
+    # the callbacks outside the loop take the same kernels (zf_op_eval)
+    x = x0 + 0.1 * rng.standard_normal(x0.size)
+    assert rel_err(prob.jac_f(x), ref.jac_f(x)) <= 1e-12 and abs(prob.f(x)[0] - ref.f(x)[0]) <= 1e-12 * abs(ref.f(x)[0])
+
+
+def test_independent_solves_on_streams_equal_the_solves_alone():
+    """zfista_amd.replicas.solve_on_streams: the notebook's sweep pattern (cameraman.ipynb cell 11: joblib over momentum
+    settings) as host threads with a HIP stream each on ONE GPU - every result must be the one the same call gives alone."""
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.replicas import solve_on_streams
+
+    prob, _, x0, L = _problem(128)
+    ratios = [(0, 0.25), (0.5, 1 / 16), (0.75, 0.25), (0.25, 1 / 64), (1 / 6, 1 / 144)]
+    kws = [dict(lr=1 / L, decay_rate=1, nesterov=True, nesterov_ratio=r, return_all=(k % 2 == 0)) for k, r in enumerate(ratios)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        alone = [minimize_proximal_gradient(*prob.callbacks(), x0, **kw) for kw in kws]
+    together = solve_on_streams([(prob, x0, kw) for kw in kws], streams=5)
+    again = solve_on_streams([(prob.callbacks(), x0, kw) for kw in kws], streams=2)
+    for a, b, c in zip(alone, together, again):
+        assert a.nit == b.nit == c.nit and a.status == b.status == c.status
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.x, c.x) and np.array_equal(np.asarray(a.fun), np.asarray(b.fun))
+        if a.allfuns is not None:
+            assert np.array_equal(np.concatenate(a.allfuns), np.concatenate(b.allfuns))

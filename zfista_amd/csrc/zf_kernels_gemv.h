@@ -161,6 +161,40 @@ __global__ __launch_bounds__(RESID_BLOCK) void zf_resid_x_kernel(const zf_contro
     }
 }
 
+// The same for LONG residuals (the operator problem: m = n pixels) in two launches: every workgroup the share of its
+// contiguous chunk -> partials[blockIdx.x]; then one workgroup adds the shares in order.  (One workgroup alone took 8 ms
+// for 1.7e7 pixels at the initialisation of a 4096 x 4096 deblurring solve.)
+__global__ __launch_bounds__(ZF_BLOCK) void zf_resid_x_wide_kernel(const double* __restrict__ s, const double* __restrict__ b,
+                                                                   int64_t m_rows, double* __restrict__ partials) {
+    __shared__ double lds[ZF_WAVES];
+    const int64_t per = (m_rows + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m_rows ? lo + per : m_rows;
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += ZF_BLOCK) {
+        const double rv = s[i] - b[i];
+        acc += rv * rv;
+    }
+    acc = zf_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+        for (int w = 1; w < ZF_WAVES; ++w) t += lds[w];
+        partials[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(RESID_BLOCK) void zf_resid_x_finish_kernel(const double* __restrict__ partials, int count, double scale,
+                                                                       double* f_out) {
+    __shared__ double lds[RESID_BLOCK / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += RESID_BLOCK) acc += partials[i];
+    const double t = zf_block_sum_1024(acc, lds);
+    if (threadIdx.x == 0) {
+        const double nrm = sqrt(t);
+        *f_out = scale * (nrm * nrm);
+    }
+}
+
 // s <- s - b (residual in place; operator evaluation outside the solver loop)
 __global__ __launch_bounds__(ZF_BLOCK) void zf_axmb_kernel(double* __restrict__ s,
                                                            const double* __restrict__ b, int64_t m_rows) {

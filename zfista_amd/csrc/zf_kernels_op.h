@@ -133,7 +133,9 @@ __device__ __forceinline__ void zf_op_correlate(const zf_op_args& P, const doubl
             for (int i = 0; i < K; ++i) out[o] = __builtin_fma(col[o + i], u[i], out[o]);
     } else {
         const double* __restrict__ taps = P.taps;   // uniform addresses: scalar loads
-#pragma unroll
+        // (one tap column per trip, not unrolled: unrolled, the scheduler hoists the K (R + K - 1) window loads of all
+        //  columns in front of the arithmetic - 292 VGPRs at K = 9, 512 + scratch at K = 13)
+#pragma unroll 1
         for (int j = 0; j < K; ++j) {
             double col[R + K - 1];
 #pragma unroll
@@ -181,28 +183,50 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
     double* __restrict__ s = idx == 0 ? s0 : idx == 1 ? s1 : s2;
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
     const int oy0 = ((int)blockIdx.x / tiles_x) * TY, ox0 = ((int)blockIdx.x % tiles_x) * ZF_OP_TX;
-    // tile load: one 2 x 2 block of W^-1 x per thread and round (tile origin and halo are even: blocks are whole)
+    // tile load: one 2 x 2 block of W^-1 x per thread and round (tile origin and halo are even: blocks are whole); the
+    // four coefficient loads of ALL rounds of a thread are issued before the first is used (a round per trip left one
+    // memory latency per round on the critical path of a workgroup that holds two or three waves per SIMD)
     {
         const int h = P.H / 2, w = P.W / 2;
         const int64_t q = (int64_t)h * w;
-        constexpr int BW = G::LW / 2, BH = G::LH / 2;
-        for (int k = threadIdx.x; k < BW * BH; k += ZF_BLOCK) {
-            const int by = k / BW, bx = k % BW;
+        constexpr int BW = G::LW / 2, BH = G::LH / 2, ROUNDS = (BW * BH + ZF_BLOCK - 1) / ZF_BLOCK;
+        double cf[ROUNDS][4];
+        int par[ROUNDS];
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int k = (int)threadIdx.x + rd * ZF_BLOCK;
+            const int kk = k < BW * BH ? k : 0;
+            const int by = kk / BW, bx = kk % BW;
             const int r0 = zf_op_reflect(oy0 - G::HP + 2 * by, P.H), r1 = zf_op_reflect(oy0 - G::HP + 2 * by + 1, P.H);
             const int c0 = zf_op_reflect(ox0 - G::HP + 2 * bx, P.W), c1 = zf_op_reflect(ox0 - G::HP + 2 * bx + 1, P.W);
             // (mirrored blocks are whole blocks with their parities swapped; clamped ones - far outside - feed no output inside)
             const int64_t at = (int64_t)(r0 >> 1) * w + (c0 >> 1);
-            const double cA = x[at], cH = x[q + at], cV = x[2 * q + at], cD = x[3 * q + at];
-            double px[2][2];
-            px[0][0] = (((cA + cH) + cV) + cD) / 2;
-            px[0][1] = (((cA + cH) - cV) - cD) / 2;
-            px[1][0] = (((cA - cH) + cV) - cD) / 2;
-            px[1][1] = (((cA - cH) - cV) + cD) / 2;
-            double* dst = tile + (2 * by) * G::PITCH + 2 * bx;
-            dst[0] = px[r0 & 1][c0 & 1];
-            dst[1] = px[r0 & 1][c1 & 1];
-            dst[G::PITCH] = px[r1 & 1][c0 & 1];
-            dst[G::PITCH + 1] = px[r1 & 1][c1 & 1];
+            cf[rd][0] = x[at];
+            cf[rd][1] = x[q + at];
+            cf[rd][2] = x[2 * q + at];
+            cf[rd][3] = x[3 * q + at];
+            par[rd] = (r0 & 1) | ((r1 & 1) << 1) | ((c0 & 1) << 2) | ((c1 & 1) << 3);
+        }
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int k = (int)threadIdx.x + rd * ZF_BLOCK;
+            if (k < BW * BH) {
+                const int by = k / BW, bx = k % BW;
+                const double cA = cf[rd][0], cH = cf[rd][1], cV = cf[rd][2], cD = cf[rd][3];
+                // pixel (r, c) of the block: (((cA +- cH) +- cV) +- cD) / 2 with the signs of its row / column parity - written
+                // with factors of +-1 (exact), not as a choice among four values: the compiler turned both an indexed array
+                // and nested selects into a table in scratch memory
+                auto pixel = [&](int rbit, int cbit) {
+                    const double sh = rbit ? -1.0 : 1.0, sv = cbit ? -1.0 : 1.0;
+                    return (((cA + sh * cH) + sv * cV) + (sh * sv) * cD) / 2;
+                };
+                const int pr0 = par[rd] & 1, pr1 = (par[rd] >> 1) & 1, pc0 = (par[rd] >> 2) & 1, pc1 = (par[rd] >> 3) & 1;
+                double* dst = tile + (2 * by) * G::PITCH + 2 * bx;
+                dst[0] = pixel(pr0, pc0);
+                dst[1] = pixel(pr0, pc1);
+                dst[G::PITCH] = pixel(pr1, pc0);
+                dst[G::PITCH + 1] = pixel(pr1, pc1);
+            }
         }
     }
     __syncthreads();
@@ -238,36 +262,52 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
             s_last = last;
         }
         __syncthreads();
-        if (!s_last || wave != 0) return;
-        // last arriver, wave 0: f(y), f(x+) from the workgroup shares (chunks of 64 workgroups in order, within a chunk
-        // the fixed shuffle tree), the prox step's partials, the pack, the decide pass
-        double fy = 0.0, fx = 0.0;
-        for (int g0 = 0; g0 < (int)gridDim.x; g0 += 64) {
-            const int g = g0 + lane;
-            const bool in = g < (int)gridDim.x;
-            fx += zf_wave_sum(in ? zf_consume(F.part_x + g) : 0.0);
-            fy += zf_wave_sum(in ? F.part_y[g] : 0.0);
+        if (!s_last) return;
+        // last arriver: f(y), f(x+) from the workgroup shares and the prox step's partials.  ALL 256 threads take part:
+        // thread t adds shares t, t + 256, ... (independent loads, several in flight), then the fixed block tree - in
+        // round 4 one wave walked the shares in chunks of 64, a dependent trip to memory per chunk: 128 trips at
+        // 4096 x 4096 (8192 workgroups) were 380 of the kernel's 566 us (profiles/r05_operator_*).  Deterministic: the
+        // order depends on the grid only.
+        __shared__ double s_red[6][ZF_WAVES];
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // |s+ - b|^2, |r(y)|^2, dot, ss, l1, max
+        const int NG = (int)gridDim.x;
+#pragma unroll 4
+        for (int g = tid; g < NG; g += ZF_BLOCK) {
+            acc[0] += zf_consume(F.part_x + g);
+            acc[1] += F.part_y[g];
         }
-        const double nx = sqrt(fx), ny = sqrt(fy);
-        const double f_x = F.scale * (nx * nx), f_y = F.scale * (ny * ny);     // np.linalg.norm(.) ** 2
-        double dot = 0.0, ss = 0.0, l1 = 0.0, mx = 0.0;
         const int64_t GS = F.grid_step;
-        for (int64_t g0 = 0; g0 < GS; g0 += 64) {
-            const int64_t g = g0 + lane;
-            const bool in = g < GS;
-            dot += zf_wave_sum(in ? F.blk_part[1 * GS + g] : 0.0);
-            ss += zf_wave_sum(in ? F.blk_part[2 * GS + g] : 0.0);
-            l1 += zf_wave_sum(in ? F.blk_part[3 * GS + g] : 0.0);
-            mx = fmax(mx, zf_wave_max(in ? F.blk_part[5 * GS + g] : 0.0));
+#pragma unroll 4
+        for (int64_t g = tid; g < GS; g += ZF_BLOCK) {
+            acc[2] += F.blk_part[1 * GS + g];
+            acc[3] += F.blk_part[2 * GS + g];
+            acc[4] += F.blk_part[3 * GS + g];
+            acc[5] = fmax(acc[5], F.blk_part[5 * GS + g]);
         }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double v = k == 5 ? zf_wave_max(acc[k]) : zf_wave_sum(acc[k]);
+            if (lane == 0) s_red[k][wave] = v;
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        double tot[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            tot[k] = s_red[k][0];
+            for (int w = 1; w < ZF_WAVES; ++w) tot[k] = k == 5 ? fmax(tot[k], s_red[k][w]) : tot[k] + s_red[k][w];
+        }
+        const double nx = sqrt(tot[0]), ny = sqrt(tot[1]);
+        const double f_x = F.scale * (nx * nx), f_y = F.scale * (ny * ny);     // np.linalg.norm(.) ** 2
+        const double dot = tot[2], ss = tot[3], l1 = tot[4], mx = tot[5];
         double pk[ZF_PACK_LEN];
         // (a rejected trial leaves y as it is: the shares of |r(y)|^2 - and f(y) - are those of the trial before)
-        pk[ZF_PK_FY] = __shfl(f_y, 0, 64);
-        pk[ZF_PK_DOT] = __shfl(dot, 0, 64);
-        pk[ZF_PK_SS] = __shfl(ss, 0, 64);
-        pk[ZF_PK_GX] = F.lam * __shfl(l1, 0, 64);
-        pk[ZF_PK_FX] = __shfl(f_x, 0, 64);
-        pk[ZF_PK_ERR] = __shfl(mx, 0, 64);
+        pk[ZF_PK_FY] = f_y;
+        pk[ZF_PK_DOT] = dot;
+        pk[ZF_PK_SS] = ss;
+        pk[ZF_PK_GX] = F.lam * l1;
+        pk[ZF_PK_FX] = f_x;
+        pk[ZF_PK_ERR] = mx;
         pk[6] = 0.0;
         pk[7] = 0.0;
         if (lane == 0) {
@@ -304,22 +344,37 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
     }
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
     const int oy0 = ((int)blockIdx.x / tiles_x) * TY, ox0 = ((int)blockIdx.x % tiles_x) * ZF_OP_TX;
-    // tile load: the rows and columns the correlation reads (lanes along x: coalesced but for the mirrored edges)
+    // tile load: the rows and columns the correlation reads (lanes along x: coalesced but for the mirrored edges), four
+    // pixels - up to twelve loads - per thread in flight at a time
     {
-        constexpr int OFF = G::HP - G::HALF, CW = ZF_OP_TX + 2 * G::HALF;
-        for (int k = threadIdx.x; k < G::TROWS * CW; k += ZF_BLOCK) {
-            const int ly = k / CW, lx = k % CW;
-            const int iy = zf_op_reflect(oy0 - G::HALF + ly, P.H), ix = zf_op_reflect(ox0 - G::HALF + lx, P.W);
-            const int64_t at = (int64_t)iy * P.W + ix;
-            double rv;
-            if (F.on) {
-                double ay = sk[at];
-                if (F.nesterov) ay = ay + beta * (ay - so[at]);   // B W^-1 y by linearity (zf_resid_y_kernel's expression)
-                rv = ay - F.b[at];
-            } else {
-                rv = r[at];
+        constexpr int OFF = G::HP - G::HALF, CW = ZF_OP_TX + 2 * G::HALF, TOTAL = G::TROWS * CW, BATCH = 4;
+        const bool fused = F.on != 0, nest = fused && F.nesterov;
+        for (int k0 = threadIdx.x; k0 < TOTAL; k0 += BATCH * ZF_BLOCK) {
+            double a0[BATCH], a1[BATCH], a2[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int k = k0 + u * ZF_BLOCK;
+                const int kk = k < TOTAL ? k : 0;
+                const int ly = kk / CW, lx = kk % CW;
+                const int iy = zf_op_reflect(oy0 - G::HALF + ly, P.H), ix = zf_op_reflect(ox0 - G::HALF + lx, P.W);
+                const int64_t at = (int64_t)iy * P.W + ix;
+                a0[u] = fused ? sk[at] : r[at];
+                a1[u] = nest ? so[at] : 0.0;
+                a2[u] = fused ? F.b[at] : 0.0;
             }
-            tile[(OFF + ly) * G::PITCH + OFF + lx] = rv;
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int k = k0 + u * ZF_BLOCK;
+                if (k < TOTAL) {
+                    const int ly = k / CW, lx = k % CW;
+                    double rv = a0[u];
+                    if (fused) {
+                        if (nest) rv = rv + beta * (rv - a1[u]);   // B W^-1 y by linearity (zf_resid_y_kernel's expression)
+                        rv = rv - a2[u];
+                    }
+                    tile[(OFF + ly) * G::PITCH + OFF + lx] = rv;
+                }
+            }
         }
     }
     __syncthreads();
@@ -364,7 +419,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
 
 // ---- host side: which instantiation runs a problem (zf_op.hip) ----------------------------------------------------
 // K as launched: the caller's odd size (3 .. 15: each has its kernels; 1 is zero-padded to 3); ty = 32 (64 x 32 tiles)
-// when that still makes a thousand tiles or more, else 8 (images of few tiles: more workgroups, shorter strips)
+// when that still makes 256 tiles or more, else 8 (images of few tiles: more workgroups, shorter strips)
 struct zf_op_plan {
     int K;          // 3 .. 15, odd
     int ty;         // 32 or 8

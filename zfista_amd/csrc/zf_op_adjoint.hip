@@ -7,6 +7,8 @@ static void launch_adjoint_k(const zf_op_plan& pl, hipStream_t st, const zf_op_a
 #define GO(TY, SEP) hipLaunchKernelGGL((zf_op_adjoint_kernel<K, TY, SEP>), dim3(pl.grid), dim3(ZF_BLOCK), 0, st, P, r, grad, two_scale, F)
     if (pl.ty == 32 && pl.sep) GO(32, true);
     else if (pl.ty == 32) GO(32, false);
+    else if (pl.ty == 16 && pl.sep) GO(16, true);
+    else if (pl.ty == 16) GO(16, false);
     else if (pl.sep) GO(8, true);
     else GO(8, false);
 #undef GO

@@ -1,5 +1,6 @@
 // zf_op_apply.hip - instantiations of zf_op_apply_kernel (B W^-1 x) and the plan of an operator problem
 #include <math.h>
+#include <stdlib.h>
 
 #include "zf_kernels_op.h"
 
@@ -8,7 +9,11 @@ zf_op_plan zf_op_make_plan(int64_t h, int64_t w, int k, bool separable) {
     pl.K = k < 3 ? 3 : k;
     const int64_t tx = (w + ZF_OP_TX - 1) / ZF_OP_TX;
     const int64_t tall = tx * ((h + 31) / 32);
-    pl.ty = tall >= 1024 ? 32 : 8;
+    pl.ty = tall >= 256 ? 32 : 8;   // (measured, round 5: 1024 x 1024 = 512 tall tiles runs 20.6 k it/s on 64 x 32 tiles, 15.5 k on 64 x 8; 256 x 256 the other way round)
+    if (const char* e = getenv("ZF_OP_TY")) {   // (experiments: 8 / 16 / 32 rows per tile)
+        const int v = atoi(e);
+        if (v == 8 || v == 16 || v == 32) pl.ty = v;
+    }
     pl.sep = separable;
     pl.grid = (int)(tx * ((h + pl.ty - 1) / pl.ty));
     return pl;
@@ -40,6 +45,8 @@ static void launch_apply_k(const zf_op_plan& pl, hipStream_t st, const zf_op_arg
 #define GO(TY, SEP) hipLaunchKernelGGL((zf_op_apply_kernel<K, TY, SEP>), dim3(pl.grid), dim3(ZF_BLOCK), 0, st, P, x0, x1, x2, s0, s1, s2, slot, F)
     if (pl.ty == 32 && pl.sep) GO(32, true);
     else if (pl.ty == 32) GO(32, false);
+    else if (pl.ty == 16 && pl.sep) GO(16, true);
+    else if (pl.ty == 16) GO(16, false);
     else if (pl.sep) GO(8, true);
     else GO(8, false);
 #undef GO

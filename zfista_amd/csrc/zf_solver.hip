@@ -192,6 +192,9 @@ struct zf_solver {
     bool own_packs = true;
     bool gemv_mfma = false;       // A^T r on v_mfma_f64_16x16x4 (n % 32 == 0; ZF_GEMV_MFMA=0 disables)
     bool ls_small = false;        // cache-resident A: two fused launches per trial (zf_kernels_ls_small.h)
+    zf_op_plan op_plan = {};      // operator problem: which instantiation of the correlation kernels runs it (zf_op_make_plan)
+    double* op_buf = nullptr;     // its taps as launched (zero-padded to K x K) and, behind them, the rank-1 factors u, v when the kernel is separable
+    const double* op_taps = nullptr, *op_sep = nullptr;
     double* row_part = nullptr;   // ls_small: workgroup sums of the row kernel
     unsigned* ls_cnt = nullptr;
     int64_t ntiles = 1;           // 16 KiB tiles of the trial kernel
@@ -270,6 +273,7 @@ struct zf_solver {
     hipEvent_t ah_evT[4] = {}, ah_evD[4] = {};   // trial kernel done (stream) / decided (stream2), by pass number of the run % 4
     int ah_run = 0;                       // passes of the current run so far
     int ah_last_nf = 0;                   // fresh trials of the last one
+    int run_mode = 0;                     // what the current run of passes in flight consists of: 0 none, 1 run-ahead passes (workgroup granularity), 2 passes ahead (kernel granularity) - a run is one or the other
     int64_t ah_passes = 0;                // passes launched ahead since creation
     // streaming return_all: caller-owned ring of iterates in HBM (zf_solver_set_history)
     double* hist = nullptr;
@@ -295,7 +299,7 @@ static int zf_solver_free_all(zf_solver* s) {
     }
     if (s->ra_join) (void)hipEventDestroy(s->ra_join);
     if (s->ra_fork) (void)hipEventDestroy(s->ra_fork);
-    void* ptrs[] = {s->row_part, s->ls_cnt, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
+    void* ptrs[] = {s->op_buf, s->row_part, s->ls_cnt, s->blk_part, s->slice_part, s->fin_cnt, s->grp_part, s->xbuf, s->partials, s->ctl_trace, s->beta_ring,
                     s->ra_word, s->ra_flags, s->blk_part2, s->grp_part2, s->fin_cnt2, s->pack2,
                     s->own_packs ? s->pack_local : nullptr, s->own_packs ? s->pack_all : nullptr,
                     s->grad, s->sbuf, s->resid, s->slab, s->ls_scal,
@@ -319,26 +323,57 @@ static bool zf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p)
 // least squares with an explicit matrix, or with the blur o inverse-Haar operator (zf_kernels_op.h): everything
 // around the two applications of A / its adjoint is shared
 static bool zf_is_ls(int kind) { return kind == ZF_PROBLEM_LEAST_SQUARES_L1 || kind == ZF_PROBLEM_BLUR_HAAR_L1; }
-static zf_op_args zf_op_of(const zf_problem_desc& d, const zf_control* ctl) {
+static zf_op_args zf_op_of(const zf_problem_desc& d, const zf_control* ctl, const zf_op_plan& pl, const double* taps, const double* sep) {
     zf_op_args P;
     P.ctl = ctl;
     P.H = (int)d.op_h;
     P.W = (int)d.op_w;
-    P.K = (int)d.op_k;
-    P.taps = d.op_taps;
+    P.K = pl.K;
+    P.taps = taps;
+    P.sep = pl.sep ? sep : nullptr;
     return P;
 }
-static int zf_op_grid(const zf_problem_desc& d) {
-    return (int)(((d.op_w + ZF_OP_TX - 1) / ZF_OP_TX) * ((d.op_h + ZF_OP_TY - 1) / ZF_OP_TY));
+static zf_op_args zf_op_of(const zf_solver* s, const zf_control* ctl) { return zf_op_of(s->desc, ctl, s->op_plan, s->op_taps, s->op_sep); }
+static zf_op_fuse zf_op_no_fuse() {
+    zf_op_fuse F;
+    memset(&F, 0, sizeof(F));
+    return F;
 }
+// The taps as the kernels take them: K x K with K the launched size (1 x 1 is zero-padded to 3 x 3), and - when the
+// kernel has rank 1 and ZF_OP_SEPARABLE is not 0 - its factors u, v behind them.  *buf: one device allocation
+// (caller frees); `st`: the stream the upload is ordered on.
+static int zf_op_prepare(const double* taps_dev, int k, int64_t h, int64_t w, hipStream_t st, zf_op_plan* pl, double** buf,
+                         const double** taps_out, const double** sep_out) {
+    double host[ZF_OP_MAXK * ZF_OP_MAXK];
+    ZF_HIP(hipMemcpyAsync(host, taps_dev, sizeof(double) * k * k, hipMemcpyDeviceToHost, st));
+    ZF_HIP(hipStreamSynchronize(st));
+    const int K = k < 3 ? 3 : k;
+    double up[ZF_OP_MAXK * ZF_OP_MAXK + 2 * (ZF_OP_MAXK + 1)];
+    memset(up, 0, sizeof(up));
+    const int pad = (K - k) / 2;
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) up[(i + pad) * K + j + pad] = host[i * k + j];
+    double* u = up + ZF_OP_MAXK * ZF_OP_MAXK;
+    double* v = u + ZF_OP_MAXK + 1;
+    const char* e = getenv("ZF_OP_SEPARABLE");
+    const bool sep = !(e && atoi(e) == 0) && zf_op_factor_rank1(up, K, u, v);
+    *pl = zf_op_make_plan(h, w, k, sep);
+    ZF_HIP(hipMalloc(buf, sizeof(up)));
+    ZF_HIP(hipMemcpyAsync(*buf, up, sizeof(up), hipMemcpyHostToDevice, st));
+    ZF_HIP(hipStreamSynchronize(st));   // `up` is a stack object
+    *taps_out = *buf;
+    *sep_out = *buf + ZF_OP_MAXK * ZF_OP_MAXK;
+    return ZF_OK;
+}
+static int zf_op_grid(const zf_problem_desc& d) { return zf_op_make_plan(d.op_h, d.op_w, d.op_k, false).grid; }
 
 // s[(cur + slot) % 3] = A x[(cur + slot) % 3] inside the loop (ctl given), or sout.p[0] = A xr.p[0] outside it (ctl NULL)
 static void zf_launch_apply_A(zf_solver* s, const zf_control* ctl, zf_ring3 xr, zf_ring3 sout, int slot) {
     const zf_problem_desc& d = s->desc;
     const int64_t n = d.n, m = d.m_rows;
     if (d.kind == ZF_PROBLEM_BLUR_HAAR_L1) {
-        hipLaunchKernelGGL(zf_op_apply_kernel<false>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, ctl), xr.p[0],
-                           xr.p[1], xr.p[2], sout.p[0], sout.p[1], sout.p[2], slot, zf_op_fuse());
+        zf_launch_op_apply(s->op_plan, s->stream, zf_op_of(s, ctl), xr.p[0], xr.p[1], xr.p[2], sout.p[0], sout.p[1], sout.p[2], slot,
+                           zf_op_no_fuse());
         return;
     }
     const int V = (n % 2 == 0) ? 2 : 1;
@@ -495,7 +530,7 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         const char* ae = getenv("ZF_AHEAD");
         s->ah = (ae ? atoi(ae) != 0 : true) && chains16 && s->nt;
         const char* ue = getenv("ZF_AHEAD_UNSHARDED");
-        s->ah_unsharded = s->ah && desc->world == 1 && !s->ra && (ue ? atoi(ue) != 0 : ZF_AHEAD_UNSHARDED_DEFAULT);
+        s->ah_unsharded = s->ah && desc->world == 1 && (ue ? atoi(ue) != 0 : ZF_AHEAD_UNSHARDED_DEFAULT);
     }
     if (s->ra || (s->ah && (desc->world > 1 || s->ah_unsharded))) {
         s->ring = 6;   // a pass never writes what its predecessor reads (zf_free_bufs)
@@ -541,8 +576,13 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         for (int k = 0; k < 3; ++k) s->sring.p[k] = s->sbuf + k * m_pad;
         ZF_TRY(hipMalloc(&s->resid, sizeof(double) * m_pad));
         ZF_TRY(hipMalloc(&s->ls_scal, sizeof(double) * 8));
-        ZF_TRY(hipMalloc(&s->row_part, sizeof(double) * 2 * zf_op_grid(*desc)));   // shares of |r(y)|^2 and of |s+ - b|^2
-        ZF_TRY(hipMemsetAsync(s->row_part, 0, sizeof(double) * 2 * zf_op_grid(*desc), s->stream));
+        if (zf_op_prepare(desc->op_taps, (int)desc->op_k, desc->op_h, desc->op_w, s->stream, &s->op_plan, &s->op_buf, &s->op_taps, &s->op_sep) != ZF_OK) {
+            zf_solver_free_all(s);
+            delete s;
+            return ZF_ERR_HIP;   // (message set by zf_op_prepare)
+        }
+        ZF_TRY(hipMalloc(&s->row_part, sizeof(double) * 2 * s->op_plan.grid));   // shares of |r(y)|^2 and of |s+ - b|^2
+        ZF_TRY(hipMemsetAsync(s->row_part, 0, sizeof(double) * 2 * s->op_plan.grid, s->stream));
         ZF_TRY(hipMalloc(&s->ls_cnt, 64));
         ZF_TRY(hipMemsetAsync(s->ls_cnt, 0, 64, s->stream));
     }
@@ -827,6 +867,7 @@ static int zf_ra_join(zf_solver* s) {
         s->ra_b_pending = false;
     }
     s->ra_last = s->ra_last2 = 0;
+    s->run_mode = 0;
     return ZF_OK;
 }
 
@@ -842,7 +883,7 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
     h.lr = before.lr;
     h.beta_next = 0.0;
     h.nit = before.nit;
-    bool chain = s->ra_last != 0 && a.pass_seq > s->ra_last;
+    bool chain = s->run_mode == 1 && s->ra_last != 0 && a.pass_seq > s->ra_last;
     if (chain) {   // what this pass writes, the pass in flight must not be reading (six buffers in ring order: it never is)
         int f0, f1;
         zf_free_bufs(h.cur, h.prev, h.ring, &f0, &f1);
@@ -883,6 +924,7 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
     if (e0) ZF_HIP(hipEventRecord(e0, st));
     zf_launch_s16_runahead(v, s->grid, st, a);
     if (e1) ZF_HIP(hipEventRecord(e1, st));
+    s->run_mode = 1;
     s->ra_last2 = chain ? s->ra_last : 0;
     s->ra_last = a.pass_seq;
     s->ra_last_idx = idx;
@@ -912,7 +954,7 @@ static int zf_launch_ahead(zf_solver* s, zf_step_args a, const zf_control& befor
     h.lr = before.lr;
     h.beta_next = 0.0;
     h.nit = before.nit;
-    bool chain = s->ra_last != 0 && a.pass_seq > s->ra_last;
+    bool chain = s->run_mode == 2 && s->ra_last != 0 && a.pass_seq > s->ra_last;
     if (chain) {   // what this pass writes, the pass before it must not be reading (six buffers in ring order: it never is)
         int f0, f1;
         zf_free_bufs(h.cur, h.prev, h.ring, &f0, &f1);
@@ -957,6 +999,7 @@ static int zf_launch_ahead(zf_solver* s, zf_step_args a, const zf_control& befor
     }
     ZF_HIP(hipEventRecord(s->ah_evD[k & 3], s->stream2));
     s->ra_b_pending = true;
+    s->run_mode = 2;
     s->ra_last2 = chain ? s->ra_last : 0;
     s->ra_last = a.pass_seq;
     s->ra_last_head = h;
@@ -1016,7 +1059,9 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         // at kernel granularity (through the library's communicator; ZF_AHEAD_UNSHARDED: other unsharded grids)
         const bool two_streams = s->stream2 != nullptr && !dry && !fin_kernel && !s->hist && s->shadow_valid;
         const bool ra_can = two_streams && s->ra && !s->ra_off && decide_in_launch && !s->comm;
-        const bool ah_can = two_streams && s->ah && !ra_can && s->ring >= 6 &&
+        // (unsharded: what the run-ahead kernel does not take - grids of several rounds, clipped problems, and on its own
+        //  grids the mid chains of a shared tail)
+        const bool ah_can = two_streams && s->ah && s->ring >= 6 &&
                             (s->comm ? !decide_in_launch : (decide_in_launch && s->ah_unsharded && d.world == 1));
         const bool have_before = ra_can || ah_can;
         if (have_before) before = s->shadow;
@@ -1026,8 +1071,8 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
                            before.ring_size == s->ring;
         const int nf_before = exact ? zf_fresh_len(&before) : 0;
         const bool ra_ok = ra_can && exact && s->part_mask == ZF_K_FULL && nf_before == s->sub && s->grid <= s->ra_cap;
-        const bool ah_ok = ah_can && exact && ((s->part_mask == ZF_K_FULL && nf_before == s->sub) ||
-                                               (s->part_mask == ZF_K_MID && nf_before == s->mid_len));
+        const bool ah_ok = ah_can && !ra_ok && exact && ((s->part_mask == ZF_K_FULL && nf_before == s->sub) ||
+                                                          (s->part_mask == ZF_K_MID && nf_before == s->mid_len));
         if (s->stream2 && a.pass_seq == 1 && !dry) {   // (the step counter started or wrapped: sequence numbers are compared)
             int rc = zf_ra_join(s);
             if (rc) return rc;
@@ -1114,13 +1159,14 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             // step's partials and decides (zf_op_fuse) - instead of resid_y / adjoint / prox / apply / resid_x / finalize
             zf_op_fuse F;
             memset(&F, 0, sizeof(F));
+            F.on = 1;
             F.b = d.b;
             for (int k = 0; k < 3; ++k) F.sk[k] = s->sring.p[k];
             F.scale = d.scale;
             F.lam = d.lam;
             F.nesterov = s->opt.nesterov;
             F.part_y = s->row_part;
-            F.part_x = s->row_part + zf_op_grid(d);
+            F.part_x = s->row_part + s->op_plan.grid;
             F.cnt = s->ls_cnt;
             F.blk_part = s->blk_part;
             F.grid_step = s->grid;
@@ -1129,16 +1175,15 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             F.ctl_rw = s->ctl;
             F.trace = s->trace;
             F.beta_ring = s->beta_ring;
-            hipLaunchKernelGGL(zf_op_adjoint_kernel<true>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, s->ctl),
-                               nullptr, s->grad, 2 * d.scale, F);
+            zf_launch_op_adjoint(s->op_plan, s->stream, zf_op_of(s, s->ctl), nullptr, s->grad, 2 * d.scale, F);
             a.p0 = s->grad;
             a.p1 = nullptr;
             if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
             zf_launch_trial_kernels(s, a, false);
             if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
             if (decide_in_launch) {
-                hipLaunchKernelGGL(zf_op_apply_kernel<true>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, s->stream, zf_op_of(d, s->ctl),
-                                   s->xb[0], s->xb[1], s->xb[2], s->sring.p[0], s->sring.p[1], s->sring.p[2], 1, F);
+                zf_launch_op_apply(s->op_plan, s->stream, zf_op_of(s, s->ctl), s->xb[0], s->xb[1], s->xb[2], s->sring.p[0], s->sring.p[1],
+                                   s->sring.p[2], 1, F);
             } else {   // (a host-driven step sequence: s+, f(x+) and the finalize launch as for a matrix)
                 zf_ring3 xr3 = {{s->xb[0], s->xb[1], s->xb[2]}};
                 zf_launch_apply_A(s, s->ctl, xr3, s->sring, 1);
@@ -1257,8 +1302,14 @@ static int zf_init_ls_tail(zf_solver* s) {
     const int64_t n = d.n, m = d.m_rows;
     zf_ring3 s0 = {{s->sring.p[0], s->sring.p[0], s->sring.p[0]}};
     ZF_HIP(hipMemcpyAsync(s->sring.p[2], s->sring.p[0], sizeof(double) * m, hipMemcpyDeviceToDevice, s->stream));
-    hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, nullptr, s0, -1, d.b, d.scale,
-                       m, s->ls_scal + 1);
+    if (m > (int64_t)1 << 18) {   // long residuals (the operator problem at image sizes beyond 512 x 512): two launches, many workgroups
+        const int wgs = zf_grid_for(m / 8);
+        hipLaunchKernelGGL(zf_resid_x_wide_kernel, dim3(wgs), dim3(ZF_BLOCK), 0, s->stream, s0.p[0], d.b, m, s->partials);
+        hipLaunchKernelGGL(zf_resid_x_finish_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, s->partials, wgs, d.scale, s->ls_scal + 1);
+    } else {
+        hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, s->stream, nullptr, s0, -1, d.b, d.scale,
+                           m, s->ls_scal + 1);
+    }
     const int g = zf_grid_for(n);
     if (s->box)
         hipLaunchKernelGGL((zf_eval_kernel<false, true>), dim3(g), dim3(ZF_BLOCK), 0, s->stream, s->xb[0], nullptr,
@@ -2084,8 +2135,11 @@ extern "C" int zf_op_eval(const double* taps_dev, int32_t k, const double* b_dev
     d.op_w = w;
     d.op_k = k;
     d.op_taps = taps_dev;
-    double *x = nullptr, *sv = nullptr, *grad = nullptr, *fdev = nullptr;
-    int rc = ZF_OK;
+    double *x = nullptr, *sv = nullptr, *grad = nullptr, *fdev = nullptr, *opbuf = nullptr;
+    zf_op_plan pl;
+    const double *taps = nullptr, *sep = nullptr;
+    int rc = zf_op_prepare(taps_dev, (int)k, h, w, nullptr, &pl, &opbuf, &taps, &sep);
+    if (rc) return rc;
 #define ZF_OP(expr)                                                               \
     do {                                                                          \
         hipError_t _e = (expr);                                                   \
@@ -2099,13 +2153,11 @@ extern "C" int zf_op_eval(const double* taps_dev, int32_t k, const double* b_dev
     if (rc == ZF_OK) {
         ZF_OP(hipMemcpyAsync(x, x_host, sizeof(double) * n, hipMemcpyHostToDevice, nullptr));
         zf_ring3 sr = {{sv, sv, sv}};
-        hipLaunchKernelGGL(zf_op_apply_kernel<false>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, nullptr, zf_op_of(d, nullptr), x, x, x,
-                           sv, sv, sv, -1, zf_op_fuse());
+        zf_launch_op_apply(pl, nullptr, zf_op_of(d, nullptr, pl, taps, sep), x, x, x, sv, sv, sv, -1, zf_op_no_fuse());
         hipLaunchKernelGGL(zf_resid_x_kernel, dim3(1), dim3(RESID_BLOCK), 0, nullptr, nullptr, sr, -1, b_dev, scale, n, fdev);
         if (grad_out_host) {
             hipLaunchKernelGGL(zf_axmb_kernel, dim3(zf_grid_for(n)), dim3(ZF_BLOCK), 0, nullptr, sv, b_dev, n);
-            hipLaunchKernelGGL(zf_op_adjoint_kernel<false>, dim3(zf_op_grid(d)), dim3(ZF_BLOCK), 0, nullptr, zf_op_of(d, nullptr), sv,
-                               grad, 2 * scale, zf_op_fuse());
+            zf_launch_op_adjoint(pl, nullptr, zf_op_of(d, nullptr, pl, taps, sep), sv, grad, 2 * scale, zf_op_no_fuse());
             ZF_OP(hipMemcpyAsync(grad_out_host, grad, sizeof(double) * n, hipMemcpyDeviceToHost, nullptr));
         }
         ZF_OP(hipGetLastError());
@@ -2113,7 +2165,7 @@ extern "C" int zf_op_eval(const double* taps_dev, int32_t k, const double* b_dev
         ZF_OP(hipStreamSynchronize(nullptr));
     }
 #undef ZF_OP
-    for (void* p : {(void*)x, (void*)sv, (void*)grad, (void*)fdev})
+    for (void* p : {(void*)x, (void*)sv, (void*)grad, (void*)fdev, (void*)opbuf})
         if (p) (void)hipFree(p);
     return rc;
 }

@@ -115,3 +115,59 @@ def solve_replicas(make_problem, starts, gpus=None, workers=None, quiet=True, **
     if errors:
         raise RuntimeError("\n".join(errors))
     return results
+
+
+def solve_on_streams(jobs, streams=None, quiet=True):
+    """Independent solves on ONE GPU at the same time: each job runs in a host thread of its own, on a HIP stream of its
+    own, so that solves too small to fill the device - a 256 x 256 deblurring problem is three launches of 128 workgroups
+    per iteration on a 256-CU chip - overlap instead of queueing behind each other.  The pattern of the reference's
+    notebook (``examples/cameraman.ipynb`` cell 11: ``joblib.Parallel`` over 15 momentum settings of one problem) without
+    processes: the problem's device arrays are shared, nothing is pickled.
+
+    ``jobs``: iterable of ``(callbacks, x0, kwargs)`` - ``callbacks`` the 4-tuple ``(f, g, jac_f, prox_wsum_g)`` (or an
+    object with ``callbacks()``); ``streams``: how many run at once (default: all jobs, at most 16).  Returns the results
+    in the order of ``jobs``; an exception in a job is raised here.  Solves are independent: every result equals the one
+    the same call gives alone."""
+    import threading
+
+    import torch
+
+    from .proximal_gradient import minimize_proximal_gradient
+
+    jobs = list(jobs)
+    width = max(1, min(len(jobs), int(streams) if streams else 16))
+    results, errors = [None] * len(jobs), []
+    lock = threading.Lock()
+    todo = list(range(len(jobs)))
+    device = torch.cuda.current_device()
+
+    def worker():
+        torch.cuda.set_device(device)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            while True:
+                with lock:
+                    if not todo or errors:
+                        return
+                    i = todo.pop(0)
+                cbs, x0, kw = jobs[i]
+                if hasattr(cbs, "callbacks"):
+                    cbs = cbs.callbacks()
+                try:
+                    with warnings.catch_warnings():
+                        if quiet:
+                            warnings.simplefilter("ignore")
+                        results[i] = minimize_proximal_gradient(*cbs, x0, **kw)
+                except Exception:   # reported to the caller, which raises
+                    with lock:
+                        errors.append(f"job {i}:\n{traceback.format_exc()}")
+                    return
+            torch.cuda.current_stream().synchronize()
+
+    threads = [threading.Thread(target=worker) for _ in range(width)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise RuntimeError("\n".join(errors))
+    return results
