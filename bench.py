@@ -67,8 +67,8 @@ ISA_PROFILE = "r02_isa_mix_trial_kernel_s{S}.json"
 # round 4: re-collected with the round's kernels (tools/profile_r4.sh); mid chains are keyed by their length
 # (round 5: "general" names the general body - part2, it read part1's counters, the short bodies'; mid chains are looked
 #  up by their length and report no counters when that length was not profiled)
-PMC_R3 = {"full": ("r04_pmc_defaults_k100_w10.json", "part0"), "mid": ("r04_pmc_driver_k20_w5.json", "part3_L{len}"),
-          "general": ("r04_pmc_defaults_k100_w10.json", "part2")}
+PMC_R3 = {"full": ("r05_pmc_defaults_k100_w10.json", "part0"), "mid": ("r05_pmc_driver_k20_w5.json", "part3_L{len}"),
+          "general": ("r05_pmc_defaults_k100_w10.json", "part2")}
 MID_MIN, MID_MAX = 9, 15   # trials of the branch-free mid chains (csrc/zf_kernels_step.h: ZF_MID_MIN .. ZF_MID_MAX), one kernel per length
 
 

@@ -428,8 +428,9 @@ typedef int (*zf_mo_exchange_fn)(void* ctx, double* vals, int32_t count, int32_t
 int zf_mo_set_shard(zf_mo* s, int64_t n_global, int64_t offset, zf_mo_exchange_fn fn, void* ctx);
 /* the same sharding over a communicator of the library instead of a callback: the totals of every reduction are
  * all-gathered on the stream and added in rank order on the device, and zf_mo_solve_dual exchanges once per BATCH
- * of its search (<= m + 1 points: ~3 collectives per trial) instead of once per dual evaluation.  The device-side
- * search (zf_mo_solve_dual_device / zf_mo_trial_launch) stays single-rank.  zf_mo_exchange_count: collectives so far. */
+ * of its search (<= m + 1 points: ~3 collectives per trial) instead of once per dual evaluation.  The persistent-kernel
+ * search (zf_mo_solve_dual_device / zf_mo_trial_launch) stays single-rank; zf_mo_solve_dual_stream is the device-driven
+ * search of a sharded x.  zf_mo_exchange_count: collectives so far. */
 int zf_mo_set_comm(zf_mo* s, zf_comm* comm, int64_t n_global, int64_t offset);
 int zf_mo_exchange_count(zf_mo* s, int64_t* count);
 /* per-coordinate box bounds (host arrays of n) instead of the scalar pair given at creation */
@@ -488,6 +489,14 @@ int zf_mo_dual_hessian(zf_mo* s, double lr, const double* w_host, double* H_out)
 int zf_mo_solve_dual(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
                      const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
                      int64_t* nit_out, int32_t* ok_out, int64_t* evals_out);
+/* (ABI 6) the same search for an x SHARDED over a library communicator (zf_mo_set_comm) with the state machine in DEVICE
+ * memory: a batch = evaluation kernel -> reduce -> ONE zf_comm_all_gather -> a one-wave kernel that adds the totals in rank
+ * order, composes D(w), grad D(w) (:165-177) and advances the machine; batches are enqueued back to back and the host looks
+ * once per six of them (zf_mo_solve_dual synchronises with the host once per batch).  What dual_solver="device" runs when x
+ * is sharded.  Arguments and results as zf_mo_solve_dual; zf_mo_recover follows. */
+int zf_mo_solve_dual_stream(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
+                            const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
+                            int64_t* nit_out, int32_t* ok_out, int64_t* evals_out);
 /* the same search and the primal recovery (:206, :510) inside ONE persistent kernel: the dual
  * evaluations run on register-resident (J, y), their sums are combined by a last-arriver reduction,
  * the solver's state machine advances on the device; f(x+), g(x+) (:295) come out of the same pass

@@ -175,6 +175,12 @@ def test_kernels_use_no_scratch_memory(tmp_path):
                     assert not ("scratch_" in line and depth >= 2), f"{name}: scratch access inside an element loop: {line.strip()}"
                 continue
             assert "zf_persist_kernel" not in name, "the multi-pass kernel was withdrawn from the product (tools/archive/)"
+            if "k_ds_advance" in name:
+                # the one-wave kernel that advances the dual state machine of a sharded device search between two
+                # all-gathers (zf_mo_solve_dual_stream): the solver step of m >= 4 spills as in k_dual_solve; it runs
+                # once per batch on 64 lanes - no element loop in it at all
+                assert size <= 8192, f"{name} uses {size} B of scratch per thread"
+                continue
             if "zf_runahead_kernel" not in name:
                 assert size == 0, f"{name} uses {size} B of scratch per thread"
                 continue

@@ -76,7 +76,9 @@ def test_bench_flags():
     assert "cpu_baseline" not in d and d["steps"] == 21
     assert d["config"]["rccl"] is None and d["config"]["overrides"] == {}
     # (21 iterations = two passes of 11 + 10 trials: no two full chains in a row, nothing runs ahead)
-    assert d["config"]["runahead"] == {"passes": 0, "launched_behind_a_pass_in_flight": 0}
+    assert d["config"]["runahead"] == {"passes": 0, "launched_behind_a_pass_in_flight": 0, "waits_that_gave_up": 0, "void_passes": 0,
+                                       "switched_off": False}
+    assert d["config"]["passes_ahead"] == {"launched": 0, "void": 0} and d["config"]["acceptance"] == "reference"
     regimes = d["config"]["iterations_per_sec_by_regime"]
     assert {"clean_regime_K20_W5", "clean_regime_K24_W5", "clean_regime_K28_W5", "clean_regime_K30_W5",
             "across_the_noise_floor_K100_W10"} <= set(regimes) and all(v > 0 for v in regimes.values())
@@ -85,6 +87,12 @@ def test_bench_flags():
     r = d["config"]["rccl"]
     assert r["via"].startswith("zf_comm (RCCL") and (r["world"], r["rank_count_seen"], r["rccl_user_rank"]) == (1, 1, 0)
     assert "rccl" in r["library"].lower() and r["exchanges_timed"] > 0 and 0.0 < r["exchange_ms_per_pass"] < 5.0
+    # (round 5) through a communicator the exactly predicted passes run AHEAD of their predecessor's decision: the line counts them
+    assert d["config"]["passes_ahead"]["launched"] >= 1 and d["config"]["passes_ahead"]["void"] == 0
+    # the acceptance test resolved below ulp(F): no trial of this workload is ever rejected, a K = 100 block is seven passes
+    d = _run("--no-cpu-baseline", "--no-regimes", "--steps", "100", "--warmup", "10", "--acceptance", "resolved")
+    assert d["config"]["acceptance"] == "resolved" and abs(d["config"]["passes_per_block"] - 7.0) < 1e-9
+    assert "ZF_ACCEPT_RESOLVED" in d["roofline"]["kernel"]
     d = _run("--no-cpu-baseline", "--total-n", "3000000")
     assert d["scaling"] == "strong" and d["config"]["n_total"] == 3000000
 

@@ -136,3 +136,33 @@ def test_resume_least_squares_is_bit_identical(nesterov):
     np.testing.assert_allclose(rows[:, _lib.TR_ERR], exp.allerrs, rtol=1e-9, atol=1e-300)
     np.testing.assert_allclose(rows[:, _lib.TR_F], exp.allfuns[1:], rtol=1e-10, atol=0)
     assert rel_err(run.solver.get_x(), exp.x) <= 1e-10
+
+
+def test_a_snapshot_carries_its_launch_geometry(monkeypatch):
+    """The tiles per workgroup decide the order of the reduced sums (knife-edge accept / reject decisions).  A snapshot says
+    which geometry it was taken with; a resume under another one (another build of the library; here: ZF_TILES_PER_WG) warns
+    and still continues with the same iterates."""
+    import warnings
+
+    from oracle import problems_ref as P
+    from zfista_amd.problems import DiagQuadL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    n = 3_000_001
+    d, c, lam = P.make_pdiag(n, seed=5)
+    prob = DiagQuadL1(d, c, lam)
+    o = BASE | dict(lr=0.45, nesterov=True, tol=0.0, max_iter=64)
+    first = NativeRun(prob, np.zeros(n), o)
+    first.advance(2)
+    state = first.snapshot()
+    assert int(state["tiles_per_wg"]) == first.solver.tiles_per_wg >= 2
+    first.solver.close()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        same = NativeRun.from_snapshot(prob, state, o)          # the same rule: no warning
+    want = (_drain(same), same.solver.get_x())[1]
+    monkeypatch.setenv("ZF_TILES_PER_WG", "1")
+    with pytest.warns(UserWarning, match="tiles per workgroup"):
+        other = NativeRun.from_snapshot(prob, state, o)
+    _drain(other)
+    assert np.array_equal(other.solver.get_x(), want)          # (clean regime: the iterates are elementwise arithmetic)

@@ -525,3 +525,86 @@ def test_after_rejections_a_pass_launches_the_two_shapes_it_can_need(world):
         # mispredicted steps are no-ops that cost a step each: a few, and far fewer kernels all the same
         assert steps_e <= steps_p <= steps_e + 8, (steps_e, steps_p)
         assert kernels_p <= 0.7 * kernels_e, (kernels_p, kernels_e)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["jos1_l1", "fds_l1", "fds_box", "jos1_l1_n1e5"])
+def test_sharded_multiobjective_device_driven_search(case, world, golden):
+    """Round 5 (SURVEY 8e row 3 + 8f-1): dual_solver="device" with x sharded over a library communicator.  The persistent
+    kernel of the single-rank device search cannot exchange between ranks; here the state machine lives in device memory
+    and a batch is evaluation -> reduce -> ONE all-gather -> a one-wave kernel that advances it (zf_mo_solve_dual_stream):
+    no host synchronisation per batch.  Thread ranks on this GPU.  Against the single-rank DEVICE solve of the same problem
+    (1e-9: the probing search here, the exact-Hessian search there - both converge to the optimum of the dual), against
+    the host-driven search of the same sharded problem (the same machine on the same numbers: bit for bit), all ranks
+    bit-identical, `dual_search_trials` says which search ran."""
+    import threading
+
+    import torch
+
+    from zfista_amd.comm import LibComm
+    from zfista_amd.problems import FDS, JOS1
+
+    if case == "jos1_l1":
+        n, tag, kw0 = 1000, "jos1_n1000_l1", dict(lr=1.0)
+        mk = lambda g: JOS1(n, l1_ratios=np.arange(1, 3) / n, l1_shifts=[0, 1], group=g)   # noqa: E731
+    elif case == "fds_l1":
+        n, tag, kw0 = 100, "fds_n100_l1", dict(lr=1e-3)
+        mk = lambda g: FDS(n, l1_ratios=np.arange(1, 4) / n, l1_shifts=[0, 1, 2], group=g)   # noqa: E731
+    elif case == "fds_box":
+        n, tag, kw0 = 103, None, dict(lr=1e-3)
+        mk = lambda g: FDS(n, bounds=(-1.5, 1.8), group=g)   # noqa: E731
+    else:
+        n, tag, kw0 = 100003, None, dict(lr=0.4 * 100003)
+        mk = lambda g: JOS1(n, l1_ratios=np.arange(1, 3) / n, l1_shifts=[0, 1], group=g)   # noqa: E731
+    kw = dict(nesterov=True, tol=1e-5, max_iter=12, return_all=True, **kw0)
+    G = golden("g4_multiobjective.npz")
+    x0 = G(f"{tag}.x0") if tag else np.random.default_rng(3).uniform(-1, 1, n)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = mk(None).minimize_proximal_gradient(x0, dual_solver="device", **kw)
+
+    def sharded(solver):
+        comms = LibComm.local_group(world, cap_doubles=4096)
+        out, errs = [None] * world, []
+
+        def rank_main(r):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    prob = mk(comms[r])
+                    lo, hi = prob.shard_bounds()
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        res = prob.minimize_proximal_gradient(x0[lo:hi], dual_solver=solver, **kw)
+                    torch.cuda.current_stream().synchronize()
+                    eng = prob._engine()
+                    out[r] = (res, eng.exchange_count(), eng.n_dual_evals, eng.n_exchanges)
+            except Exception as exc:   # pragma: no cover - reported below
+                errs.append(exc)
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        for c_ in comms:
+            c_.close()
+        assert not errs, errs
+        assert all(o is not None for o in out), "a rank thread did not finish"
+        return out
+
+    dev = sharded("device")
+    nat = sharded("native")
+    res0 = dev[0][0]
+    for (res, n_coll, n_dual, n_py), (resn, *_) in zip(dev, nat):
+        assert res.nit == res0.nit == full.nit and res.status == full.status
+        assert res["dual_search_trials"]["device"] >= res.nit and res["dual_search_trials"]["native"] == 0
+        assert np.array_equal(np.asarray(res.allerrs), np.asarray(res0.allerrs)), "ranks must agree bit for bit"
+        assert np.array_equal(np.stack(res.allfuns), np.stack(res0.allfuns))
+        assert n_py == 0 and n_dual > 0
+        # the same machine on the same numbers as the host-driven search of the sharded problem
+        assert resn.nit == res.nit and np.array_equal(np.stack(resn.allfuns), np.stack(res.allfuns))
+        assert all(np.array_equal(a, b) for a, b in zip(resn.allvecs, res.allvecs))
+    for k in range(res0.nit + 1):
+        xk = np.concatenate([o[0].allvecs[k] for o in dev])
+        assert np.linalg.norm(xk - full.allvecs[k]) <= 1e-9 * max(1.0, np.linalg.norm(full.allvecs[k])), k
+    np.testing.assert_allclose(np.stack(res0.allfuns), np.stack(full.allfuns), rtol=1e-9)

@@ -171,6 +171,9 @@ SIGNATURES = {
     "zf_mo_solve_dual": (C.c_int, [_P, C.c_double, _P, _P, C.c_int32, _P, C.c_double, C.c_int64, _P,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int64)]),
+    "zf_mo_solve_dual_stream": (C.c_int, [_P, C.c_double, _P, _P, C.c_int32, _P, C.c_double, C.c_int64, _P,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int64)]),
     "zf_mo_solve_dual_device": (C.c_int, [_P, C.c_double, _P, _P, C.c_int32, _P, C.c_double, C.c_int64, _P,
                                          C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int64), C.POINTER(C.c_double), _P, _P, _P]),

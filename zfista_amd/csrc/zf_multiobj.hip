@@ -1197,6 +1197,13 @@ struct zf_mo {
     double* cm_totals = nullptr;     // MO_CM_CAP: this rank's totals of the batch
     double* cm_gathered = nullptr;   // world x MO_CM_CAP, rank-major
     double* h_cm = nullptr;          // pinned host mirror of the combined totals
+    // the same search driven FROM THE DEVICE (zf_mo_solve_dual_stream): the state machine lives in device memory and is
+    // advanced by a one-wave kernel between stream-ordered all-gathers - no host round trip per batch
+    void* ds_state = nullptr;        // device: zf_dual::machine<m> (the largest, m = 8, fits)
+    void* h_ds_state = nullptr;      // pinned host mirror (upload of the started machine, download of the finished one)
+    double* ds_consts = nullptr;     // device: f_y[MO_MAX_M], F_old[MO_MAX_M] of the trial
+    double* h_ds_consts = nullptr;   // pinned staging of the same
+    int64_t ds_rounds = 0;           // batches enqueued so far (diagnostics / tests)
     int64_t n_exchanges = 0;         // collectives issued so far (diagnostics / tests)
     // device-side dual search (k_dual_solve): workspace, allocated at first use
     unsigned long long* solve_partials = nullptr;
@@ -1428,6 +1435,10 @@ extern "C" int zf_mo_destroy(zf_mo* s) {
     if (s->cm_totals) (void)hipFree(s->cm_totals);
     if (s->cm_gathered) (void)hipFree(s->cm_gathered);
     if (s->h_cm) (void)hipHostFree(s->h_cm);
+    if (s->ds_state) (void)hipFree(s->ds_state);
+    if (s->h_ds_state) (void)hipHostFree(s->h_ds_state);
+    if (s->ds_consts) (void)hipFree(s->ds_consts);
+    if (s->h_ds_consts) (void)hipHostFree(s->h_ds_consts);
     (void)hipFree(s->buf);
     (void)hipFree(s->partials);
     (void)hipFree(s->totals);
@@ -1729,6 +1740,235 @@ int mo_solve_dual_batched(zf_mo* s, double lr, const double* f_y, const double* 
     return ZF_OK;
 }
 }  // namespace
+
+// ---- the dual search on a SHARDED x without a host round trip per batch (dual_solver="device" through a library
+// communicator).  The persistent kernel of the single-rank device search (k_dual_solve) cannot exchange between ranks
+// from inside a launch; the host-driven search above synchronises with the host once per batch (~5 per trial).  Here the
+// state machine (zf_dual::machine<M>, the probing mode the host loop runs) lives in DEVICE memory; a round is
+//     k_ds_eval  (every point of the pending batch against this rank's share of J, y -> block partials)
+//     k_mo_reduce -> zf_comm_all_gather (ONE collective per batch) -> k_ds_advance (one wave: totals added in rank
+//     order, D(w) and grad D(w) composed as :165-177, the machine advanced, the next batch left in its place)
+// - all stream-ordered; ROUNDS of them are enqueued back to back (a round after the search has finished exits at once:
+// the machine says so) and the host looks once per chunk.  Every rank advances an identical copy on identical numbers.
+namespace {
+constexpr int MO_DS_CHUNK = 6;   // rounds enqueued between two looks of the host (a trial of cfg4 takes 4 - 5)
+
+template <int M>
+__global__ __launch_bounds__(ZF_BLOCK) void k_ds_eval(const double* __restrict__ J, const double* __restrict__ y, mo_g G,
+                                                      const zf_dual::machine<M>* mach, double lr, int64_t n, double* partials) {
+    constexpr int NQ = 2 * M + 2;
+    using mach_t = zf_dual::machine<M>;
+    __shared__ double lds[ZF_WAVES * NQ];
+    if (mach->phase == mach_t::P_DONE) return;
+    const int npts = mach->npts;
+    __shared__ mo_w sW;   // (in LDS: as a local its arrays - handed to mo_prox by address - went to scratch memory)
+    for (int k = 0; k < npts; ++k) {
+        if (threadIdx.x == 0) {   // mo_fill_w on the device: weight = lr w, coef = weight * l1_ratios (proximal_gradient.py:164, problems.py:127)
+            sW.lr = lr;
+            double tail = 0.0;
+#pragma unroll
+            for (int i = 0; i < MO_MAX_M; ++i) {
+                const double wi = i < M ? mach->pts[k][i < M ? i : 0] : 0.0;
+                sW.w[i] = wi;
+                sW.coef[i] = (i < M && G.has_l1) ? (lr * wi) * G.ratio[i] : 0.0;
+                if (i >= 1 && i < M) tail += sW.coef[i];
+            }
+            sW.tail_sum = tail;
+        }
+        __syncthreads();
+        const mo_w& W = sW;
+        double acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+        const int64_t stride = (int64_t)gridDim.x * ZF_BLOCK;
+        for (int64_t j = (int64_t)blockIdx.x * ZF_BLOCK + threadIdx.x; j < n; j += stride) {   // (k_dual_eval's element body)
+            double Jc[M];
+            double wJ = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                Jc[i] = J[(int64_t)i * n + j];
+                wJ += W.w[i] * Jc[i];
+            }
+            const double yj = y[j];
+            const double v = yj - W.lr * wJ;
+            const double p = mo_prox(G, W.coef, W.tail_sum, v, j);
+#pragma unroll
+            for (int i = 0; i < M; ++i) acc[i] += fabs(p - G.shift[i]);
+            const double dv = p - v;
+            acc[M] += dv * dv;
+            acc[M + 1] += wJ * wJ;
+            const double dy = p - yj;
+#pragma unroll
+            for (int i = 0; i < M; ++i) acc[M + 2 + i] += Jc[i] * dy;
+        }
+        const double maxs[1] = {0.0};
+        double out = 0.0;
+        zf_block_reduce<NQ, 0, ZF_WAVES>(acc, maxs, lds, out);
+        if (threadIdx.x < NQ) partials[(int64_t)(k * NQ + threadIdx.x) * gridDim.x + blockIdx.x] = out;
+        __syncthreads();   // (lds is reused by the next point)
+    }
+}
+
+struct mo_ds_consts {
+    double lr;
+    int deprecated, has_l1, world, pad;
+    double ratio[MO_MAX_M];
+};
+
+template <int M>
+__global__ __launch_bounds__(64) void k_ds_advance(zf_dual::machine<M>* g_mach, const double* __restrict__ gathered,
+                                                   const double* __restrict__ consts /* f_y, F_old */, mo_ds_consts C,
+                                                   long long* evals) {
+    constexpr int NQ = 2 * M + 2;
+    using mach_t = zf_dual::machine<M>;
+    constexpr int NB = mach_t::NB;
+    __shared__ double s_tot[NB * NQ];
+    __shared__ double s_fun[NB];
+    __shared__ double s_jac[NB][M];
+    __shared__ mach_t s_mach;
+    const int lane = threadIdx.x;
+    if (g_mach->phase == mach_t::P_DONE) return;
+    const int npts = g_mach->npts;
+    for (int q = lane; q < npts * NQ; q += 64) {   // this batch's totals of all ranks, added in RANK ORDER
+        double v = gathered[q];
+        for (int r = 1; r < C.world; ++r) v += gathered[(int64_t)r * (NB * NQ) + q];
+        s_tot[q] = v;
+    }
+    __syncthreads();
+    if (lane < NB) {   // D(w), grad D(w) of point `lane` as mo_dual_fn composes them (:165-177)
+        double f = 0.0, jac[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) jac[i] = 0.0;
+        if (lane < npts) {
+            const double* t = s_tot + lane * NQ;
+            double g_p[M], inner = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                g_p[i] = C.has_l1 ? C.ratio[i] * t[i] : 0.0;
+                inner += g_mach->pts[lane][i] * g_p[i];
+            }
+            const double n_pv = sqrt(t[M]), n_wJ = sqrt(t[M + 1]);
+            f = -inner - n_pv * n_pv / 2 / C.lr + C.lr / 2 * (n_wJ * n_wJ);
+#pragma unroll
+            for (int i = 0; i < M; ++i) jac[i] = -g_p[i] - t[M + 2 + i];
+            if (!C.deprecated) {
+                double corr = 0.0;
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    const double dF = consts[MO_MAX_M + i] - consts[i];
+                    corr += g_mach->pts[lane][i] * dF;
+                    jac[i] += dF;
+                }
+                f += corr;
+            }
+        }
+        s_fun[lane] = f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) s_jac[lane][i] = jac[i];
+    }
+    // (the whole wave steps the machine: the KKT systems of the simplex QP are solved lane-parallel on the device)
+    if (lane == 0) s_mach = *g_mach;
+    __syncthreads();
+    {
+        mach_t mach = s_mach;
+        mach.advance(*reinterpret_cast<const double(*)[NB]>(s_fun), *reinterpret_cast<const double(*)[NB][M]>(s_jac));
+        if (lane == 0) {
+            *g_mach = mach;
+            *evals += npts;
+        }
+    }
+}
+
+template <int M>
+int mo_solve_dual_stream(zf_mo* s, double lr, const double* f_y, const double* F_old, int deprecated, const double* w0, double tol,
+                         long max_iter, double* w_out, double* fun_out, long* nit_out, int* ok_out, int64_t* evals) {
+    constexpr int NQ = 2 * M + 2;
+    using mach_t = zf_dual::machine<M>;
+    constexpr int NB = mach_t::NB;
+    static_assert(NB * NQ <= MO_CM_CAP, "batch buffers too small");
+    static_assert(sizeof(mach_t) + 16 <= 8192, "the device blob holds the machine and the evaluation counter");
+    mach_t* hm = static_cast<mach_t*>(s->h_ds_state);
+    long long* h_evals = reinterpret_cast<long long*>(static_cast<char*>(s->h_ds_state) + 8192 - 16);
+    memset(s->h_ds_state, 0, 8192);
+    hm->start(w0, tol, max_iter);
+    *h_evals = 0;
+    for (int i = 0; i < MO_MAX_M; ++i) {
+        s->h_ds_consts[i] = i < M ? f_y[i] : 0.0;
+        s->h_ds_consts[MO_MAX_M + i] = i < M ? F_old[i] : 0.0;
+    }
+    ZF_HIP(hipMemcpyAsync(s->ds_state, s->h_ds_state, 8192, hipMemcpyHostToDevice, s->stream));
+    ZF_HIP(hipMemcpyAsync(s->ds_consts, s->h_ds_consts, sizeof(double) * 2 * MO_MAX_M, hipMemcpyHostToDevice, s->stream));
+    mo_ds_consts C;
+    C.lr = lr;
+    C.deprecated = deprecated;
+    C.has_l1 = s->G.has_l1;
+    C.world = s->comm_world;
+    C.pad = 0;
+    for (int i = 0; i < MO_MAX_M; ++i) C.ratio[i] = s->G.ratio[i];
+    mach_t* dm = static_cast<mach_t*>(s->ds_state);
+    long long* d_evals = reinterpret_cast<long long*>(static_cast<char*>(s->ds_state) + 8192 - 16);
+    // a search needs a handful of batches; max_iter Newton iterations bound it (2 batches each + the start)
+    const long cap = 2 * max_iter + 8;
+    for (long done_rounds = 0; done_rounds < cap;) {
+        for (int r = 0; r < MO_DS_CHUNK; ++r) {
+            hipLaunchKernelGGL(k_ds_eval<M>, dim3(s->grid), dim3(ZF_BLOCK), 0, s->stream, s->J, s->y, s->G, dm, lr, s->n, s->cm_partials);
+            hipLaunchKernelGGL(k_mo_reduce, dim3(1), dim3(64 * MO_RED_WAVES), 0, s->stream, s->cm_partials, s->grid, NB * NQ, -1,
+                               s->cm_totals);
+            ZF_HIP(hipGetLastError());
+            if (int rc = zf_comm_all_gather(s->comm, s->cm_totals, s->cm_gathered, NB * NQ, s->stream)) return rc;
+            s->n_exchanges += 1;
+            hipLaunchKernelGGL(k_ds_advance<M>, dim3(1), dim3(64), 0, s->stream, dm, s->cm_gathered, s->ds_consts, C, d_evals);
+            ZF_HIP(hipGetLastError());
+        }
+        done_rounds += MO_DS_CHUNK;
+        s->ds_rounds += MO_DS_CHUNK;
+        ZF_HIP(hipMemcpyAsync(s->h_ds_state, s->ds_state, 8192, hipMemcpyDeviceToHost, s->stream));
+        ZF_HIP(hipStreamSynchronize(s->stream));
+        if (hm->done()) break;
+    }
+    *evals += (int64_t)*h_evals;
+    if (!hm->done()) return zf_fail(ZF_ERR_STATE, "zf_mo_solve_dual_stream: the search did not finish within its round budget%s");
+    *ok_out = hm->ok;
+    for (int i = 0; i < M; ++i) w_out[i] = hm->w[i];
+    *fun_out = hm->fun;
+    *nit_out = hm->nit;
+    return ZF_OK;
+}
+}  // namespace
+
+// dual_solver="device" with x sharded over a library communicator (zf_mo_set_comm): the search of zf_mo_solve_dual with
+// the state machine on the device - ONE collective per batch, no host synchronisation per batch (MO_DS_CHUNK batches
+// per look).  Same arguments and results as zf_mo_solve_dual; x+ is NOT recovered here (zf_mo_recover follows).
+extern "C" int zf_mo_solve_dual_stream(zf_mo* s, double lr, const double* f_y, const double* F_old, int32_t deprecated,
+                                       const double* w0, double tol, int64_t max_iter, double* w_out, double* fun_out,
+                                       int64_t* nit_out, int32_t* ok_out, int64_t* evals_out) {
+    ZF_REQUIRE(s && f_y && F_old && w_out && fun_out && nit_out && ok_out, "zf_mo_solve_dual_stream: null argument");
+    ZF_REQUIRE(lr > 0.0 && max_iter >= 1, "zf_mo_solve_dual_stream: lr must be > 0 and max_iter >= 1");
+    ZF_REQUIRE(s->comm, "zf_mo_solve_dual_stream: needs a communicator (zf_mo_set_comm); single-rank solves take zf_mo_solve_dual_device");
+    if (int rc = mo_flush(s)) return rc;
+    if (!s->ds_state) {
+        ZF_HIP(hipMalloc(&s->ds_state, 8192));
+        ZF_HIP(hipHostMalloc(&s->h_ds_state, 8192, hipHostMallocDefault));
+        ZF_HIP(hipMalloc(&s->ds_consts, sizeof(double) * 2 * MO_MAX_M));
+        ZF_HIP(hipHostMalloc((void**)&s->h_ds_consts, sizeof(double) * 2 * MO_MAX_M, hipHostMallocDefault));
+    }
+    long nit = 0;
+    int ok = 1;
+    double fun = 0.0;
+    int64_t evals = 0;
+    int rc = ZF_ERR_ARG;
+    switch (s->m) {
+#define ZF_MO_STREAM(MM) case MM: rc = mo_solve_dual_stream<MM>(s, lr, f_y, F_old, (int)deprecated, w0, tol, (long)max_iter, w_out, &fun, &nit, &ok, &evals); break;
+        ZF_MO_STREAM(2) ZF_MO_STREAM(3) ZF_MO_STREAM(4) ZF_MO_STREAM(5) ZF_MO_STREAM(6) ZF_MO_STREAM(7) ZF_MO_STREAM(8)
+#undef ZF_MO_STREAM
+    }
+    if (evals_out) *evals_out = evals;
+    if (rc) return rc;
+    *fun_out = fun;
+    *nit_out = nit;
+    *ok_out = ok;
+    return ZF_OK;
+}
 
 // w0 may be NULL (uniform start).  *ok_out = 0: the start point is not finite (e.g. F(x_k) = inf
 // outside the box) - nothing was solved, use the reference's SciPy calls.  *evals_out counts the

@@ -98,10 +98,12 @@ class MoEngine:
         self._exchange_error = None
         from .comm import LibComm
 
+        self.libcomm = False   # exchanges through the library's communicator (zf_mo_set_comm)
         if isinstance(group, LibComm) and os.environ.get("ZF_MO_COMM", "lib") == "lib":
             # the library's own communicator: every reduction exchanges on the stream (all-gather + rank-ordered
             # sum on the device), zf_mo_solve_dual once per batch of its search - no Python per exchange
             _lib.check(self.lib.zf_mo_set_comm(h, group.handle, int(n_global), int(offset)), "zf_mo_set_comm")
+            self.libcomm = True
         elif group is not None:
             def exchange(_ctx, vals, count, max_index):
                 try:
@@ -219,6 +221,26 @@ class MoEngine:
                                        C.byref(nit), C.byref(ok), C.byref(evals))
         self.n_dual_evals += int(evals.value)
         self._check(rc, "zf_mo_solve_dual")
+        if not ok.value:
+            return None
+        return w, np.float64(fun.value), int(nit.value)
+
+    def solve_dual_stream(self, lr, f_y, F_old, deprecated, w0, tol, max_iter):
+        """The dual search of a trial for an x sharded over a library communicator, driven from the device
+        (zf_mo_solve_dual_stream): the state machine lives in device memory, a batch is evaluation -> reduce -> ONE
+        all-gather -> a one-wave kernel that advances the machine; no host synchronisation per batch.  Returns
+        (weight, fun, nit) or None when it was not attempted (non-finite start)."""
+        f_y = np.ascontiguousarray(f_y, dtype=np.float64)
+        F_old = np.ascontiguousarray(F_old, dtype=np.float64)
+        w0 = None if w0 is None else np.ascontiguousarray(w0, dtype=np.float64)
+        w = np.zeros(self.m)
+        fun, nit, ok, evals = C.c_double(0.0), C.c_int64(0), C.c_int32(0), C.c_int64(0)
+        rc = self.lib.zf_mo_solve_dual_stream(self.h, float(lr), C.c_void_p(_lib.ptr(f_y)), C.c_void_p(_lib.ptr(F_old)),
+                                              int(bool(deprecated)), None if w0 is None else C.c_void_p(_lib.ptr(w0)),
+                                              float(tol), int(max_iter), C.c_void_p(_lib.ptr(w)), C.byref(fun),
+                                              C.byref(nit), C.byref(ok), C.byref(evals))
+        self.n_dual_evals += int(evals.value)
+        self._check(rc, "zf_mo_solve_dual_stream")
         if not ok.value:
             return None
         return w, np.float64(fun.value), int(nit.value)
@@ -675,6 +697,13 @@ def solve_native(problem, x0, o):
                         searches["device"] += 1
                 if f_y is None:   # the device search was not attempted (non-finite start): fetch f(y)
                     f_y = eng.get_f_y()
+                if out is None and dual_solver == "device" and eng.libcomm:
+                    # x sharded over a library communicator: the same search driven from the device, one collective
+                    # per batch and no host round trip per batch (the persistent kernel is single-rank)
+                    out = eng.solve_dual_stream(lr, f_y, F_old, o["deprecated"], w0, o["tol_internal"],
+                                                o["max_iter_internal"])
+                    if out is not None:
+                        searches["device"] += 1
                 if out is None and use_native:   # the library's own dual solver: no Python between the evaluations
                     out = eng.solve_dual(lr, f_y, F_old, o["deprecated"], w0, o["tol_internal"],
                                          o["max_iter_internal"])

@@ -303,8 +303,11 @@ class NativeRun:
         if ctl.status == _lib.ZF_RUNNING and ctl.lag > 0:
             self.solver.flush()
             ctl, _ = self.solver.poll()
+        # (the launch geometry decides the order of the reduced sums, hence knife-edge accept / reject decisions: it travels
+        #  with the state so that a resume under another rule - another build of the library - can say so)
         return dict(x=self.solver.get_x(), x_prev=self.solver.get_x_prev(),
-                    control=np.frombuffer(bytes(ctl), dtype=np.uint8).copy())
+                    control=np.frombuffer(bytes(ctl), dtype=np.uint8).copy(),
+                    tiles_per_wg=np.int64(getattr(self.solver, "tiles_per_wg", 0) or 0))
 
     @classmethod
     def from_snapshot(cls, problem, state, opts, timing=False):
@@ -315,7 +318,14 @@ class NativeRun:
         if opts.get("return_all"):
             raise ValueError("return_all is not available for a solve resumed from a snapshot (the iterates before "
                              "the snapshot are not part of the saved state)")
-        return cls(problem, np.asarray(state["x"]), opts, timing=timing, _snapshot=state)
+        run = cls(problem, np.asarray(state["x"]), opts, timing=timing, _snapshot=state)
+        saved = int(np.asarray(state["tiles_per_wg"])) if "tiles_per_wg" in state else 0
+        now = int(getattr(run.solver, "tiles_per_wg", 0) or 0)
+        if saved and now and saved != now:
+            warn(f"the snapshot was taken with {saved} tiles per workgroup, this build runs the problem with {now}: the resumed "
+                 "solve computes the same iterates, but its sums are added in another order and accept / reject decisions at "
+                 "the resolution limit of the acceptance test may differ from the uninterrupted solve", stacklevel=2)
+        return run
 
     def _fill_beta(self, upto):
         """Upload momentum factors for accepted-iteration counts < upto."""
