@@ -270,19 +270,42 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
         // order depends on the grid only.
         __shared__ double s_red[6][ZF_WAVES];
         double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // |s+ - b|^2, |r(y)|^2, dot, ss, l1, max
+        // (16 shares per thread and trip, all loads of a trip issued before the first addition: 8192 workgroups are two trips,
+        //  not the 24 dependent round trips of four-at-a-time - this workgroup's reduction is the tail of the whole launch)
         const int NG = (int)gridDim.x;
-#pragma unroll 4
-        for (int g = tid; g < NG; g += ZF_BLOCK) {
-            acc[0] += zf_consume(F.part_x + g);
-            acc[1] += F.part_y[g];
+        for (int g0 = tid; g0 < NG; g0 += 16 * ZF_BLOCK) {
+            double px[16], py[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int g = g0 + u * ZF_BLOCK;
+                px[u] = g < NG ? zf_consume(F.part_x + g) : 0.0;
+                py[u] = g < NG ? F.part_y[g] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                acc[0] += px[u];
+                acc[1] += py[u];
+            }
         }
         const int64_t GS = F.grid_step;
-#pragma unroll 4
-        for (int64_t g = tid; g < GS; g += ZF_BLOCK) {
-            acc[2] += F.blk_part[1 * GS + g];
-            acc[3] += F.blk_part[2 * GS + g];
-            acc[4] += F.blk_part[3 * GS + g];
-            acc[5] = fmax(acc[5], F.blk_part[5 * GS + g]);
+        for (int64_t g0 = tid; g0 < GS; g0 += 8 * ZF_BLOCK) {
+            double q1[8], q2[8], q3[8], q5[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t g = g0 + u * ZF_BLOCK;
+                const bool in = g < GS;
+                q1[u] = in ? F.blk_part[1 * GS + g] : 0.0;
+                q2[u] = in ? F.blk_part[2 * GS + g] : 0.0;
+                q3[u] = in ? F.blk_part[3 * GS + g] : 0.0;
+                q5[u] = in ? F.blk_part[5 * GS + g] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc[2] += q1[u];
+                acc[3] += q2[u];
+                acc[4] += q3[u];
+                acc[5] = fmax(acc[5], q5[u]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
