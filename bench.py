@@ -318,9 +318,11 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
         barrier()
         torch.cuda.synchronize()
 
-    def measure(K, W, min_seconds, max_blocks):
+    def measure(K, W, min_seconds, max_blocks, acceptance=None):
         """Blocks of W untimed + K timed iterations (a fresh solve each) until min_seconds are timed."""
         o = dict(opts, max_iter=max(W, 1))
+        if acceptance:
+            o["acceptance"] = acceptance
         run = NativeRun(prob, x0, o, timing=timing)
         S = run.sub_iters
         m = dict(blocks=[], timed=0.0, full_ms=0.0, full_n=0, part_ms=0.0, part_n=0, part_fresh=0, part_lag=0, S=S,
@@ -409,6 +411,12 @@ def rank_body(args, rank, world, group, barrier, max_over_ranks, thread_ranks=0)
             d2 = statistics.median(m2["blocks"])
             regimes[tag] = (world * k2 / d2 * (n / N_PER_GPU)) if not args.total_n else k2 / d2
 
+    # ... and the noisy regime once more with the acceptance test resolved below ulp(F) (acceptance="resolved": the same
+    # inequality, f(x+) - f(y) accumulated element by element - no trial of this workload is rejected, 7 passes instead of 9)
+    if not args.no_regimes and args.acceptance == "reference":
+        m3 = measure(100, 10, 0.2, 60, acceptance="resolved")
+        d3 = statistics.median(m3["blocks"])
+        regimes["across_the_noise_floor_K100_W10_acceptance_resolved"] = (world * 100 / d3 * (n / N_PER_GPU)) if not args.total_n else 100 / d3
     line = None
     if rank == 0:
         n_gpus = 1 if thread_ranks else world

@@ -81,7 +81,8 @@ def test_bench_flags():
     assert d["config"]["passes_ahead"] == {"launched": 0, "void": 0} and d["config"]["acceptance"] == "reference"
     regimes = d["config"]["iterations_per_sec_by_regime"]
     assert {"clean_regime_K20_W5", "clean_regime_K24_W5", "clean_regime_K28_W5", "clean_regime_K30_W5",
-            "across_the_noise_floor_K100_W10"} <= set(regimes) and all(v > 0 for v in regimes.values())
+            "across_the_noise_floor_K100_W10", "across_the_noise_floor_K100_W10_acceptance_resolved"} <= set(regimes)
+    assert all(v > 0 for v in regimes.values())
     # the per-pass exchange through a REAL (1-rank) RCCL communicator: the line says what RCCL itself reports
     d = _run("--no-cpu-baseline", "--no-regimes", "--libcomm")
     r = d["config"]["rccl"]

@@ -128,3 +128,47 @@ def test_nan_input_propagates_like_the_reference(capsys):
     capsys.readouterr()
     assert res.success == exp.success is False and res.message == exp.message
     assert np.array_equal(res.x, exp.x)
+
+
+@pytest.mark.parametrize("seed", range(24 * SCALE))
+def test_fuzz_diag_quad_l1_resolved_acceptance(seed):
+    """The same random sweep with acceptance="resolved" against the oracle's restatement of that form
+    (oracle.cpu_ref.minimize_proximal_gradient(..., f_diff=): the sufficient-decrease test with F(x_k) and g(x+)
+    cancelled and f(x+) - f(y) formed element by element).  The resolved form does not stall where the reference's
+    does, so the runs are NOT cut at the stagnation point: nit, status, message, lr and trial sequences, chained and
+    single-trial solves, iterates bit for bit (the iterate arithmetic is NumPy's in both)."""
+    from oracle import cpu_ref, problems_ref as P
+    from zfista_amd import _lib, minimize_proximal_gradient
+    from zfista_amd.problems import DiagQuadL1
+    from zfista_amd.proximal_gradient import NativeRun
+
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([1, 2, 3, 7, 64, 255, 1024, 2049, 5000, 20011]))
+    d, c, lam = P.make_pdiag(n, seed=seed)
+    lam = float(rng.choice([0.0, 0.1, 1.5]))
+    o = _options(rng)
+    x0 = rng.standard_normal(n) * rng.choice([0.0, 1.0, 100.0])
+    prob, ref = DiagQuadL1(d, c, lam), P.DiagQuadL1Ref(d, c, lam)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, return_all=True, f_diff=ref.f_diff, **o)
+        res = minimize_proximal_gradient(*prob.callbacks(), x0, return_all=True, acceptance="resolved", **o)     # single trials
+        res16 = minimize_proximal_gradient(*prob.callbacks(), x0, acceptance="resolved", **o)                    # chains of 16
+    for r in (res, res16):
+        assert r.success == exp.success and r.message == exp.message, (r.message, exp.message)
+        assert r.nit == exp.nit and r.get("status") == exp.get("status") and r["acceptance"] == "resolved"
+        # (a knife-edge decision may still fall differently: the two sum f(x+) - f(y) in different orders - but the sums are
+        #  of the size of the step, and the sweep has not met one)
+        assert np.array_equal(r.x, exp.x)
+        np.testing.assert_allclose(r.fun, exp.fun, rtol=TOL, atol=0)
+    full = dict(max_iter_internal=100000, warm_start=False, verbose=False, return_all=False, acceptance="resolved") | o
+    run = NativeRun(prob, x0, full)
+    rows = [np.zeros((0, _lib.ZF_TRACE_COLS))]
+    while run.status == _lib.ZF_RUNNING:
+        rows.append(run.advance(3))
+    rows = np.concatenate(rows)
+    k = len(rows)
+    assert k == len(exp.alllrs[:k]) and (k == exp.nit or not exp.success)
+    assert np.array_equal(rows[:, _lib.TR_LR], np.asarray(exp.alllrs[:k], float))
+    assert np.array_equal(rows[:, _lib.TR_TRIALS].astype(np.int64), np.asarray(exp.alltrials[:k], np.int64))
+    run.solver.close()
