@@ -38,7 +38,17 @@ struct zf_op_args {
     int H, W, K;             // image size (even), kernel size as launched (odd, 3 .. ZF_OP_MAXK; zero-padded from the caller's)
     const double* taps;      // K x K, row-major
     const double* sep;       // NULL: general kernel; else u[ZF_OP_MAXK + 1] (rows) then v[ZF_OP_MAXK + 1] (columns): taps[i][j] = u[i] v[j]
+    int xcd_bands;           // != 0: workgroups that share an XCD (blockIdx % 8: the dispatcher deals workgroups round-robin) take a
+                             // contiguous band of tiles, so that the halo a tile shares with its neighbours is found in THAT L2
 };
+
+// tile of workgroup `b` of `nwg` (row-major tile order).  Banded: the bijective XCD remap of the programming guide (5.5 T1) -
+// a speed choice only: any bijection is correct, and nothing relies on which XCD a workgroup really runs on.
+__device__ __forceinline__ int zf_op_tile(int b, int nwg, int banded) {
+    if (!banded || nwg < 16) return b;
+    const int q = nwg / 8, r = nwg % 8, x = b % 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+}
 
 // The fused forms (inside the solver loop: three launches per trial instead of six; F.on != 0).
 // adjoint kernel: the residual at y is formed in the tile load - r = (s_k + beta (s_k - s_{k-1})) - b by linearity from
@@ -182,7 +192,8 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
     const double* __restrict__ x = idx == 0 ? x0 : idx == 1 ? x1 : x2;
     double* __restrict__ s = idx == 0 ? s0 : idx == 1 ? s1 : s2;
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
-    const int oy0 = ((int)blockIdx.x / tiles_x) * TY, ox0 = ((int)blockIdx.x % tiles_x) * ZF_OP_TX;
+    const int tile_id = zf_op_tile((int)blockIdx.x, (int)gridDim.x, P.xcd_bands);
+    const int oy0 = (tile_id / tiles_x) * TY, ox0 = (tile_id % tiles_x) * ZF_OP_TX;
     // tile load: one 2 x 2 block of W^-1 x per thread and round (tile origin and halo are even: blocks are whole); the
     // four coefficient loads of ALL rounds of a thread are issued before the first is used (a round per trip left one
     // memory latency per round on the critical path of a workgroup that holds two or three waves per SIMD)
@@ -366,7 +377,8 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
         beta = F.nesterov ? P.ctl->beta_next : 0.0;
     }
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
-    const int oy0 = ((int)blockIdx.x / tiles_x) * TY, ox0 = ((int)blockIdx.x % tiles_x) * ZF_OP_TX;
+    const int tile_id = zf_op_tile((int)blockIdx.x, (int)gridDim.x, P.xcd_bands);
+    const int oy0 = (tile_id / tiles_x) * TY, ox0 = (tile_id % tiles_x) * ZF_OP_TX;
     // tile load: the rows and columns the correlation reads (lanes along x: coalesced but for the mirrored edges), four
     // pixels - up to twelve loads - per thread in flight at a time
     {

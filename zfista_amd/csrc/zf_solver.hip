@@ -331,6 +331,8 @@ static zf_op_args zf_op_of(const zf_problem_desc& d, const zf_control* ctl, cons
     P.K = pl.K;
     P.taps = taps;
     P.sep = pl.sep ? sep : nullptr;
+    static const int bands = [] { const char* e = getenv("ZF_OP_XCD_BANDS"); return e ? atoi(e) : 1; }();
+    P.xcd_bands = bands;
     return P;
 }
 static zf_op_args zf_op_of(const zf_solver* s, const zf_control* ctl) { return zf_op_of(s->desc, ctl, s->op_plan, s->op_taps, s->op_sep); }
@@ -534,11 +536,12 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     }
     if (s->ra || (s->ah && (desc->world > 1 || s->ah_unsharded))) {
         s->ring = 6;   // a pass never writes what its predecessor reads (zf_free_bufs)
-        hipError_t e2 = zf_second_stream(s);
-        if (e2 != hipSuccess) {
-            zf_solver_free_all(s);
-            delete s;
-            return zf_fail(ZF_ERR_HIP, "zf_solver_create (second stream): %s", hipGetErrorString(e2));
+        // (no second stream - a runtime without stream priorities, an allocation that failed: every pass then runs on the
+        //  caller's stream, one launch at a time; nothing else depends on it)
+        if (zf_second_stream(s) != hipSuccess) {
+            (void)hipGetLastError();
+            s->ra = false;
+            s->ah = false;
         }
     }
     ZF_TRY(hipMalloc(&s->xbuf, sizeof(double) * s->ring * n_pad));
@@ -1654,7 +1657,10 @@ extern "C" int zf_solver_set_comm(zf_solver* s, zf_comm* comm) {
                 (void)hipGetLastError();   // (no room for two more iterates: the solve runs one pass at a time)
             }
         }
-        if (s->ring >= 6) ZF_HIP(zf_second_stream(s));
+        if (s->ring >= 6 && zf_second_stream(s) != hipSuccess) {
+            (void)hipGetLastError();
+            s->ah = false;   // (the sequence trial -> all-gather -> decide on the caller's stream, as without passes ahead)
+        }
     }
     return ZF_OK;
 }
