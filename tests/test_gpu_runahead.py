@@ -50,7 +50,7 @@ CASES = [
     (10007, dict(lr=0.45, nesterov=True, tol=0.0, max_iter=200), None),            # clean: long runs of full chains
     (10007, dict(lr=0.45, nesterov=False, tol=0.0, max_iter=333), None),
     (4099, dict(lr=0.45, nesterov=True, tol=0.0, max_iter=170), None),             # two workgroups + a remainder
-    (4099, dict(lr=0.45, nesterov=True, tol=0.0, max_iter=160), (-0.3, 0.4)),      # a box: one launch per pass (no run-ahead variant)
+    (4099, dict(lr=0.45, nesterov=True, tol=0.0, max_iter=160), (-0.3, 0.4)),      # a box: its own run-ahead kernels (full chains)
     (300001, dict(lr=0.45, nesterov=True, tol=1e-7, max_iter=5000), None),         # terminates inside a chain: the pass behind is void
     (300001, dict(lr=16.0, nesterov=True, tol=0.0, max_iter=150), None),           # rejections first, then chains
     (1_000_001, dict(lr=0.45, nesterov=True, nesterov_ratio=(0.5, 1 / 16), tol=0.0, max_iter=170), None),
@@ -72,15 +72,71 @@ def test_runahead_passes_equal_one_launch_per_pass(case, monkeypatch):
         got = _run(prob, x0, opts, chunk=chunk)
         _same(got, ref)
         passes, ahead = got["ra"]
-        if bounds is not None:
-            assert passes == 0   # (no run-ahead kernel for clipped problems: zf_solver_create)
-        elif chunk >= 2:
+        if chunk >= 2:
             assert passes >= 2 and ahead >= 1, "run-ahead passes were expected (a grid of <= 512 workgroups, full chains)"
         else:
             assert ahead == 0   # one step per call: nothing to run ahead of
     if n <= 2_000_003:
         one = _run(prob, x0, opts, sub=1)     # and both equal the one-trial-per-pass loop
         _same(one, ref)
+
+
+@pytest.mark.parametrize("max_iter,lengths", [(20, (10, 10)), (26, (13, 13)), (45, (16, 15, 14)), (58, (16, 16, 13, 13)),
+                                              (31, (16, 15)), (9, (9,)), (75, (16, 16, 16, 14, 13)), (23, (12, 11))])
+@pytest.mark.parametrize("nesterov", [True, False])
+def test_mid_chains_run_ahead_too(max_iter, lengths, nesterov, monkeypatch):
+    """The passes of a tail shared by two passes (K = 20 -> 10 + 10) and the tail itself are branch-free mid chains of
+    9 .. 15 trials: as run-ahead passes (zf_runahead_kernel<..., L>) they overlap like the full chains in front of them,
+    with the results of one launch per pass, bit for bit.  (n = 5e6: five tiles per workgroup - in the middle of the sizes at
+    which a run may START with a mid chain; at every one-round size a mid chain goes on a run that is in flight.)"""
+    n = 5_000_011
+    prob = _pdiag(n, seed=60 + max_iter)
+    opts = dict(lr=0.45, nesterov=nesterov, tol=0.0, max_iter=max_iter)
+    x0 = np.random.default_rng(max_iter).standard_normal(n)
+    monkeypatch.setenv("ZF_RUNAHEAD", "0")
+    ref = _run(prob, x0, opts)
+    assert ref["ra"] == (0, 0) and ref["nit"] == max_iter
+    clean = ref["trials"] == max_iter   # (no trial rejected: the passes are exactly `lengths`)
+    monkeypatch.delenv("ZF_RUNAHEAD")
+    got = _run(prob, x0, opts)
+    _same(got, ref)
+    if clean:
+        assert got["ra"] == (len(lengths), len(lengths) - 1), (got["ra"], lengths)   # every pass of the solve, mid chains included
+    got = _run(prob, x0, opts, chunk=3)
+    _same(got, ref)
+
+
+def test_where_a_run_starts_with_a_mid_chain(monkeypatch):
+    """Small grids: two launches on one stream cost less than the fork and join of two streams - a run does not start
+    with a mid chain there (it goes on with one: 16 + 15); the results are the same either way."""
+    n = 1_000_001
+    prob = _pdiag(n, seed=77)
+    for max_iter, want in ((20, (0, 0)), (31, (2, 1))):
+        opts = dict(lr=0.45, nesterov=True, tol=0.0, max_iter=max_iter)
+        monkeypatch.setenv("ZF_RUNAHEAD", "0")
+        ref = _run(prob, np.zeros(n), opts)
+        monkeypatch.delenv("ZF_RUNAHEAD")
+        got = _run(prob, np.zeros(n), opts)
+        _same(got, ref)
+        assert got["ra"] == want, (max_iter, got["ra"])
+
+
+@pytest.mark.parametrize("bounds", [(-0.3, 0.4), (0.0, np.inf)])
+def test_clipped_problems_run_ahead(bounds, monkeypatch):
+    """Box constraints: the full chains run ahead (their own kernels); tails take the general per-pass body (there are no
+    clipped mid chains), so a run of passes ends in front of them."""
+    n = 1_000_001
+    prob = _pdiag(n, seed=71, bounds=bounds)
+    opts = dict(lr=0.45, nesterov=True, tol=0.0, max_iter=106)   # 16 x 5, then 13 + 13
+    x0 = np.clip(np.random.default_rng(3).standard_normal(n), bounds[0], min(bounds[1], 10.0))
+    monkeypatch.setenv("ZF_RUNAHEAD", "0")
+    ref = _run(prob, x0, opts)
+    monkeypatch.delenv("ZF_RUNAHEAD")
+    for chunk in (64, 3):
+        got = _run(prob, x0, opts, chunk=chunk)
+        _same(got, ref)
+    got = _run(prob, x0, opts)
+    assert got["nit"] >= 64 and got["ra"][0] >= 4 and got["ra"][1] >= 3, (got["nit"], got["ra"])   # (a clipped solve may end before max_iter: an iterate that no longer moves)
 
 
 def test_runahead_is_not_used_beyond_the_resident_grid():

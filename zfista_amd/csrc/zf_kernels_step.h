@@ -514,7 +514,7 @@ __device__ __forceinline__ double zf_sum_rows(const double* rows, int count, boo
     return is_max ? acc : acc + comp;
 }
 
-template <int SP, bool RA = false>
+template <int SP, bool RA = false, int LEN = SP>   // LEN: fresh trials of a run-ahead pass (a full or a mid chain)
 __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double v) {
     constexpr int NQ = SP * ZF_NPART;
     __shared__ int s_role;
@@ -658,7 +658,7 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
             __builtin_amdgcn_wave_barrier();
             // belt and braces: the block IS what the host expected (by induction it is, if ok)
             ok = (c->status == ZF_RUNNING && c->pend_status == 0 && c->lag == 0 && c->nit == A.ra_head.nit &&
-                  c->lr == A.ra_head.lr && c->cur == A.ra_head.cur && c->prev == A.ra_head.prev && zf_fresh_len(c) == SP) ? 1 : 0;
+                  c->lr == A.ra_head.lr && c->cur == A.ra_head.cur && c->prev == A.ra_head.prev && zf_fresh_len(c) == LEN) ? 1 : 0;
         }
         ok = __builtin_amdgcn_readfirstlane(ok);
         unsigned good = (unsigned)W;
@@ -668,13 +668,13 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
             __builtin_amdgcn_wave_barrier();
             if (t < CW) __hip_atomic_store(gw + t, lw[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // as expected: every trial accepted, nothing terminated - the next pass's head is the one the host predicted
-            if (c->status == ZF_RUNNING && c->pend_status == 0 && c->lag == 0 && c->nit == A.ra_head.nit + SP && c->lr == A.ra_head.lr)
+            if (c->status == ZF_RUNNING && c->pend_status == 0 && c->lag == 0 && c->nit == A.ra_head.nit + LEN && c->lr == A.ra_head.lr)
                 good = (unsigned)A.pass_seq;
         }
         if (t == 0) {
             // the shape of the pass is logged HERE, by the one wave that knows whether the pass counted: a void pass
             // (shape 0) is no full chain in the host's statistics; a void pass is counted for the poll as well
-            if (A.pass_log) A.pass_log[A.pass_slot] = A.pass_tag | (ok ? zf_log_shape(0, SP, 0) : 0);
+            if (A.pass_log) A.pass_log[A.pass_slot] = A.pass_tag | (ok ? zf_log_shape(0, LEN, 0) : 0);
             if (!ok) __hip_atomic_fetch_add(A.ra_stats + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -858,8 +858,10 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
                                                 const int nf, zf_d2* stage = nullptr) {
     constexpr bool FULL = (MODE == 0);          // nothing replayed, S fresh trials
     static_assert(!RES || GRAD_INLINE, "resolved differences f(x+) - f(y): the separable problem");
-    static_assert(!COH || (FULL && !HIST && GRAD_INLINE && zf_uses_glds<S, MODE, HIST, GRAD_INLINE, SP>()),
-                  "coherent iterate traffic: the full chain through the DMA pipeline");
+    static_assert(!COH || (FULL && !HIST && GRAD_INLINE && SP >= 16 && ZF_S16_GLDS != 0),
+                  "coherent iterate traffic: branch-free chains of a 16-chain solver through the DMA pipeline");
+    // (a run-ahead mid chain of <= ZF_MID_REG_MAX trials takes the DMA pipeline too: the coherent 16-byte load exists as DMA only)
+    constexpr bool GLDS = COH || zf_uses_glds<S, MODE, HIST, GRAD_INLINE, SP>();
     const unsigned tidx = threadIdx.x;
     constexpr bool FRESH_FULL = (MODE <= 1);    // S fresh trials
     const int cur = HD.cur;
@@ -873,8 +875,12 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
     // momentum factor of the trial that produces iteration i + 1: ring[i % ZF_RING]; that of the
     // first trial of the pass was resolved into the control block by the previous decide step
     beta[0] = NESTEROV ? ((FULL || lag == 0) ? HD.beta_next : A.beta_ring[nit % ZF_RING]) : 0.0;
+    // (COH - a run-ahead pass: behind the atomics of its entry logic these wave-uniform loads are no longer provably
+    //  unclobbered, so they become VECTOR loads and the S factors live in 2 S vector registers - the clipped full chain then
+    //  needs 289 of 256; moved into scalar registers by hand they cost what they cost the per-pass kernels: none)
 #pragma unroll
-    for (int j = 1; j < S; ++j) beta[j] = NESTEROV ? A.beta_ring[(nit + j) % ZF_RING] : 0.0;
+    for (int j = 1; j < S; ++j)
+        beta[j] = NESTEROV ? (COH ? zf_uniform_f64(A.beta_ring[(nit + j) % ZF_RING]) : A.beta_ring[(nit + j) % ZF_RING]) : 0.0;
     const double tau = A.lam * lr;   // oracle: soft_threshold(x, lam * weight)
     // The lagging iterations' parameters, one iteration per LANE (lag <= 31 < 64): replay step i takes its three
     // doubles with v_readlane - no memory access inside the replay loop.  As wave-uniform scalar loads (one per step
@@ -995,7 +1001,7 @@ __device__ __forceinline__ double zf_trial_body(const zf_step_args& A, double* l
 #pragma unroll
         for (int u = 0; u < UB; ++u) advance(a[u], o[u], q[u], cc[u], first_unit + u * ZF_BLOCK);
     };
-    if constexpr (zf_uses_glds<S, MODE, HIST, GRAD_INLINE, SP>()) {
+    if constexpr (GLDS) {
         // LDS-DMA pipeline over this workgroup's units (tile-major, ZF_TILE_U units per tile): stage k % NST holds
         // unit k and NST - 1 units are in flight ahead of the one being computed (bytes in flight per CU = waves x
         // 4 KiB x (NST - 1): one unit ahead left the pipe latency-bound at n = 1e7, where a chain takes ~1 us).
@@ -1378,12 +1384,18 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
 // in buffers nobody reads (six iterate buffers: a pass never writes what its predecessor reads) - when pass p did not
 // go as expected; passes p and p + 2 share a stream, so pass p + 2 starts after pass p was decided and exits at once
 // (ra_need) if that went wrong.  Results are those of one launch per pass, bit for bit (tests/test_gpu_runahead.py).
-// (Held to two waves per SIMD like the full chain it is: with the entry logic in front of the chain the allocator
-//  otherwise takes 258 registers; capped it parks one 8-byte value in scratch across the tile loop, stored and loaded once.)
-template <bool NESTEROV, bool BOX, bool NT, bool RES = false>
+// (Two waves per SIMD: the full chains by their registers, the mid chains by the 48 KiB of DMA stages + 6 KiB of sums and
+//  blocks in LDS - three workgroups would need 54.3 KiB each.  Every variant, the clipped ones included, allocates what the
+//  per-pass kernel of the same chain does, now that the momentum factors are moved into scalar registers by hand: see
+//  zf_trial_body on COH.)
+// L: 0 - the full chain; ZF_MID_MIN .. ZF_MID_MAX - a branch-free mid chain of L trials (the passes of a tail shared by two
+// passes, the tail itself), through the same DMA pipeline.
+template <bool NESTEROV, bool BOX, bool NT, bool RES = false, int L = 0>
 __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void zf_runahead_kernel(zf_step_args A) {
     constexpr int S = ZF_MAX_SUB;
-    static_assert(S == 16, "run-ahead passes are full chains of 16");
+    static_assert(S == 16, "run-ahead passes are chains of a 16-chain solver");
+    static_assert(L == 0 || (L >= ZF_MID_MIN && L <= ZF_MID_MAX), "a full chain, or a mid chain of ZF_MID_MIN .. ZF_MID_MAX trials");
+    constexpr int LEN = L == 0 ? S : L;
     __shared__ double lds[ZF_WAVES * S * ZF_NPART];
     __shared__ zf_d2 stage[ZF_GLDS_NST * ZF_GLDS_STAGE_UNITS];
     __shared__ zf_control s_ctl;   // the deciding workgroup's copy of the control block
@@ -1394,7 +1406,7 @@ __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
         // nothing is in flight: the block is what an earlier launch left - checked as every per-pass kernel checks it
         const zf_control* c = A.ctl;
         const bool same = c->status == ZF_RUNNING && c->pend_status == 0 && c->lag == 0 && c->nit == HD.nit && c->lr == HD.lr &&
-                          c->cur == HD.cur && c->prev == HD.prev && zf_fresh_len(c) == S;
+                          c->cur == HD.cur && c->prev == HD.prev && zf_fresh_len(c) == LEN;
         if (!same) {   // (every workgroup finds the same) - decided: void; a pass launched behind this one must not wait for it
             if (b == 0 && threadIdx.x == 0) {
                 const unsigned long long W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1443,13 +1455,13 @@ __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
         return;
     }
     const bool run = go == 1;
-    HD.beta_next = NESTEROV ? A.beta_ring[HD.nit % ZF_RING] : 0.0;   // (zf_resolve_beta with nothing lagging)
+    HD.beta_next = NESTEROV ? zf_uniform_f64(A.beta_ring[HD.nit % ZF_RING]) : 0.0;   // (zf_resolve_beta with nothing lagging)
     double v = 0.0;
-    if (run) v = zf_trial_body<true, NESTEROV, BOX, NT, S, 0, false, S, true, RES>(A, lds, HD, 0, S, stage);
+    if (run) v = zf_trial_body<true, NESTEROV, BOX, NT, LEN, 0, false, S, true, RES>(A, lds, HD, 0, LEN, stage);
     zf_step_args T = A;   // decided on the deciding workgroup's own copy of the block
     T.ctl = A.ctl_rw;
     T.ctl_rw = &s_ctl;
-    zf_pass_tail<S, true>(T, v);
+    zf_pass_tail<S, true, LEN>(T, v);
 }
 
 // --- f(x), g(x) at a point (initial F(x0), proximal_gradient.py:466,472) -------

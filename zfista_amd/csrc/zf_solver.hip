@@ -239,7 +239,8 @@ struct zf_solver {
     // Run-ahead passes (zf_runahead_kernel): consecutive full chains of a grid the device holds at once go alternately
     // to `stream` and `stream2`; stream k has its own rows / group rows / counters / packs (two passes are in flight)
     bool ra = false;                      // eligible (separable f, chains of 16, one rank, a one-round grid) and not switched off (ZF_RUNAHEAD=0)
-    int ra_cap = -1;                      // co-resident workgroups of the run-ahead kernel (-1: not asked yet)
+    int ra_cap = -1;                      // co-resident workgroups of the run-ahead full chain (-1: not asked yet)
+    int ra_cap_mid[ZF_MAX_SUB_ITERS] = {};   // ... of the run-ahead mid chain of that length (0: no such kernel; asked at the first use: -1)
     unsigned ra_spin = 1u << 13;          // polls before a wait gives up (ZF_RUNAHEAD_SPIN_LIMIT): ~15 ms, some tens of passes' worth
     hipStream_t stream2 = nullptr;
     hipEvent_t ra_join = nullptr;         // stream2 -> stream at the end of a run of run-ahead passes
@@ -511,9 +512,8 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
     s->ring = s->sub > 1 ? 4 : 3;   // x_k, x_{k-1} + the one or two iterates a pass stores
     {   // passes that run ahead of their predecessor's decision (chains of 16 of the separable problem), two ways:
         // * run-ahead passes at WORKGROUP granularity (zf_runahead_kernel): one rank, a grid the device holds at once
-        //   (the geometry is a function of n; what the device holds of the kernel is asked of the runtime), no box (clipping
-        //   costs the chain the registers the entry logic needs - held to two waves per SIMD that variant reloads a spilled
-        //   value inside the tile loop);
+        //   (the geometry is a function of n; what the device holds of the kernel is asked of the runtime): full chains of
+        //   every variant, mid chains where the per-pass mid chains exist (no box);
         // * passes AHEAD at KERNEL granularity: every grid, boxes too; for sharded solves through the library's
         //   communicator (zf_solver_set_comm) and - ZF_AHEAD_UNSHARDED - unsharded grids the other scheme does not take.
         const char* e = getenv("ZF_RUNAHEAD");
@@ -523,11 +523,12 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         const int64_t grid = (s->ntiles + t - 1) / t;
         if (const char* l = getenv("ZF_RUNAHEAD_SPIN_LIMIT")) s->ra_spin = (unsigned)strtoul(l, nullptr, 10);
         const bool chains16 = desc->kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->sub >= 16 && !zf_fin_kernel_mode();
-        s->ra = on && chains16 && desc->world == 1 && !s->box;
+        s->ra = on && chains16 && desc->world == 1;
         if (s->ra) {
             const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt, s->res};
-            s->ra_cap = zf_runahead_capacity(v);
+            s->ra_cap = zf_runahead_capacity(v, s->sub);
             s->ra = grid <= s->ra_cap;
+            for (int l = 0; l < ZF_MAX_SUB_ITERS; ++l) s->ra_cap_mid[l] = -1;
         }
         const char* ae = getenv("ZF_AHEAD");
         s->ah = (ae ? atoi(ae) != 0 : true) && chains16 && s->nt;
@@ -769,6 +770,9 @@ static bool zf_fin_kernel_mode() {
 
 // grids of at most this many workgroups are latency-bound: a second (idle) launch per pass costs more than a slower body
 constexpr int ZF_SMALL_GRID = 64;
+// tiles per workgroup (a function of n: zf_tiles_for) between which a run of run-ahead passes may START with a mid chain
+constexpr int ZF_RA_MID_START_MIN_TILES = 4;    // n >= ~4e6
+constexpr int ZF_RA_MID_START_MAX_TILES = 12;   // n <= ~1.2e7
 
 // move the shadow control block past a pass on the assumption that every fresh trial is accepted and nothing
 // terminates but max_iter - true for whole chunks in the regime a line search settles in
@@ -877,7 +881,7 @@ static int zf_ra_join(zf_solver* s) {
 // A full chain the shadow predicts exactly, as a run-ahead pass (zf_runahead_kernel): behind another one of the same
 // run it goes to the other stream and starts while that one is still finalising.  `before`: the shadow control block
 // in front of this pass.
-static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& before, hipEvent_t e0, hipEvent_t e1) {
+static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& before, int nf, hipEvent_t e0, hipEvent_t e1) {
     const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt, s->res};
     zf_pass_head h;
     h.cur = before.cur;
@@ -891,7 +895,7 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
         int f0, f1;
         zf_free_bufs(h.cur, h.prev, h.ring, &f0, &f1);
         const zf_pass_head& q = s->ra_last_head;
-        if (f0 == q.cur || f0 == q.prev || f1 == q.cur || f1 == q.prev || h.nit != q.nit + s->sub) chain = false;
+        if (f0 == q.cur || f0 == q.prev || f1 == q.cur || f1 == q.prev || h.nit != q.nit + s->ah_last_nf) chain = false;
     }
     int idx = 0;
     if (!chain) {
@@ -925,9 +929,10 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
     }
     hipStream_t st = idx == 1 ? s->stream2 : s->stream;
     if (e0) ZF_HIP(hipEventRecord(e0, st));
-    zf_launch_s16_runahead(v, s->grid, st, a);
+    if (!zf_launch_s16_runahead(v, nf, s->grid, st, a)) return zf_fail(ZF_ERR_STATE, "zf_launch_runahead: no run-ahead kernel of that length%s");
     if (e1) ZF_HIP(hipEventRecord(e1, st));
     s->run_mode = 1;
+    s->ah_last_nf = nf;
     s->ra_last2 = chain ? s->ra_last : 0;
     s->ra_last = a.pass_seq;
     s->ra_last_idx = idx;
@@ -1073,7 +1078,20 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         const bool exact = have_before && before.status == ZF_RUNNING && before.lag == 0 && before.pend_status == 0 &&
                            before.ring_size == s->ring;
         const int nf_before = exact ? zf_fresh_len(&before) : 0;
-        const bool ra_ok = ra_can && exact && s->part_mask == ZF_K_FULL && nf_before == s->sub && s->grid <= s->ra_cap;
+        bool ra_ok = ra_can && exact && s->part_mask == ZF_K_FULL && nf_before == s->sub && s->grid <= s->ra_cap;
+        // A mid chain (the passes of a tail shared by two passes, the tail itself): its own kernel, its own capacity.  Behind a
+        // pass of the same run it always runs ahead (the alternative joins the two streams first).  A run that STARTS with
+        // one - blocks of K = 20: 10 + 10 - pays only in the middle of the one-round sizes (profiles/r05_runahead_mid_k20_by_size.jsonl:
+        // n = 4e6 .. 1e7 +2-3 %, with bench.py's events +4-7 %): below, two launches on one stream cost less than the fork and
+        // join of two; above, the chain of <= 10 trials is HBM-bound and its per-pass kernel loads through registers, 4 % faster
+        // than the DMA pipeline the coherent loads need.
+        const bool mid_run = s->run_mode == 1 && s->ra_last != 0;
+        if (ra_can && exact && !ra_ok && s->part_mask == ZF_K_MID && nf_before == s->mid_len && nf_before < ZF_MAX_SUB_ITERS &&
+            (mid_run || (s->tiles >= ZF_RA_MID_START_MIN_TILES && s->tiles <= ZF_RA_MID_START_MAX_TILES))) {
+            int& cap = s->ra_cap_mid[nf_before];
+            if (cap < 0) cap = zf_runahead_capacity(zf_trial_sel{s->opt.nesterov != 0, s->box, s->nt, s->res}, nf_before);
+            ra_ok = cap > 0 && s->grid <= cap;
+        }
         const bool ah_ok = ah_can && !ra_ok && exact && ((s->part_mask == ZF_K_FULL && nf_before == s->sub) ||
                                                           (s->part_mask == ZF_K_MID && nf_before == s->mid_len));
         if (s->stream2 && a.pass_seq == 1 && !dry) {   // (the step counter started or wrapped: sequence numbers are compared)
@@ -1092,7 +1110,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             s->kernels_issued += __builtin_popcount(shapes);
         }
         if (ra_ok) {
-            int rc = zf_launch_runahead(s, a, before, e0, e1);
+            int rc = zf_launch_runahead(s, a, before, nf_before, e0, e1);
             if (rc) return rc;
         } else if (ah_ok) {
             int rc = zf_launch_ahead(s, a, before, s->part_mask == ZF_K_FULL ? 0 : 3, nf_before, e0, e1);
@@ -1763,7 +1781,7 @@ static int zf_tiles_for(int64_t ntiles) {
     if (ntiles <= SLOTS) return 1;
     // (round 4) between one round of single-tile workgroups and 4096 tiles the same cost rule over T = 1 .. 8: whole
     // rounds here too - n = 2e6 runs ONE round of 489 workgroups of 2 tiles instead of two rounds of single tiles - and
-    // a grid the device holds at once, which is what lets several passes share a launch (zf_persist_kernel)
+    // a grid the device holds at once, which is what lets passes run ahead of each other (zf_runahead_kernel)
     const int t_lo = ntiles < 4096 ? 1 : 8, t_hi = ntiles < 4096 ? 8 : ZF_MAX_TILES_PER_WG;
     int best_t = t_lo;
     double best_cost = 0.0;

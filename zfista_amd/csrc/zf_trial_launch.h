@@ -25,9 +25,33 @@ bool zf_have_s16_mid(const zf_trial_sel& v, int len);
 void zf_launch_s16_ahead_full(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
 bool zf_launch_s16_ahead_mid(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a);
 void zf_launch_s16_tail(hipStream_t st, const zf_step_args& a);
-// the run-ahead full chain (zf_runahead_kernel) and the workgroups of it the device holds at once
-void zf_launch_s16_runahead(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
-int zf_runahead_capacity(const zf_trial_sel& v);
+// the run-ahead kernels (zf_runahead_kernel): len = 16 the full chain (every variant), ZF_MID_MIN .. ZF_MID_MAX a mid chain
+// (no box, nontemporal policy - where the per-pass mid chains exist); false / 0: no such kernel.  The capacity is the
+// number of workgroups of that kernel the device holds at once.
+bool zf_launch_s16_runahead(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a);
+int zf_runahead_capacity(const zf_trial_sel& v, int len);
+// ONE run-ahead kernel: launched (grid > 0: returns 1), or asked of the runtime how many of its workgroups the device
+// holds at once (grid == 0: returns that number, cached per kernel and process; 0 when it cannot be determined)
+template <bool N, bool B, bool NT, bool RES, int L>
+inline int zf_ra_kernel_op(int grid, hipStream_t st, const zf_step_args& a) {
+    if (grid > 0) {
+        hipLaunchKernelGGL((zf_runahead_kernel<N, B, NT, RES, L>), dim3(grid), dim3(ZF_BLOCK), 0, st, a);
+        return 1;
+    }
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zf_runahead_kernel<N, B, NT, RES, L>, ZF_BLOCK, 0) != hipSuccess) return 0;
+    cached = per_cu * prop.multiProcessorCount;
+    return cached;
+}
+// (by translation unit; -1: not one of its kernels)
+int zf_ra_op_mid_a(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a);
+int zf_ra_op_mid_b(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a);
+int zf_ra_op_res(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a);
+int zf_ra_op_res_mid(const zf_trial_sel& v, int len, int grid, hipStream_t st, const zf_step_args& a);
 // chains of 8 / 4 / 2 (part 0: full chain, part 1: every other shape) and single trials (S = 1, part 0)
 void zf_launch_chain(const zf_trial_sel& v, int S, int part, int grid, hipStream_t st, const zf_step_args& a);
 // history-recording kernels (streaming return_all; nontemporal policy only): separable S = 8 / 1, gradient vector S = 1
@@ -62,8 +86,6 @@ void zf_launch_vec(const zf_trial_sel& v, int grid, hipStream_t st, const zf_ste
 
 // ZF_ACCEPT_RESOLVED solvers (v.res): every launcher above forwards to these (zf_trial_res_*.hip)
 void zf_launch_res_full(const zf_trial_sel& v, bool ahead, int grid, hipStream_t st, const zf_step_args& a);
-void zf_launch_res_runahead(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
-int zf_res_runahead_capacity(const zf_trial_sel& v);
 void zf_launch_res_short(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
 void zf_launch_res_general(const zf_trial_sel& v, int grid, hipStream_t st, const zf_step_args& a);
 bool zf_launch_res_mid(const zf_trial_sel& v, bool ahead, int len, int grid, hipStream_t st, const zf_step_args& a);
