@@ -37,6 +37,7 @@ def main():
                 nesterov_ratio=(0, 0.25), deprecated=False, sub_iters=16, acceptance=args.acceptance)
     x0 = torch.zeros(n, dtype=torch.float64, device="cuda")
     rows = []
+    polls = []
     run = None
     for rep in range(args.reps):
         if run is None or run.nit_seen + K > 80:   # stay in front of the noise floor: a fresh solve every block
@@ -52,14 +53,19 @@ def main():
         t0 = time.perf_counter()
         run.enqueue_only((K + S - 1) // S)
         t1 = time.perf_counter()
-        run.collect()
+        run.solver.poll()            # (what collect() starts with: the library call alone)
+        tp = time.perf_counter()
+        run.collect()                # (a second poll on an idle stream + the host's bookkeeping)
         t2 = time.perf_counter()
+        polls.append((tp - t1, t2 - tp))
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         assert run.nit_seen - nit0 == K and run.status == _lib.ZF_MAXITER, (run.nit_seen - nit0, run.status)
         rows.append((t1 - t0, t2 - t1, t3 - t2, t3 - t0))
     a = np.array(rows[5:]) * 1e6
     med = np.median(a, axis=0)
+    pm = np.median(np.array(polls[5:]) * 1e6, axis=0)
+    print(json.dumps(dict(first_poll_us=round(float(pm[0]), 1), idle_poll_and_bookkeeping_us=round(float(pm[1]), 1))), file=sys.stderr)
     print(json.dumps(dict(n=n, K=K, events=bool(args.events), passes=(K + 15) // 16, enqueue_us=round(float(med[0]), 1),
                           collect_us=round(float(med[1]), 1), sync_us=round(float(med[2]), 1), block_us=round(float(med[3]), 1),
                           us_per_pass=round(float(med[3]) / ((K + 15) // 16), 1), it_per_s=round(K / med[3] * 1e6))))

@@ -512,8 +512,8 @@ __global__ __launch_bounds__(ZF_BLOCK) void k_dual_hessian(const double* __restr
 // batch.  Workgroup 0 polls the records of all workgroups (a torn or stale record fails the check and
 // is simply read again), adds them in workgroup-index order (sums; quantity max_index, if >= 0, a
 // maximum: deterministic, no float atomics) and publishes the totals the same way; every workgroup
-// polls the totals.  Two dependent memory round trips (records visible to workgroup 0, totals visible
-// to all) instead of the six of publish / ticket / gather / publish / flag / read: 12.5 -> ~4 us.
+// polls the totals, each thread its own.  Two dependent memory round trips (records visible to workgroup 0,
+// totals visible to all) instead of the six of publish / ticket / gather / publish / flag / read.
 // Records of batch e + 2 reuse the slots of batch e, which nobody can still need: a workgroup
 // publishes e + 2 only after it has read the totals of e + 1, which exist only after every workgroup
 // published e + 1, i.e. after every workgroup read the totals of e.
@@ -598,9 +598,11 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
                 }
             }
         }
-        // a wave with a lane that gave up publishes NO totals (sums over records that never arrived are not
-        // totals); the "totals are out" record below then says ABORT and no workgroup reads any of them
-        const bool wave_ok = *lds_flag != 0;   // (this wave's own give-up is visible to it; another wave's may be)
+        // Every wave of the reducer must have all of its records before ANY total goes out (sums over records that never
+        // arrived are not totals): the give-up flag settles at the barrier.  Then the totals - or, in slot 0, an ABORT
+        // record (the complemented key): every workgroup leaves the search at once instead of spinning to its own limit.
+        __syncthreads();
+        const bool all_ok = *lds_flag != 0;
 #pragma unroll
         for (int a = 0; a < QW; ++a) {
             const int q = wave + a * MO_SOLVE_WAVES;
@@ -609,39 +611,30 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
 #pragma unroll
             for (int c = 1; c < GL; ++c) v = is_max ? fmax(v, pv[a][c]) : v + pv[a][c];
             v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
-            if (wave_ok && lane == 0 && q < count) mo_put(totals + 2 * q, v, key);
+            if (all_ok && lane == 0 && q < count) mo_put(totals + 2 * q, v, key);
         }
-        // "totals are out" record, after them in program order (its readers validate every total anyway):
-        // 1 = read them, -1 = the reducer gave up - every workgroup leaves the search at once instead of
-        // spinning to its own limit
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // (two threads, one store each: a select between the two values in one thread made k_dual_solve<3>,
-        //  which sits at 256 VGPRs, spill 20 bytes per thread)
-        if (tid == 0 && *lds_flag) mo_put(totals + 2 * count, 1.0, key);
-        if (tid == 64 && !*lds_flag) mo_put(totals + 2 * count, -1.0, key);
+        if (!all_ok && tid == 0) mo_put(totals, 0.0, ~key);
     }
-    if (tid == 0) {   // ONE poller per workgroup (hundreds of threads spinning on three cache lines slow the writer down)
+    // Every workgroup: thread t < count polls ITS total - self-validating like the records, so no "totals are out" word in
+    // front of them and no second trip to memory behind it (round 5: one dependent trip fewer per hand-over, and the
+    // reducer no longer waits for its stores).  Slot 0 is read along with it: the reducer's ABORT.
+    if (tid < count) {
         unsigned spins = 0;
         double v = 0.0;
-        while (!mo_get(totals + 2 * count, key, &v)) {
+        for (;;) {
+            const mo_u64 lo = __hip_atomic_load(totals + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const mo_u64 hi = __hip_atomic_load(totals + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const mo_u64 lo0 = __hip_atomic_load(totals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const mo_u64 hi0 = __hip_atomic_load(totals + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((lo ^ hi) == key) {
+                v = __longlong_as_double((long long)lo);
+                break;
+            }
+            if ((lo0 ^ hi0) == ~key || ++spins > spin_limit) {
+                *lds_flag = 0;
+                break;
+            }
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > spin_limit) {
-                *lds_flag = 0;
-                break;
-            }
-        }
-        if (v < 0.0) *lds_flag = 0;   // the reducer's ABORT
-    }
-    __syncthreads();
-    if (tid < count && *lds_flag) {
-        unsigned spins = 0;
-        double v = 0.0;
-        while (!mo_get(totals + 2 * tid, key, &v)) {
-            if (++spins > spin_limit) {
-                *lds_flag = 0;
-                break;
-            }
         }
         lds_tot[tid] = v;
     }
