@@ -534,7 +534,9 @@ __device__ __forceinline__ bool mo_get(const mo_u64* rec, mo_u64 key, double* v)
 }
 
 // QW: quantities per wave of the reducer = ceil(largest count / waves)
-template <int QW>
+// LAST: the hand-over whose totals only workgroup 0 needs (the trial's result record): every other workgroup leaves behind
+// its records, workgroup 0 keeps the totals it has just added up - one trip to memory instead of two at the end of the kernel
+template <int QW, bool LAST = false>
 __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, count */, int count, int max_index,
                                                 mo_u64* partials /* [count][G] records */, mo_u64* totals /* [count + 1] */,
                                                 unsigned nonce, unsigned epoch, double* lds_tot, int* lds_flag,
@@ -611,9 +613,17 @@ __device__ __forceinline__ bool mo_grid_combine(const double* my_vals /* lds, co
 #pragma unroll
             for (int c = 1; c < GL; ++c) v = is_max ? fmax(v, pv[a][c]) : v + pv[a][c];
             v = is_max ? zf_wave_max(v) : zf_wave_sum(v);
-            if (all_ok && lane == 0 && q < count) mo_put(totals + 2 * q, v, key);
+            if (LAST) {
+                if (lane == 0 && q < count) lds_tot[q] = v;
+            } else if (all_ok && lane == 0 && q < count) {
+                mo_put(totals + 2 * q, v, key);
+            }
         }
-        if (!all_ok && tid == 0) mo_put(totals, 0.0, ~key);
+        if (!LAST && !all_ok && tid == 0) mo_put(totals, 0.0, ~key);
+    }
+    if constexpr (LAST) {
+        __syncthreads();
+        return *lds_flag != 0;
     }
     // Every workgroup: thread t < count polls ITS total - self-validating like the records, so no "totals are out" word in
     // front of them and no second trip to memory behind it (round 5: one dependent trip fewer per hand-over, and the
@@ -1098,7 +1108,7 @@ __global__ __launch_bounds__(MO_SOLVE_TPB) void k_dual_solve(mo_solve_args A) {
         }
         __syncthreads();
         const int parity = (int)(epoch & 1u);
-        if (!mo_grid_combine<(NT + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES>(s_mine, NT, 0, A.partials + 2 * ((int64_t)parity * REC_CAP * gridDim.x),
+        if (!mo_grid_combine<(NT + MO_SOLVE_WAVES - 1) / MO_SOLVE_WAVES, true>(s_mine, NT, 0, A.partials + 2 * ((int64_t)parity * REC_CAP * gridDim.x),
                              A.totals + 2 * (parity * REC_CAP), A.nonce, epoch, s_tot, &s_flag, A.spin_limit))
             timed_out = 1;
     }
