@@ -142,6 +142,54 @@ def test_beyond_the_notebook_size_and_every_kernel_path(variant, monkeypatch):
     assert rel_err(prob.jac_f(x), ref.jac_f(x)) <= 1e-12 and abs(prob.f(x)[0] - ref.f(x)[0]) <= 1e-12 * abs(ref.f(x)[0])
 
 
+@pytest.mark.parametrize("case", ["fista_line_search", "ista", "box", "non_square_k5", "tall_tiles_1024"])
+def test_prox_step_in_the_adjoint_kernel_equals_a_launch_of_its_own(case, monkeypatch):
+    """Round 5: the prox step of a trial rides in the epilogue of the adjoint kernel (two launches per trial; images of up
+    to 5 Mi pixels, no history ring).  ZF_OP_FUSE_PROX=0 is the three-launch trial: same iterates (the step is the same
+    expression on the same values - only the order in which its four sums are added differs), same decisions, and both equal
+    the oracle."""
+    from oracle import cpu_ref, operator_ref as O
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.problems import BlurHaarL1
+
+    rng = np.random.default_rng(11)
+    ksize, shape, bounds = 9, (64, 64), None
+    kw = dict(lr=40.0, nesterov=True, tol=1e-9, max_iter=60)   # rejections first: a retry runs the fused kernel again
+    if case == "ista":
+        kw = dict(lr=0.5, nesterov=False, tol=0.0, max_iter=40)
+    elif case == "box":
+        bounds = (-0.05, 0.4)
+    elif case == "non_square_k5":
+        ksize, shape = 5, (48, 160)
+    elif case == "tall_tiles_1024":
+        shape = (1024, 1024)
+        kw = dict(lr=0.9, nesterov=True, tol=0.0, max_iter=12)
+    kernel = O.gaussian_kernel(ksize, 2.0)
+    kernel = kernel / kernel.sum()
+    observed = rng.standard_normal(shape)
+    prob = BlurHaarL1(kernel, observed, 0.02, bounds=bounds)
+    x0 = O.dwt(observed)
+    if bounds is not None:
+        x0 = np.clip(x0, *bounds)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("ZF_OP_FUSE_PROX", fuse)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out[fuse] = minimize_proximal_gradient(*prob.callbacks(), x0, **kw)
+    a, b = out["1"], out["0"]
+    assert a.nit == b.nit and a.status == b.status
+    assert rel_err(a.x, b.x) <= 1e-13
+    np.testing.assert_allclose(np.asarray(a.fun), np.asarray(b.fun), rtol=1e-12)
+    if case != "tall_tiles_1024" and bounds is None:   # (the oracle's SciPy correlation at 1024 x 1024 takes its time; box: no oracle callbacks)
+        ref = O.BlurHaarL1Ref(kernel, observed, l1_ratio=0.02)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, **kw)
+        assert a.nit == exp.nit and a.status == exp.status
+        assert rel_err(a.x, exp.x) <= TOL
+
+
 def test_independent_solves_on_streams_equal_the_solves_alone():
     """zfista_amd.replicas.solve_on_streams: the notebook's sweep pattern (cameraman.ipynb cell 11: joblib over momentum
     settings) as host threads with a HIP stream each on ONE GPU - every result must be the one the same call gives alone."""

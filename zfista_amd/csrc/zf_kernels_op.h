@@ -29,6 +29,7 @@
 #pragma once
 #include "zf_common.h"
 #include "zf_decide.h"
+#include "zf_kernels_step.h"   // (zf_elem_vec: the prox step of a trial, fused into the adjoint kernel's epilogue)
 
 constexpr int ZF_OP_TX = 64;                    // output tile width of a workgroup (lanes run along x)
 constexpr int ZF_OP_MAXK = 15;                  // largest supported kernel size (odd)
@@ -50,9 +51,15 @@ __device__ __forceinline__ int zf_op_tile(int b, int nwg, int banded) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
 }
 
-// The fused forms (inside the solver loop: three launches per trial instead of six; F.on != 0).
+// The fused forms (inside the solver loop: two launches per trial instead of six; F.on != 0).
 // adjoint kernel: the residual at y is formed in the tile load - r = (s_k + beta (s_k - s_{k-1})) - b by linearity from
 // the cached B W^-1 x_k, B W^-1 x_{k-1} - and the workgroup's share of |r|^2 (its own tile, no halo) goes to part_y.
+// ... and (F.prox, round 5) the PROX STEP of the trial runs in its epilogue: the gradient of a 2 x 2 Haar block is in
+// registers there - x+ = prox(y - lr grad) is formed at its four coefficients from x_k, x_{k-1} (zf_elem_vec: the same
+// expression, the same bits as the separate launch), x+ is stored instead of the gradient, and the workgroup's shares of
+// <grad, x+ - y>, |x+ - y|^2, |x+|_1, max|x+ - y| go to step_part.  The gradient never exists in memory: a trial is
+// 48 + 40 bytes per pixel in two launches instead of 32 + 40 + 40 in three.  (A retry after a rejected trial runs the
+// adjoint again - need_grad is not consulted: rejections are rare, a third kernel in every trial is not.)
 // apply kernel: the workgroup's share of |s+ - b|^2 goes to part_x, and the LAST workgroup to arrive adds both in
 // workgroup order, adds the partials of the prox step, builds the pack and runs the decide pass (model value,
 // acceptance, lr decay, termination, buffer hand-over, trace row: proximal_gradient.py:149-155,:298-307,:510,:525,:539)
@@ -68,6 +75,14 @@ struct zf_op_fuse {
     unsigned* cnt;            // arrival counter of the fused apply kernel (zero between launches)
     const double* blk_part;   // the prox step's partials, quantity-major [6][grid_step]
     int grid_step;
+    // the prox step inside the adjoint kernel
+    int prox;                 // != 0: fused; blk_part then holds what THAT kernel wrote (step_part), grid_step = its grid
+    int box;
+    double lo, hi;
+    double* xb[3];            // the iterate ring (zf_solver::xb)
+    double* step_part;        // [6][workgroups of the adjoint kernel], quantities 1, 2, 3, 5 written
+    int* pass_log;            // timing mode: the trial's shape entry (zf_collect_timing), else NULL
+    int pass_slot, pass_tag;
     double* ls_scal;          // [0] f(y) [1] f(x+)
     double* pack;
     zf_control* ctl_rw;
@@ -366,7 +381,8 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
     __shared__ double tile[G::TILE_DOUBLES > TY * ZF_OP_TX ? G::TILE_DOUBLES : TY * ZF_OP_TX];   // later: the blurred tile
     __shared__ double tmp[SEP ? G::TMP_DOUBLES : 1];
     __shared__ double s_w[ZF_WAVES];
-    if (P.ctl && (P.ctl->status != ZF_RUNNING || !P.ctl->need_grad)) return;
+    const bool prox = F.on != 0 && F.prox != 0;
+    if (P.ctl && (P.ctl->status != ZF_RUNNING || (!prox && !P.ctl->need_grad))) return;
     const double* __restrict__ sk = nullptr;
     const double* __restrict__ so = nullptr;
     double beta = 0.0;
@@ -379,11 +395,47 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
     const int tile_id = zf_op_tile((int)blockIdx.x, (int)gridDim.x, P.xcd_bands);
     const int oy0 = (tile_id / tiles_x) * TY, ox0 = (tile_id % tiles_x) * ZF_OP_TX;
+    // The fused prox step (epilogue): a thread owns the 2 x 2 Haar blocks k = threadIdx.x + rd * 256 of the tile.  Their
+    // coefficients of x_k, x_{k-1} are fetched HERE, in front of the tile load: the loads then retire behind the
+    // correlation instead of standing, unhidden, at the end of a workgroup of three phases separated by barriers (fetched
+    // in the epilogue the fused kernel took as long as the two it replaced: 4096 x 4096, profiles/r05_operator_fuse_prox_ab.txt).
+    constexpr int BW = ZF_OP_TX / 2, BH = TY / 2, PR = (BW * BH + ZF_BLOCK - 1) / ZF_BLOCK;
+    const bool nest = F.on != 0 && F.nesterov != 0;
+    const double* __restrict__ xk = nullptr;
+    const double* __restrict__ xo = nullptr;
+    double* __restrict__ xn = nullptr;
+    double lr = 0.0, tau = 0.0;
+    double kv[PR][4], ov[PR][4];
+    if (prox) {   // the trial's head, as the separate prox launch reads it (zf_head_of; x+ goes to the first free buffer)
+        const int cur = P.ctl->cur, prev = P.ctl->prev;
+        int first, second;
+        zf_free_bufs(cur, prev, P.ctl->ring_size, &first, &second);
+        xk = F.xb[cur];
+        xo = F.xb[prev];
+        xn = F.xb[first];
+        lr = P.ctl->lr;
+        tau = F.lam * lr;
+        if (F.pass_log && blockIdx.x == 0 && threadIdx.x == 0) F.pass_log[F.pass_slot] = F.pass_tag | zf_log_shape(0, 1, 0);
+        const int64_t w2 = P.W / 2, q = (int64_t)(P.H / 2) * w2;
+#pragma unroll
+        for (int rd = 0; rd < PR; ++rd) {
+            const int k = (int)threadIdx.x + rd * ZF_BLOCK;
+            const int by = k / BW, bx = k % BW;
+            const int py = oy0 + 2 * by, px = ox0 + 2 * bx;
+            const bool in = k < BW * BH && py < P.H && px < P.W;
+            const int64_t at = in ? (int64_t)(py >> 1) * w2 + (px >> 1) : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                kv[rd][u] = xk[u * q + at];
+                ov[rd][u] = nest ? xo[u * q + at] : kv[rd][u];
+            }
+        }
+    }
     // tile load: the rows and columns the correlation reads (lanes along x: coalesced but for the mirrored edges), four
     // pixels - up to twelve loads - per thread in flight at a time
     {
         constexpr int OFF = G::HP - G::HALF, CW = ZF_OP_TX + 2 * G::HALF, TOTAL = G::TROWS * CW, BATCH = 4;
-        const bool fused = F.on != 0, nest = fused && F.nesterov;
+        const bool fused = F.on != 0;
         for (int k0 = threadIdx.x; k0 < TOTAL; k0 += BATCH * ZF_BLOCK) {
             double a0[BATCH], a1[BATCH], a2[BATCH];
 #pragma unroll
@@ -435,19 +487,51 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
         blurred[(rg * G::R + o) * ZF_OP_TX + c] = (oy0 + rg * G::R + o < P.H && ox0 + c < P.W) ? out[o] : 0.0;
     __syncthreads();
     // one Haar level of the tile: a thread owns 2 x 2 blocks (by, bx), bx along the lanes
-    constexpr int BW = ZF_OP_TX / 2, BH = TY / 2;
-    for (int k = threadIdx.x; k < BW * BH; k += ZF_BLOCK) {
+    zf_elem_acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int rd = 0; rd < PR; ++rd) {
+        const int k = (int)threadIdx.x + rd * ZF_BLOCK;
         const int by = k / BW, bx = k % BW;
         const int py = oy0 + 2 * by, px = ox0 + 2 * bx;
-        if (py < P.H && px < P.W) {
+        if (k < BW * BH && py < P.H && px < P.W) {
             const double a = blurred[(2 * by) * ZF_OP_TX + 2 * bx], b = blurred[(2 * by) * ZF_OP_TX + 2 * bx + 1];
             const double cc = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx], d = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx + 1];
             const int h = P.H / 2, w = P.W / 2;
             const int64_t q = (int64_t)h * w, at = (int64_t)(py >> 1) * w + (px >> 1);
-            grad[at] = two_scale * ((((a + b) + cc) + d) / 2);
-            grad[q + at] = two_scale * ((((a + b) - cc) - d) / 2);
-            grad[2 * q + at] = two_scale * ((((a - b) + cc) - d) / 2);
-            grad[3 * q + at] = two_scale * ((((a - b) - cc) + d) / 2);
+            double g[4];
+            g[0] = two_scale * ((((a + b) + cc) + d) / 2);
+            g[1] = two_scale * ((((a + b) - cc) - d) / 2);
+            g[2] = two_scale * ((((a - b) + cc) - d) / 2);
+            g[3] = two_scale * ((((a - b) - cc) + d) / 2);
+            if (prox) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    xn[u * q + at] = zf_elem_vec_rt(nest, F.box != 0, kv[rd][u], ov[rd][u], g[u], beta, lr, tau, F.lo, F.hi, acc);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) grad[u * q + at] = g[u];
+            }
+        }
+    }
+    if (prox) {   // this workgroup's shares of the step's sums: rows of the quantity-major table the apply kernel adds up
+        __syncthreads();   // (s_w was read by every thread after the |r|^2 sum; three more sums go through it)
+        const int64_t NG = gridDim.x;
+        const double dot = zf_op_block_sum(acc.dot, s_w);
+        __syncthreads();
+        const double ss = zf_op_block_sum(acc.ss, s_w);
+        __syncthreads();
+        const double l1 = zf_op_block_sum(acc.l1, s_w);
+        __syncthreads();
+        const double mw = zf_wave_max(acc.mx);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = mw;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mx = s_w[0];
+            for (int wv = 1; wv < ZF_WAVES; ++wv) mx = fmax(mx, s_w[wv]);
+            F.step_part[1 * NG + blockIdx.x] = dot;
+            F.step_part[2 * NG + blockIdx.x] = ss;
+            F.step_part[3 * NG + blockIdx.x] = l1;
+            F.step_part[5 * NG + blockIdx.x] = mx;
         }
     }
 }

@@ -93,6 +93,14 @@ __device__ __forceinline__ double zf_elem_vec(double xk, double xo, double grad,
     return xn;
 }
 
+// the same step with the variant chosen at run time (the operator problem's adjoint kernel runs it in its epilogue: one
+// kernel per blur size there, not per variant of the step)
+__device__ __forceinline__ double zf_elem_vec_rt(bool nesterov, bool box, double xk, double xo, double grad, double beta, double lr,
+                                                 double tau, double lo, double hi, zf_elem_acc& a) {
+    if (nesterov) return box ? zf_elem_vec<true, true>(xk, xo, grad, beta, lr, tau, lo, hi, a) : zf_elem_vec<true, false>(xk, xo, grad, beta, lr, tau, lo, hi, a);
+    return box ? zf_elem_vec<false, true>(xk, xo, grad, beta, lr, tau, lo, hi, a) : zf_elem_vec<false, false>(xk, xo, grad, beta, lr, tau, lo, hi, a);
+}
+
 // ---------------------------------------------------------------------------
 // launch geometry of the trial kernel (measured on MI355X, tools/tune_trial.hip,
 // n = 1e8: 0.66 ms = 6.05 TB/s for the streaming part; a capped grid-stride loop

@@ -770,6 +770,7 @@ static bool zf_fin_kernel_mode() {
 
 // grids of at most this many workgroups are latency-bound: a second (idle) launch per pass costs more than a slower body
 constexpr int ZF_SMALL_GRID = 64;
+constexpr int64_t ZF_OP_FUSE_MAX_PIXELS = int64_t(5) << 20;   // operator problem: the prox step rides in the adjoint kernel up to this size
 // tiles per workgroup (a function of n: zf_tiles_for) between which a run of run-ahead passes may START with a mid chain
 constexpr int ZF_RA_MID_START_MIN_TILES = 4;    // n >= ~4e6
 constexpr int ZF_RA_MID_START_MAX_TILES = 12;   // n <= ~1.2e7
@@ -1175,9 +1176,10 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         const int64_t nv = n / V;
         dim3 gT((unsigned)((nv + ZF_BLOCK - 1) / ZF_BLOCK), (unsigned)s->slices);
         if (d.kind == ZF_PROBLEM_BLUR_HAAR_L1) {
-            // THREE launches per trial (unsharded, deciding in the launch): the residual at y formed inside the adjoint
-            // kernel's tile load, the prox step, and s+ = B W^-1 x+ whose last workgroup sums f(y), f(x+) and the prox
-            // step's partials and decides (zf_op_fuse) - instead of resid_y / adjoint / prox / apply / resid_x / finalize
+            // TWO launches per trial (unsharded, deciding in the launch): the adjoint kernel - the residual at y formed in its
+            // tile load, the PROX STEP in its epilogue (round 5; ZF_OP_FUSE_PROX=0 or a history ring: a launch of its own
+            // in between) - and s+ = B W^-1 x+ whose last workgroup sums f(y), f(x+) and the prox step's partials and decides
+            // (zf_op_fuse) - instead of resid_y / adjoint / prox / apply / resid_x / finalize
             zf_op_fuse F;
             memset(&F, 0, sizeof(F));
             F.on = 1;
@@ -1196,12 +1198,37 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
             F.ctl_rw = s->ctl;
             F.trace = s->trace;
             F.beta_ring = s->beta_ring;
-            zf_launch_op_adjoint(s->op_plan, s->stream, zf_op_of(s, s->ctl), nullptr, s->grad, 2 * d.scale, F);
-            a.p0 = s->grad;
-            a.p1 = nullptr;
-            if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
-            zf_launch_trial_kernels(s, a, false);
-            if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+            static const bool fuse_env = [] {
+                const char* e = getenv("ZF_OP_FUSE_PROX");
+                return e ? atoi(e) != 0 : true;
+            }();
+            // (images whose six arrays - x_k, x_{k-1}, x+, the two cached B W^-1 x, b - no longer fit the 256 MB of memory-side
+            //  cache gain nothing: 3072^2 and 4096^2 -0.3 ... -0.7 %, the epilogue's 256-byte pieces of four coefficient
+            //  quadrants go to HBM at 0.56 of peak where the separate step streams at 0.74; up to 2048^2: +6 ... +16 %,
+            //  profiles/r05_operator_fuse_prox_ab.txt)
+            const bool fuse_prox = fuse_env && decide_in_launch && !s->hist && d.n <= ZF_OP_FUSE_MAX_PIXELS;
+            if (fuse_prox) {
+                F.prox = 1;
+                F.box = s->box ? 1 : 0;
+                F.lo = d.box_lo;
+                F.hi = d.box_hi;
+                for (int k = 0; k < 3; ++k) F.xb[k] = s->xb[k];
+                F.step_part = s->blk_part;
+                F.grid_step = s->op_plan.grid;
+                F.pass_log = a.pass_log;
+                F.pass_slot = a.pass_slot;
+                F.pass_tag = a.pass_tag;
+                if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
+                zf_launch_op_adjoint(s->op_plan, s->stream, zf_op_of(s, s->ctl), nullptr, s->grad, 2 * d.scale, F);
+                if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+            } else {
+                zf_launch_op_adjoint(s->op_plan, s->stream, zf_op_of(s, s->ctl), nullptr, s->grad, 2 * d.scale, F);
+                a.p0 = s->grad;
+                a.p1 = nullptr;
+                if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
+                zf_launch_trial_kernels(s, a, false);
+                if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
+            }
             if (decide_in_launch) {
                 zf_launch_op_apply(s->op_plan, s->stream, zf_op_of(s, s->ctl), s->xb[0], s->xb[1], s->xb[2], s->sring.p[0], s->sring.p[1],
                                    s->sring.p[2], 1, F);
