@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--check", type=int, default=0)
+    ap.add_argument("--k", type=int, default=0, help="another blur size (odd, 3 .. 15): a normalised Gaussian window, lr = 1/2")
+    ap.add_argument("--general", action="store_true", help="with --k: a rank-2 kernel (the general correlation path)")
     a = ap.parse_args()
     import torch
 
@@ -32,6 +34,14 @@ def main():
     from zfista_amd.problems import BlurHaarL1
 
     kernel, observed, x0, L = make_deblur(a.size)   # (the 9 x 9 Gaussian window of the notebook)
+    if a.k:
+        from oracle.operator_ref import gaussian_kernel
+
+        kernel = gaussian_kernel(a.k, 2.0)
+        if a.general:
+            kernel = kernel + 0.3 * np.outer(np.arange(a.k), np.ones(a.k)) / a.k
+        kernel = kernel / kernel.sum()
+        L = 2.0
     kw = dict(lr=1 / L, decay_rate=1, nesterov=True, tol=0.0)
     native = BlurHaarL1(kernel, observed, L1_RATIO)
     with warnings.catch_warnings():
@@ -46,7 +56,7 @@ def main():
     # per iteration: adjoint kernel reads s_k, s_{k-1}, b (24 B) and writes grad (8 B); prox step reads x_k, x_{k-1}, grad (24 B),
     # writes x+ (8 B); apply kernel reads x+ (8 B) and b (8 B), writes s+ (8 B)
     bytes_iter = 88 * n
-    out = {"workload": f"operator-form LASSO, {a.size} x {a.size}, 9 x 9 Gaussian window, FISTA, lr = 1/L, decay_rate = 1",
+    out = {"workload": f"operator-form LASSO, {a.size} x {a.size}, {kernel.shape[0]} x {kernel.shape[0]} {'rank-2 kernel' if a.general else 'Gaussian window'}, FISTA, lr = 1/L, decay_rate = 1",
            "n": n, "iterations": a.iters, "it_per_s": a.iters / dt, "ms_per_iteration": dt / a.iters * 1e3,
            "algorithmic_bytes_per_iteration": bytes_iter,
            "hbm_fraction_of_8TBps": bytes_iter / (dt / a.iters) / 8e12, "F_final": float(np.asarray(res.fun).reshape(-1)[0])}

@@ -48,8 +48,15 @@ for sub in ("fetch", "write", "lds"):
     for (k, _), d in per.items():
         # launches that found the solve finished and left at once are not the kernel (the median duration tells them apart)
         acc[k][f"{sub}:_all"].append(d)
+# (round 5: up to 5 Mi pixels the prox step rides in the adjoint kernel - no separate zf_trial_kernel in the loop: that kernel
+#  then also reads x_k, x_{k-1} and writes x+ in place of the gradient)
+fused = not any("fetch:_all" in d and len(d["fetch:_all"]) > 8 for k, d in acc.items() if k == "zf_trial_kernel")
+if fused:
+    KERNELS["zf_op_adjoint_kernel"] = "adjoint + prox step (W B r with the residual at y formed in the tile load; x+ = prox(y - lr grad) in the epilogue)"
+    MODEL["zf_op_adjoint_kernel"] = (24 + 16) * n + 8 * n
+    MODEL_READ["zf_op_adjoint_kernel"] = (24 + 16) * n
 mean = lambda v: sum(v) / len(v) if v else None   # noqa: E731
-res = {"image": f"{size} x {size}", "n": n, "kernels": {}, "units": "FETCH_SIZE / WRITE_SIZE in KiB; bytes = counter x 1024"}
+res = {"image": f"{size} x {size}", "n": n, "prox_step_fused_into_adjoint": fused, "kernels": {}, "units": "FETCH_SIZE / WRITE_SIZE in KiB; bytes = counter x 1024"}
 raw = {}
 for k, d in acc.items():
     e = {"what": KERNELS[k], "model_bytes_per_launch": MODEL[k]}

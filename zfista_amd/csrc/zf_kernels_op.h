@@ -39,6 +39,7 @@ struct zf_op_args {
     int H, W, K;             // image size (even), kernel size as launched (odd, 3 .. ZF_OP_MAXK; zero-padded from the caller's)
     const double* taps;      // K x K, row-major
     const double* sep;       // NULL: general kernel; else u[ZF_OP_MAXK + 1] (rows) then v[ZF_OP_MAXK + 1] (columns): taps[i][j] = u[i] v[j]
+    int tiles;               // tiles of the image (0: one per workgroup of the launch)
     int xcd_bands;           // != 0: workgroups that share an XCD (blockIdx % 8: the dispatcher deals workgroups round-robin) take a
                              // contiguous band of tiles, so that the halo a tile shares with its neighbours is found in THAT L2
 };
@@ -111,6 +112,17 @@ struct zf_op_geo {
     static constexpr int TMP_PITCH = ZF_OP_TX + 2;
     static constexpr int TILE_DOUBLES = LH * PITCH;
     static constexpr int TMP_DOUBLES = TROWS * TMP_PITCH;
+    // the next tile's loads in flight during the correlation of this one (registers: 24 in the apply kernel, up to 72 in the
+    // adjoint kernel).  Blur sizes above 9 x 9 have no room for them: with the prefetch their kernels fall to one wave per
+    // SIMD and lose up to half their rate (K = 15, general path, 4096 x 4096: 810 against 1 484 it/s).
+    // WALK: a workgroup walks several tiles (the host launches what the device holds at once).  Blur sizes above 9 x 9 keep a
+    // workgroup per tile: the loop costs their kernels a wave per SIMD (K = 13, general path, 4096 x 4096: 1 403 against 1 684 it/s).
+    static constexpr bool WALK = K <= 9;
+    static constexpr bool PREFETCH = WALK;
+#ifndef ZF_OP_ADJ_PREFETCH
+#define ZF_OP_ADJ_PREFETCH 0
+#endif
+    static constexpr bool PREFETCH_ADJ = PREFETCH && (ZF_OP_ADJ_PREFETCH != 0);
 };
 
 // The correlation of the staged tile: thread (c, rg) produces out[o] = (B tile)(row rg R + o, column c), o < R.
@@ -206,18 +218,25 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
     }
     const double* __restrict__ x = idx == 0 ? x0 : idx == 1 ? x1 : x2;
     double* __restrict__ s = idx == 0 ? s0 : idx == 1 ? s1 : s2;
+    // Tiles: a workgroup takes tiles v = blockIdx.x, blockIdx.x + gridDim.x, ... of the P.tiles the image has (round 5,
+    // second half: the host launches what the device holds at once).  A workgroup is three phases between barriers - tile
+    // load, correlation, stores - and then, fused, two dependent trips to memory for its share and its ticket: with a
+    // workgroup per tile every tile paid all of that as latency (2048 x 2048: 16 us in the life of a workgroup whose bytes
+    // need 2, 0.30 of HBM; profiles/r05_operator_pmc_2048x2048_one_tile_per_workgroup.json).  Now the coefficients of the
+    // NEXT tile are fetched into registers before the correlation of this one, shares are stored plainly, and the
+    // ticket is taken once.  Shares are indexed by v as before: the sums of the last arriver are the same sums.
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
-    const int tile_id = zf_op_tile((int)blockIdx.x, (int)gridDim.x, P.xcd_bands);
-    const int oy0 = (tile_id / tiles_x) * TY, ox0 = (tile_id % tiles_x) * ZF_OP_TX;
-    // tile load: one 2 x 2 block of W^-1 x per thread and round (tile origin and halo are even: blocks are whole); the
-    // four coefficient loads of ALL rounds of a thread are issued before the first is used (a round per trip left one
-    // memory latency per round on the critical path of a workgroup that holds two or three waves per SIMD)
-    {
-        const int h = P.H / 2, w = P.W / 2;
-        const int64_t q = (int64_t)h * w;
-        constexpr int BW = G::LW / 2, BH = G::LH / 2, ROUNDS = (BW * BH + ZF_BLOCK - 1) / ZF_BLOCK;
-        double cf[ROUNDS][4];
-        int par[ROUNDS];
+    const int NT = P.tiles > 0 ? P.tiles : (int)gridDim.x;
+    const int hh = P.H / 2, hw = P.W / 2;
+    const int64_t q = (int64_t)hh * hw;
+    constexpr int BW = G::LW / 2, BH = G::LH / 2, ROUNDS = (BW * BH + ZF_BLOCK - 1) / ZF_BLOCK;
+    double cf[ROUNDS][4];
+    int par[ROUNDS];
+    // one 2 x 2 block of W^-1 x per thread and round (tile origin and halo are even: blocks are whole); the four coefficient
+    // loads of ALL rounds of a thread are issued before the first is used
+    auto fetch = [&](int v) {
+        const int tile_id = zf_op_tile(v, NT, P.xcd_bands);
+        const int oy0 = (tile_id / tiles_x) * TY, ox0 = (tile_id % tiles_x) * ZF_OP_TX;
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             const int k = (int)threadIdx.x + rd * ZF_BLOCK;
@@ -226,13 +245,15 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
             const int r0 = zf_op_reflect(oy0 - G::HP + 2 * by, P.H), r1 = zf_op_reflect(oy0 - G::HP + 2 * by + 1, P.H);
             const int c0 = zf_op_reflect(ox0 - G::HP + 2 * bx, P.W), c1 = zf_op_reflect(ox0 - G::HP + 2 * bx + 1, P.W);
             // (mirrored blocks are whole blocks with their parities swapped; clamped ones - far outside - feed no output inside)
-            const int64_t at = (int64_t)(r0 >> 1) * w + (c0 >> 1);
+            const int64_t at = (int64_t)(r0 >> 1) * hw + (c0 >> 1);
             cf[rd][0] = x[at];
             cf[rd][1] = x[q + at];
             cf[rd][2] = x[2 * q + at];
             cf[rd][3] = x[3 * q + at];
             par[rd] = (r0 & 1) | ((r1 & 1) << 1) | ((c0 & 1) << 2) | ((c1 & 1) << 3);
         }
+    };
+    auto stage = [&]() {
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             const int k = (int)threadIdx.x + rd * ZF_BLOCK;
@@ -254,31 +275,44 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
                 dst[G::PITCH + 1] = pixel(pr1, pc1);
             }
         }
-    }
-    __syncthreads();
-    double out[G::R];
-    zf_op_correlate<K, TY, SEP>(P, tile, tmp, out);
+    };
     const int c = threadIdx.x & (ZF_OP_TX - 1), rg = threadIdx.x >> 6;
-    const int ox = ox0 + c;
-    double sq = 0.0;
+    int v = (int)blockIdx.x;
+    if (G::PREFETCH && v < NT) fetch(v);
+    for (; v < NT; v += (int)gridDim.x) {
+        const int tile_id = zf_op_tile(v, NT, P.xcd_bands);
+        const int oy0 = (tile_id / tiles_x) * TY, ox0 = (tile_id % tiles_x) * ZF_OP_TX;
+        if (!G::PREFETCH) fetch(v);
+        stage();
+        __syncthreads();
+        if (G::PREFETCH && v + (int)gridDim.x < NT) fetch(v + (int)gridDim.x);   // in flight during the correlation
+        double out[G::R];
+        zf_op_correlate<K, TY, SEP>(P, tile, tmp, out);
+        const int ox = ox0 + c;
+        double sq = 0.0;
 #pragma unroll
-    for (int o = 0; o < G::R; ++o) {
-        const int oy = oy0 + rg * G::R + o;
-        if (oy < P.H && ox < P.W) {
-            s[(int64_t)oy * P.W + ox] = out[o];
-            if (F.on) {
-                const double rv = out[o] - F.b[(int64_t)oy * P.W + ox];
-                sq = __builtin_fma(rv, rv, sq);
+        for (int o = 0; o < G::R; ++o) {
+            const int oy = oy0 + rg * G::R + o;
+            if (oy < P.H && ox < P.W) {
+                s[(int64_t)oy * P.W + ox] = out[o];
+                if (F.on) {
+                    const double rv = out[o] - F.b[(int64_t)oy * P.W + ox];
+                    sq = __builtin_fma(rv, rv, sq);
+                }
             }
         }
+        if (F.on) {
+            const double t = zf_op_block_sum(sq, s_w);
+            if (threadIdx.x == 0) zf_publish(F.part_x + v, t);
+        }
+        __syncthreads();   // the tile, the second array and s_w are free for the next tile
+        if constexpr (!G::WALK) break;
     }
     if (!F.on) return;
     {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const double t = zf_op_block_sum(sq, s_w);
         if (tid == 0) {
-            zf_publish(F.part_x + blockIdx.x, t);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the shares of this workgroup's tiles are out)
             const unsigned tk = __hip_atomic_fetch_add(F.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (tk == (unsigned)(gridDim.x - 1));
             if (last) {
@@ -298,7 +332,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
         double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // |s+ - b|^2, |r(y)|^2, dot, ss, l1, max
         // (16 shares per thread and trip, all loads of a trip issued before the first addition: 8192 workgroups are two trips,
         //  not the 24 dependent round trips of four-at-a-time - this workgroup's reduction is the tail of the whole launch)
-        const int NG = (int)gridDim.x;
+        const int NG = NT;
         for (int g0 = tid; g0 < NG; g0 += 16 * ZF_BLOCK) {
             double px[16], py[16];
 #pragma unroll
@@ -373,7 +407,9 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
 }
 
 // grad = 2 scale W (B r):  r an H x W image (the residual at y); skipped unless ctl->need_grad.  F.on: r is formed in
-// the tile load from the ring of B W^-1 x (zf_op_fuse), `r` is not read.
+// the tile load from the ring of B W^-1 x (zf_op_fuse), `r` is not read.  Tiles: as in the apply kernel - a workgroup walks
+// tiles v = blockIdx.x, + gridDim.x, ...; the three arrays of the NEXT tile are fetched into registers before the correlation of
+// this one.
 template <int K, int TY, bool SEP>
 __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, const double* __restrict__ r,
                                                                  double* __restrict__ grad, double two_scale, zf_op_fuse F) {
@@ -393,19 +429,16 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
         beta = F.nesterov ? P.ctl->beta_next : 0.0;
     }
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
-    const int tile_id = zf_op_tile((int)blockIdx.x, (int)gridDim.x, P.xcd_bands);
-    const int oy0 = (tile_id / tiles_x) * TY, ox0 = (tile_id % tiles_x) * ZF_OP_TX;
+    const int NT = P.tiles > 0 ? P.tiles : (int)gridDim.x;
+    const bool fused = F.on != 0, nest = fused && F.nesterov != 0;
     // The fused prox step (epilogue): a thread owns the 2 x 2 Haar blocks k = threadIdx.x + rd * 256 of the tile.  Their
-    // coefficients of x_k, x_{k-1} are fetched HERE, in front of the tile load: the loads then retire behind the
-    // correlation instead of standing, unhidden, at the end of a workgroup of three phases separated by barriers (fetched
-    // in the epilogue the fused kernel took as long as the two it replaced: 4096 x 4096, profiles/r05_operator_fuse_prox_ab.txt).
+    // coefficients of x_k, x_{k-1} are fetched at the TOP of a tile, in front of its correlation: the loads retire behind it
+    // instead of standing, unhidden, at the end (fetched in the epilogue the fused kernel took as long as the two it replaced).
     constexpr int BW = ZF_OP_TX / 2, BH = TY / 2, PR = (BW * BH + ZF_BLOCK - 1) / ZF_BLOCK;
-    const bool nest = F.on != 0 && F.nesterov != 0;
     const double* __restrict__ xk = nullptr;
     const double* __restrict__ xo = nullptr;
     double* __restrict__ xn = nullptr;
     double lr = 0.0, tau = 0.0;
-    double kv[PR][4], ov[PR][4];
     if (prox) {   // the trial's head, as the separate prox launch reads it (zf_head_of; x+ goes to the first free buffer)
         const int cur = P.ctl->cur, prev = P.ctl->prev;
         int first, second;
@@ -416,123 +449,169 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
         lr = P.ctl->lr;
         tau = F.lam * lr;
         if (F.pass_log && blockIdx.x == 0 && threadIdx.x == 0) F.pass_log[F.pass_slot] = F.pass_tag | zf_log_shape(0, 1, 0);
-        const int64_t w2 = P.W / 2, q = (int64_t)(P.H / 2) * w2;
+    }
+    const int64_t w2 = P.W / 2, q = (int64_t)(P.H / 2) * w2;
+    // the rows and columns the correlation reads (lanes along x: coalesced but for the mirrored edges): NB pixels - up to 3 NB
+    // loads - per thread, all of a tile in flight at once
+    constexpr int OFF = G::HP - G::HALF, CW = ZF_OP_TX + 2 * G::HALF, TOTAL = G::TROWS * CW, NB = (TOTAL + ZF_BLOCK - 1) / ZF_BLOCK;
+    double a0[G::PREFETCH_ADJ ? NB : 1], a1[G::PREFETCH_ADJ ? NB : 1], a2[G::PREFETCH_ADJ ? NB : 1];
+    auto fetch = [&](int v) {
+        const int tile_id = zf_op_tile(v, NT, P.xcd_bands);
+        const int oy0 = (tile_id / tiles_x) * TY, ox0 = (tile_id % tiles_x) * ZF_OP_TX;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int k = (int)threadIdx.x + u * ZF_BLOCK;
+            const int kk = k < TOTAL ? k : 0;
+            const int ly = kk / CW, lx = kk % CW;
+            const int iy = zf_op_reflect(oy0 - G::HALF + ly, P.H), ix = zf_op_reflect(ox0 - G::HALF + lx, P.W);
+            const int64_t at = (int64_t)iy * P.W + ix;
+            a0[u] = fused ? sk[at] : r[at];
+            a1[u] = nest ? so[at] : 0.0;
+            a2[u] = fused ? F.b[at] : 0.0;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int k = (int)threadIdx.x + u * ZF_BLOCK;
+            if (k < TOTAL) {
+                const int ly = k / CW, lx = k % CW;
+                double rv = a0[u];
+                if (fused) {
+                    if (nest) rv = rv + beta * (rv - a1[u]);   // B W^-1 y by linearity (zf_resid_y_kernel's expression)
+                    rv = rv - a2[u];
+                }
+                tile[(OFF + ly) * G::PITCH + OFF + lx] = rv;
+            }
+        }
+    };
+    const int c = threadIdx.x & (ZF_OP_TX - 1), rg = threadIdx.x >> 6;
+    const int64_t NG = NT;
+    int v = (int)blockIdx.x;
+    if constexpr (G::PREFETCH_ADJ)
+        if (v < NT) fetch(v);
+    for (; v < NT; v += (int)gridDim.x) {
+        const int tile_id = zf_op_tile(v, NT, P.xcd_bands);
+        const int oy0 = (tile_id / tiles_x) * TY, ox0 = (tile_id % tiles_x) * ZF_OP_TX;
+        double kv[PR][4], ov[PR][4];
+        if (prox) {
+#pragma unroll
+            for (int rd = 0; rd < PR; ++rd) {
+                const int k = (int)threadIdx.x + rd * ZF_BLOCK;
+                const int by = k / BW, bx = k % BW;
+                const int py = oy0 + 2 * by, px = ox0 + 2 * bx;
+                const bool in = k < BW * BH && py < P.H && px < P.W;
+                const int64_t at = in ? (int64_t)(py >> 1) * w2 + (px >> 1) : 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    kv[rd][u] = xk[u * q + at];
+                    ov[rd][u] = nest ? xo[u * q + at] : kv[rd][u];
+                }
+            }
+        }
+        if constexpr (G::PREFETCH_ADJ) {
+            stage();
+        } else {   // four pixels - up to twelve loads - per thread in flight at a time, staged as they arrive
+            constexpr int BATCH = 4;
+            for (int k0 = threadIdx.x; k0 < TOTAL; k0 += BATCH * ZF_BLOCK) {
+                double b0[BATCH], b1[BATCH], b2[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int k = k0 + u * ZF_BLOCK;
+                    const int kk = k < TOTAL ? k : 0;
+                    const int ly = kk / CW, lx = kk % CW;
+                    const int iy = zf_op_reflect(oy0 - G::HALF + ly, P.H), ix = zf_op_reflect(ox0 - G::HALF + lx, P.W);
+                    const int64_t at = (int64_t)iy * P.W + ix;
+                    b0[u] = fused ? sk[at] : r[at];
+                    b1[u] = nest ? so[at] : 0.0;
+                    b2[u] = fused ? F.b[at] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int k = k0 + u * ZF_BLOCK;
+                    if (k < TOTAL) {
+                        const int ly = k / CW, lx = k % CW;
+                        double rv = b0[u];
+                        if (fused) {
+                            if (nest) rv = rv + beta * (rv - b1[u]);
+                            rv = rv - b2[u];
+                        }
+                        tile[(OFF + ly) * G::PITCH + OFF + lx] = rv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (G::PREFETCH_ADJ)
+            if (v + (int)gridDim.x < NT) fetch(v + (int)gridDim.x);   // in flight during the correlation
+        if (F.on) {   // this tile's share of |r|^2: its own pixels (the halo belongs to the neighbours)
+            double sq = 0.0;
+#pragma unroll
+            for (int o = 0; o < G::R; ++o) {
+                if (oy0 + rg * G::R + o < P.H && ox0 + c < P.W) {
+                    const double rv = tile[(G::HP + rg * G::R + o) * G::PITCH + G::HP + c];
+                    sq = __builtin_fma(rv, rv, sq);
+                }
+            }
+            const double t = zf_op_block_sum(sq, s_w);
+            if (threadIdx.x == 0) F.part_y[v] = t;
+        }
+        double out[G::R];
+        zf_op_correlate<K, TY, SEP>(P, tile, tmp, out);
+        __syncthreads();   // every read of the tile is done: it becomes the blurred tile
+        double* blurred = tile;
+#pragma unroll
+        for (int o = 0; o < G::R; ++o)
+            blurred[(rg * G::R + o) * ZF_OP_TX + c] = (oy0 + rg * G::R + o < P.H && ox0 + c < P.W) ? out[o] : 0.0;
+        __syncthreads();
+        // one Haar level of the tile: a thread owns 2 x 2 blocks (by, bx), bx along the lanes
+        zf_elem_acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int rd = 0; rd < PR; ++rd) {
             const int k = (int)threadIdx.x + rd * ZF_BLOCK;
             const int by = k / BW, bx = k % BW;
             const int py = oy0 + 2 * by, px = ox0 + 2 * bx;
-            const bool in = k < BW * BH && py < P.H && px < P.W;
-            const int64_t at = in ? (int64_t)(py >> 1) * w2 + (px >> 1) : 0;
+            if (k < BW * BH && py < P.H && px < P.W) {
+                const double a = blurred[(2 * by) * ZF_OP_TX + 2 * bx], b = blurred[(2 * by) * ZF_OP_TX + 2 * bx + 1];
+                const double cc = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx], d = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx + 1];
+                const int64_t at = (int64_t)(py >> 1) * w2 + (px >> 1);
+                double g[4];
+                g[0] = two_scale * ((((a + b) + cc) + d) / 2);
+                g[1] = two_scale * ((((a + b) - cc) - d) / 2);
+                g[2] = two_scale * ((((a - b) + cc) - d) / 2);
+                g[3] = two_scale * ((((a - b) - cc) + d) / 2);
+                if (prox) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                kv[rd][u] = xk[u * q + at];
-                ov[rd][u] = nest ? xo[u * q + at] : kv[rd][u];
-            }
-        }
-    }
-    // tile load: the rows and columns the correlation reads (lanes along x: coalesced but for the mirrored edges), four
-    // pixels - up to twelve loads - per thread in flight at a time
-    {
-        constexpr int OFF = G::HP - G::HALF, CW = ZF_OP_TX + 2 * G::HALF, TOTAL = G::TROWS * CW, BATCH = 4;
-        const bool fused = F.on != 0;
-        for (int k0 = threadIdx.x; k0 < TOTAL; k0 += BATCH * ZF_BLOCK) {
-            double a0[BATCH], a1[BATCH], a2[BATCH];
+                    for (int u = 0; u < 4; ++u)
+                        xn[u * q + at] = zf_elem_vec_rt(nest, F.box != 0, kv[rd][u], ov[rd][u], g[u], beta, lr, tau, F.lo, F.hi, acc);
+                } else {
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int k = k0 + u * ZF_BLOCK;
-                const int kk = k < TOTAL ? k : 0;
-                const int ly = kk / CW, lx = kk % CW;
-                const int iy = zf_op_reflect(oy0 - G::HALF + ly, P.H), ix = zf_op_reflect(ox0 - G::HALF + lx, P.W);
-                const int64_t at = (int64_t)iy * P.W + ix;
-                a0[u] = fused ? sk[at] : r[at];
-                a1[u] = nest ? so[at] : 0.0;
-                a2[u] = fused ? F.b[at] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int k = k0 + u * ZF_BLOCK;
-                if (k < TOTAL) {
-                    const int ly = k / CW, lx = k % CW;
-                    double rv = a0[u];
-                    if (fused) {
-                        if (nest) rv = rv + beta * (rv - a1[u]);   // B W^-1 y by linearity (zf_resid_y_kernel's expression)
-                        rv = rv - a2[u];
-                    }
-                    tile[(OFF + ly) * G::PITCH + OFF + lx] = rv;
+                    for (int u = 0; u < 4; ++u) grad[u * q + at] = g[u];
                 }
             }
         }
-    }
-    __syncthreads();
-    const int c = threadIdx.x & (ZF_OP_TX - 1), rg = threadIdx.x >> 6;
-    if (F.on) {   // this workgroup's share of |r|^2: its own pixels (the halo belongs to the neighbours)
-        double sq = 0.0;
-#pragma unroll
-        for (int o = 0; o < G::R; ++o) {
-            if (oy0 + rg * G::R + o < P.H && ox0 + c < P.W) {
-                const double rv = tile[(G::HP + rg * G::R + o) * G::PITCH + G::HP + c];
-                sq = __builtin_fma(rv, rv, sq);
+        __syncthreads();   // (the blurred tile was read; s_w was read by every thread after the |r|^2 sum)
+        if (prox) {   // this tile's shares of the step's sums: rows of the quantity-major table the apply kernel adds up
+            const double dot = zf_op_block_sum(acc.dot, s_w);
+            __syncthreads();
+            const double ss = zf_op_block_sum(acc.ss, s_w);
+            __syncthreads();
+            const double l1 = zf_op_block_sum(acc.l1, s_w);
+            __syncthreads();
+            const double mw = zf_wave_max(acc.mx);
+            if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = mw;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double mx = s_w[0];
+                for (int wv = 1; wv < ZF_WAVES; ++wv) mx = fmax(mx, s_w[wv]);
+                F.step_part[1 * NG + v] = dot;
+                F.step_part[2 * NG + v] = ss;
+                F.step_part[3 * NG + v] = l1;
+                F.step_part[5 * NG + v] = mx;
             }
+            __syncthreads();   // s_w is free for the next tile
         }
-        const double t = zf_op_block_sum(sq, s_w);
-        if (threadIdx.x == 0) F.part_y[blockIdx.x] = t;
-    }
-    double out[G::R];
-    zf_op_correlate<K, TY, SEP>(P, tile, tmp, out);
-    __syncthreads();   // every read of the tile is done: it becomes the blurred tile
-    double* blurred = tile;
-#pragma unroll
-    for (int o = 0; o < G::R; ++o)
-        blurred[(rg * G::R + o) * ZF_OP_TX + c] = (oy0 + rg * G::R + o < P.H && ox0 + c < P.W) ? out[o] : 0.0;
-    __syncthreads();
-    // one Haar level of the tile: a thread owns 2 x 2 blocks (by, bx), bx along the lanes
-    zf_elem_acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int rd = 0; rd < PR; ++rd) {
-        const int k = (int)threadIdx.x + rd * ZF_BLOCK;
-        const int by = k / BW, bx = k % BW;
-        const int py = oy0 + 2 * by, px = ox0 + 2 * bx;
-        if (k < BW * BH && py < P.H && px < P.W) {
-            const double a = blurred[(2 * by) * ZF_OP_TX + 2 * bx], b = blurred[(2 * by) * ZF_OP_TX + 2 * bx + 1];
-            const double cc = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx], d = blurred[(2 * by + 1) * ZF_OP_TX + 2 * bx + 1];
-            const int h = P.H / 2, w = P.W / 2;
-            const int64_t q = (int64_t)h * w, at = (int64_t)(py >> 1) * w + (px >> 1);
-            double g[4];
-            g[0] = two_scale * ((((a + b) + cc) + d) / 2);
-            g[1] = two_scale * ((((a + b) - cc) - d) / 2);
-            g[2] = two_scale * ((((a - b) + cc) - d) / 2);
-            g[3] = two_scale * ((((a - b) - cc) + d) / 2);
-            if (prox) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    xn[u * q + at] = zf_elem_vec_rt(nest, F.box != 0, kv[rd][u], ov[rd][u], g[u], beta, lr, tau, F.lo, F.hi, acc);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) grad[u * q + at] = g[u];
-            }
-        }
-    }
-    if (prox) {   // this workgroup's shares of the step's sums: rows of the quantity-major table the apply kernel adds up
-        __syncthreads();   // (s_w was read by every thread after the |r|^2 sum; three more sums go through it)
-        const int64_t NG = gridDim.x;
-        const double dot = zf_op_block_sum(acc.dot, s_w);
-        __syncthreads();
-        const double ss = zf_op_block_sum(acc.ss, s_w);
-        __syncthreads();
-        const double l1 = zf_op_block_sum(acc.l1, s_w);
-        __syncthreads();
-        const double mw = zf_wave_max(acc.mx);
-        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = mw;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double mx = s_w[0];
-            for (int wv = 1; wv < ZF_WAVES; ++wv) mx = fmax(mx, s_w[wv]);
-            F.step_part[1 * NG + blockIdx.x] = dot;
-            F.step_part[2 * NG + blockIdx.x] = ss;
-            F.step_part[3 * NG + blockIdx.x] = l1;
-            F.step_part[5 * NG + blockIdx.x] = mx;
-        }
+        if constexpr (!G::WALK) break;
     }
 }
 
@@ -550,5 +629,7 @@ void zf_launch_op_apply(const zf_op_plan& pl, hipStream_t st, const zf_op_args& 
                         double* s0, double* s1, double* s2, int slot, const zf_op_fuse& F);
 void zf_launch_op_adjoint(const zf_op_plan& pl, hipStream_t st, const zf_op_args& P, const double* r, double* grad, double two_scale,
                           const zf_op_fuse& F);
+bool zf_op_persist();
+int zf_op_resident(const void* kernel, int* cache);
 // rank-1 test of a K x K kernel (host arrays): on success u[K], v[K] with |k[i][j] - u[i] v[j]| <= 1e-14 max |k|
 bool zf_op_factor_rank1(const double* taps, int k, double* u, double* v);

@@ -1,10 +1,20 @@
 // zf_op_adjoint.hip - instantiations of zf_op_adjoint_kernel (W B r)
 #include "zf_kernels_op.h"
 
+template <int K, int TY, bool SEP>
+static int adjoint_wgs(int tiles) {   // (zf_op_apply.hip: the tiles, or what the device holds of this kernel at once)
+    static int cache = -1;
+    if (!zf_op_geo<K, TY>::WALK || !zf_op_persist()) return tiles;
+    const int r = zf_op_resident(reinterpret_cast<const void*>(zf_op_adjoint_kernel<K, TY, SEP>), &cache);
+    return (r > 0 && tiles > r) ? r : tiles;
+}
+
 template <int K>
-static void launch_adjoint_k(const zf_op_plan& pl, hipStream_t st, const zf_op_args& P, const double* r, double* grad, double two_scale,
+static void launch_adjoint_k(const zf_op_plan& pl, hipStream_t st, const zf_op_args& P0, const double* r, double* grad, double two_scale,
                              const zf_op_fuse& F) {
-#define GO(TY, SEP) hipLaunchKernelGGL((zf_op_adjoint_kernel<K, TY, SEP>), dim3(pl.grid), dim3(ZF_BLOCK), 0, st, P, r, grad, two_scale, F)
+    zf_op_args P = P0;
+    P.tiles = pl.grid;
+#define GO(TY, SEP) hipLaunchKernelGGL((zf_op_adjoint_kernel<K, TY, SEP>), dim3(adjoint_wgs<K, TY, SEP>(pl.grid)), dim3(ZF_BLOCK), 0, st, P, r, grad, two_scale, F)
     if (pl.ty == 32 && pl.sep) GO(32, true);
     else if (pl.ty == 32) GO(32, false);
     else if (pl.ty == 16 && pl.sep) GO(16, true);

@@ -39,10 +39,38 @@ bool zf_op_factor_rank1(const double* taps, int k, double* u, double* v) {
     return true;
 }
 
+// workgroups of a launch: the tiles of the image, or - more tiles than the device holds workgroups of this kernel at once - that
+// many (a multiple of 8: a workgroup's tiles stay on its XCD); the kernels walk their tiles (ZF_OP_PERSIST=0: a workgroup per tile)
+bool zf_op_persist() {
+    static const bool on = [] {
+        const char* e = getenv("ZF_OP_PERSIST");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return on;
+}
+int zf_op_resident(const void* kernel, int* cache) {
+    if (*cache >= 0) return *cache;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, ZF_BLOCK, 0) != hipSuccess) return 0;
+    *cache = (per_cu * prop.multiProcessorCount) & ~7;
+    return *cache;
+}
+template <int K, int TY, bool SEP>
+static int apply_wgs(int tiles) {
+    static int cache = -1;
+    if (!zf_op_geo<K, TY>::WALK || !zf_op_persist()) return tiles;
+    const int r = zf_op_resident(reinterpret_cast<const void*>(zf_op_apply_kernel<K, TY, SEP>), &cache);
+    return (r > 0 && tiles > r) ? r : tiles;
+}
+
 template <int K>
-static void launch_apply_k(const zf_op_plan& pl, hipStream_t st, const zf_op_args& P, const double* x0, const double* x1, const double* x2,
+static void launch_apply_k(const zf_op_plan& pl, hipStream_t st, const zf_op_args& P0, const double* x0, const double* x1, const double* x2,
                            double* s0, double* s1, double* s2, int slot, const zf_op_fuse& F) {
-#define GO(TY, SEP) hipLaunchKernelGGL((zf_op_apply_kernel<K, TY, SEP>), dim3(pl.grid), dim3(ZF_BLOCK), 0, st, P, x0, x1, x2, s0, s1, s2, slot, F)
+    zf_op_args P = P0;
+    P.tiles = pl.grid;
+#define GO(TY, SEP) hipLaunchKernelGGL((zf_op_apply_kernel<K, TY, SEP>), dim3(apply_wgs<K, TY, SEP>(pl.grid)), dim3(ZF_BLOCK), 0, st, P, x0, x1, x2, s0, s1, s2, slot, F)
     if (pl.ty == 32 && pl.sep) GO(32, true);
     else if (pl.ty == 32) GO(32, false);
     else if (pl.ty == 16 && pl.sep) GO(16, true);

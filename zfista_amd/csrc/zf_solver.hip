@@ -334,6 +334,7 @@ static zf_op_args zf_op_of(const zf_problem_desc& d, const zf_control* ctl, cons
     P.sep = pl.sep ? sep : nullptr;
     static const int bands = [] { const char* e = getenv("ZF_OP_XCD_BANDS"); return e ? atoi(e) : 1; }();
     P.xcd_bands = bands;
+    P.tiles = pl.grid;
     return P;
 }
 static zf_op_args zf_op_of(const zf_solver* s, const zf_control* ctl) { return zf_op_of(s->desc, ctl, s->op_plan, s->op_taps, s->op_sep); }
