@@ -190,6 +190,39 @@ def test_prox_step_in_the_adjoint_kernel_equals_a_launch_of_its_own(case, monkey
         assert rel_err(a.x, exp.x) <= TOL
 
 
+@pytest.mark.parametrize("ksize,general", [(9, False), (7, True)])
+def test_workgroups_that_walk_their_tiles_with_partial_tiles_at_the_edges(ksize, general, monkeypatch):
+    """More tiles than the device holds workgroups (1410 of 64 x 32 on a 1502 x 1898 image, sides no multiples of the tile):
+    a workgroup walks several tiles, the apply kernel with the next tile's coefficients in flight.  ZF_OP_PERSIST=0 (a
+    workgroup per tile) adds the same shares in the same order: bit-identical; both equal the oracle."""
+    from oracle import cpu_ref, operator_ref as O
+    from zfista_amd import minimize_proximal_gradient
+    from zfista_amd.problems import BlurHaarL1
+
+    rng = np.random.default_rng(23)
+    kernel = O.gaussian_kernel(ksize, 2.0)
+    if general:
+        kernel = kernel + 0.3 * np.outer(np.arange(ksize), np.ones(ksize)) / ksize
+    kernel = kernel / kernel.sum()
+    observed = rng.standard_normal((1502, 1898))
+    prob = BlurHaarL1(kernel, observed, 0.02)
+    x0 = O.dwt(observed)
+    kw = dict(lr=0.5, nesterov=True, tol=0.0, max_iter=5)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ZF_OP_PERSIST", mode)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out[mode] = minimize_proximal_gradient(*prob.callbacks(), x0, **kw)
+    assert np.array_equal(out["1"].x, out["0"].x) and np.array_equal(np.asarray(out["1"].fun), np.asarray(out["0"].fun))
+    ref = O.BlurHaarL1Ref(kernel, observed, l1_ratio=0.02)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = cpu_ref.minimize_proximal_gradient(*ref.callbacks(), x0, **kw)
+    assert out["1"].nit == exp.nit and rel_err(out["1"].x, exp.x) <= TOL
+    np.testing.assert_allclose(np.asarray(out["1"].fun), np.asarray(exp.fun), rtol=TOL)
+
+
 def test_independent_solves_on_streams_equal_the_solves_alone():
     """zfista_amd.replicas.solve_on_streams: the notebook's sweep pattern (cameraman.ipynb cell 11: joblib over momentum
     settings) as host threads with a HIP stream each on ONE GPU - every result must be the one the same call gives alone."""
