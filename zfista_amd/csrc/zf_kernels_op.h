@@ -286,9 +286,19 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
         stage();
         __syncthreads();
         if (G::PREFETCH && v + (int)gridDim.x < NT) fetch(v + (int)gridDim.x);   // in flight during the correlation
+        // (the observed pixels this thread's outputs are compared with: fetched in front of the correlation too - behind it
+        //  every tile waited for them with nothing left to do)
+        const int ox = ox0 + c;
+        double bv[G::R];
+        if (F.on) {
+#pragma unroll
+            for (int o = 0; o < G::R; ++o) {
+                const int oy = oy0 + rg * G::R + o;
+                bv[o] = (oy < P.H && ox < P.W) ? F.b[(int64_t)oy * P.W + ox] : 0.0;
+            }
+        }
         double out[G::R];
         zf_op_correlate<K, TY, SEP>(P, tile, tmp, out);
-        const int ox = ox0 + c;
         double sq = 0.0;
 #pragma unroll
         for (int o = 0; o < G::R; ++o) {
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
             if (oy < P.H && ox < P.W) {
                 s[(int64_t)oy * P.W + ox] = out[o];
                 if (F.on) {
-                    const double rv = out[o] - F.b[(int64_t)oy * P.W + ox];
+                    const double rv = out[o] - bv[o];
                     sq = __builtin_fma(rv, rv, sq);
                 }
             }
