@@ -426,7 +426,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
     using G = zf_op_geo<K, TY>;
     __shared__ double tile[G::TILE_DOUBLES > TY * ZF_OP_TX ? G::TILE_DOUBLES : TY * ZF_OP_TX];   // later: the blurred tile
     __shared__ double tmp[SEP ? G::TMP_DOUBLES : 1];
-    __shared__ double s_w[ZF_WAVES];
+    __shared__ double s_w5[5][ZF_WAVES];   // the wave totals of a tile's five shares (|r|^2, <grad, dx>, |dx|^2, |x+|_1, max|dx|)
     const bool prox = F.on != 0 && F.prox != 0;
     if (P.ctl && (P.ctl->status != ZF_RUNNING || (!prox && !P.ctl->need_grad))) return;
     const double* __restrict__ sk = nullptr;
@@ -554,8 +554,8 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
         __syncthreads();
         if constexpr (G::PREFETCH_ADJ)
             if (v + (int)gridDim.x < NT) fetch(v + (int)gridDim.x);   // in flight during the correlation
-        if (F.on) {   // this tile's share of |r|^2: its own pixels (the halo belongs to the neighbours)
-            double sq = 0.0;
+        double sq = 0.0;
+        if (F.on) {   // this tile's share of |r|^2: its own pixels (the halo belongs to the neighbours); added up with the step's shares below
 #pragma unroll
             for (int o = 0; o < G::R; ++o) {
                 if (oy0 + rg * G::R + o < P.H && ox0 + c < P.W) {
@@ -563,8 +563,6 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
                     sq = __builtin_fma(rv, rv, sq);
                 }
             }
-            const double t = zf_op_block_sum(sq, s_w);
-            if (threadIdx.x == 0) F.part_y[v] = t;
         }
         double out[G::R];
         zf_op_correlate<K, TY, SEP>(P, tile, tmp, out);
@@ -600,27 +598,36 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
                 }
             }
         }
-        __syncthreads();   // (the blurred tile was read; s_w was read by every thread after the |r|^2 sum)
-        if (prox) {   // this tile's shares of the step's sums: rows of the quantity-major table the apply kernel adds up
-            const double dot = zf_op_block_sum(acc.dot, s_w);
-            __syncthreads();
-            const double ss = zf_op_block_sum(acc.ss, s_w);
-            __syncthreads();
-            const double l1 = zf_op_block_sum(acc.l1, s_w);
-            __syncthreads();
-            const double mw = zf_wave_max(acc.mx);
-            if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = mw;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double mx = s_w[0];
-                for (int wv = 1; wv < ZF_WAVES; ++wv) mx = fmax(mx, s_w[wv]);
-                F.step_part[1 * NG + v] = dot;
-                F.step_part[2 * NG + v] = ss;
-                F.step_part[3 * NG + v] = l1;
-                F.step_part[5 * NG + v] = mx;
+        // this tile's shares: ONE reduction for all five (a barrier pair, not five: a tile is a dozen phases between barriers and
+        // every one of them waits for the slowest wave) - wave totals by the fixed shuffle tree, then in wave order, as before
+        if (F.on) {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const double w0 = zf_wave_sum(sq), w1 = zf_wave_sum(acc.dot), w2 = zf_wave_sum(acc.ss), w3 = zf_wave_sum(acc.l1), w4 = zf_wave_max(acc.mx);
+            if (lane == 0) {
+                s_w5[0][wave] = w0;
+                s_w5[1][wave] = w1;
+                s_w5[2][wave] = w2;
+                s_w5[3][wave] = w3;
+                s_w5[4][wave] = w4;
             }
-            __syncthreads();   // s_w is free for the next tile
         }
+        __syncthreads();   // (also: the blurred tile was read)
+        if (F.on && threadIdx.x == 0) {
+            double tot[5];
+#pragma unroll
+            for (int qq = 0; qq < 5; ++qq) {
+                tot[qq] = s_w5[qq][0];
+                for (int wv = 1; wv < ZF_WAVES; ++wv) tot[qq] = qq == 4 ? fmax(tot[qq], s_w5[qq][wv]) : tot[qq] + s_w5[qq][wv];
+            }
+            F.part_y[v] = tot[0];
+            if (prox) {   // rows of the quantity-major table the apply kernel adds up
+                F.step_part[1 * NG + v] = tot[1];
+                F.step_part[2 * NG + v] = tot[2];
+                F.step_part[3 * NG + v] = tot[3];
+                F.step_part[5 * NG + v] = tot[4];
+            }
+        }
+        // (s_w5 is written again behind the barriers of the next tile's staging and correlation)
         if constexpr (!G::WALK) break;
     }
 }
