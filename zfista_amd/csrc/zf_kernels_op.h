@@ -222,7 +222,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_apply_kernel(zf_op_args P, con
     // second half: the host launches what the device holds at once).  A workgroup is three phases between barriers - tile
     // load, correlation, stores - and then, fused, two dependent trips to memory for its share and its ticket: with a
     // workgroup per tile every tile paid all of that as latency (2048 x 2048: 16 us in the life of a workgroup whose bytes
-    // need 2, 0.30 of HBM; profiles/r05_operator_pmc_2048x2048_one_tile_per_workgroup.json).  Now the coefficients of the
+    // need 2, 0.30 of HBM at 42.6 us; 35.9 us now: profiles/r05_operator_pmc_2048x2048.json).  Now the coefficients of the
     // NEXT tile are fetched into registers before the correlation of this one, shares are stored plainly, and the
     // ticket is taken once.  Shares are indexed by v as before: the sums of the last arriver are the same sums.
     const int tiles_x = (P.W + ZF_OP_TX - 1) / ZF_OP_TX;
