@@ -139,6 +139,32 @@ def test_clipped_problems_run_ahead(bounds, monkeypatch):
     assert got["nit"] >= 64 and got["ra"][0] >= 4 and got["ra"][1] >= 3, (got["nit"], got["ra"])   # (a clipped solve may end before max_iter: an iterate that no longer moves)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_solves_with_and_without_runahead_passes(seed, monkeypatch):
+    """A seeded sweep over what decides which passes run ahead - size (tiles per workgroup), the length of the solve (full
+    chains, shared tails, single tails), a box, momentum, a step size the line search has to cut first, the host's chunking:
+    always the results of one launch per pass, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(150_000, 6_000_000)) | 1
+    bounds = None if rng.random() < 0.6 else (-float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.2, 0.8)))
+    opts = dict(lr=float(rng.choice([0.45, 0.45, 0.9, 8.0])), nesterov=bool(rng.random() < 0.75), tol=0.0,
+                max_iter=int(rng.integers(9, 140)))
+    if rng.random() < 0.3:
+        opts["nesterov_ratio"] = (0.5, 1 / 16)
+    prob = _pdiag(n, seed=500 + seed, bounds=bounds)
+    x0 = rng.standard_normal(n) if bounds is None else np.clip(rng.standard_normal(n), *bounds)
+    chunk = int(rng.choice([64, 7, 3, 2]))
+    monkeypatch.setenv("ZF_RUNAHEAD", "0")
+    ref = _run(prob, x0, opts, chunk=chunk)
+    monkeypatch.delenv("ZF_RUNAHEAD")
+    got = _run(prob, x0, opts, chunk=chunk)
+    _same(got, ref)
+    # (a clean solve of two FULL chains or more: something ran ahead.  Clipped problems have no mid chains: 48 iterations are
+    #  16 + 16 + 16, 41 are 16 + 13 + 12 - one full chain, and the tail takes the general per-pass body)
+    if opts["max_iter"] >= (32 if bounds is None else 48) and ref["trials"] == ref["nit"] and ref["nit"] == opts["max_iter"] and chunk >= 2:
+        assert got["ra"][1] >= 1, (n, opts, bounds, got["ra"])
+
+
 def test_runahead_is_not_used_beyond_the_resident_grid():
     n = 30_000_000     # two rounds of workgroups
     r = _run(_pdiag(n, seed=9), np.zeros(n), dict(lr=0.45, nesterov=True, tol=0.0, max_iter=48))
