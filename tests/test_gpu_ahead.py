@@ -161,7 +161,7 @@ def test_passes_ahead_on_an_unsharded_grid_of_several_rounds(monkeypatch):
 
 def test_waits_that_give_up_are_counted_and_switch_run_ahead_off(monkeypatch):
     """The advisor's finding of round 4: a run-ahead wait that times out cost its whole limit, voided the pass - and was
-    invisible.  ZF_RUNAHEAD_SPIN_LIMIT=0 makes every workgroup that finds its predecessor unfinished give up at once.
+    invisible.  ZF_RUNAHEAD_SPIN_LIMIT=0 makes every workgroup of a pass launched behind a pass in flight give up at once (without looking: what it would find depends on the box).
     The device counts it, the next poll reads the count, the solver launches no further run-ahead passes, and the
     result of minimize_proximal_gradient says so - with every bit of the solve as it is without run-ahead passes."""
     from zfista_amd import minimize_proximal_gradient

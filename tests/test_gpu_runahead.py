@@ -172,7 +172,7 @@ def test_runahead_is_not_used_beyond_the_resident_grid():
 
 
 def test_a_wait_that_gives_up_voids_the_pass_and_the_solve_recovers(monkeypatch):
-    """ZF_RUNAHEAD_SPIN_LIMIT=0: every workgroup that finds its predecessor unfinished gives up at once - the pass
+    """ZF_RUNAHEAD_SPIN_LIMIT=0: every workgroup of a pass launched behind a pass in flight gives up at once - the pass
     contributes rows of zeros and must be void; the solve continues from the control block the next poll reads."""
     n = 1_000_001
     prob = _pdiag(n, seed=31)

@@ -1432,7 +1432,9 @@ __global__ __launch_bounds__(ZF_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
             } else {
                 unsigned k = 0;
                 for (;;) {
-                    if ((int)__hip_atomic_load(A.ra_flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.ra_wait) break;
+                    // (a limit of 0 - ZF_RUNAHEAD_SPIN_LIMIT=0, the tests' hook - gives up without looking: whether a predecessor
+                    //  happens to be finished at the first look depends on the box, the counters a test reads must not)
+                    if (A.ra_spin != 0 && (int)__hip_atomic_load(A.ra_flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.ra_wait) break;
                     // (the word every waiting workgroup would poll - one line, one memory channel, the one the deciding
                     //  wave of the predecessor writes to - only now and then: it matters when the predecessor is void)
                     if ((k & 15) == 15) {

@@ -241,7 +241,7 @@ struct zf_solver {
     bool ra = false;                      // eligible (separable f, chains of 16, one rank, a one-round grid) and not switched off (ZF_RUNAHEAD=0)
     int ra_cap = -1;                      // co-resident workgroups of the run-ahead full chain (-1: not asked yet)
     int ra_cap_mid[ZF_MAX_SUB_ITERS] = {};   // ... of the run-ahead mid chain of that length (0: no such kernel; asked at the first use: -1)
-    unsigned ra_spin = 1u << 13;          // polls before a wait gives up (ZF_RUNAHEAD_SPIN_LIMIT): ~15 ms, some tens of passes' worth
+    unsigned ra_spin = 1u << 13;          // polls before a wait gives up (ZF_RUNAHEAD_SPIN_LIMIT): ~15 ms, some tens of passes' worth; 0: every pass behind a pass in flight gives up at once (tests)
     hipStream_t stream2 = nullptr;
     hipEvent_t ra_join = nullptr;         // stream2 -> stream at the end of a run of run-ahead passes
     hipEvent_t ra_fork = nullptr;         // stream -> stream2 in front of a run
@@ -991,9 +991,15 @@ static int zf_launch_ahead(zf_solver* s, zf_step_args a, const zf_control& befor
     if (e0) ZF_HIP(hipEventRecord(e0, s->stream));
     if (part == 0) zf_launch_s16_ahead_full(v, s->grid, s->stream, a);
     else if (!zf_launch_s16_ahead_mid(v, nf, s->grid, s->stream, a)) return zf_fail(ZF_ERR_STATE, "zf_launch_ahead: no mid chain of that length%s");
-    if (e1) ZF_HIP(hipEventRecord(e1, s->stream));
-    ZF_HIP(hipEventRecord(s->ah_evT[k & 3], s->stream));
-    ZF_HIP(hipStreamWaitEvent(s->stream2, s->ah_evT[k & 3], 0));
+    // "trial kernel p is done": the timing mode's closing event when there is one (a wait captures what the event holds NOW) -
+    // every event packet between two trial kernels costs the chain 3-6 us (profiles/r05_event_probe.txt)
+    if (e1) {
+        ZF_HIP(hipEventRecord(e1, s->stream));
+        ZF_HIP(hipStreamWaitEvent(s->stream2, e1, 0));
+    } else {
+        ZF_HIP(hipEventRecord(s->ah_evT[k & 3], s->stream));
+        ZF_HIP(hipStreamWaitEvent(s->stream2, s->ah_evT[k & 3], 0));
+    }
     // rows -> packs; unsharded: the deciding wave of the same launch decides
     a.decide = s->comm ? 0 : 1;
     zf_launch_s16_tail(s->stream2, a);
