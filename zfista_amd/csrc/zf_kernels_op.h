@@ -632,7 +632,7 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_op_adjoint_kernel(zf_op_args P, c
     }
 }
 
-// ---- host side: which instantiation runs a problem (zf_op.hip) ----------------------------------------------------
+// ---- host side: which instantiation runs a problem (zf_op_apply.hip, zf_op_adjoint.hip) ----------------------------------------------------
 // K as launched: the caller's odd size (3 .. 15: each has its kernels; 1 is zero-padded to 3); ty = 32 (64 x 32 tiles)
 // when that still makes 256 tiles or more, else 8 (images of few tiles: more workgroups, shorter strips)
 struct zf_op_plan {

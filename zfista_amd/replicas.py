@@ -119,7 +119,7 @@ def solve_replicas(make_problem, starts, gpus=None, workers=None, quiet=True, **
 
 def solve_on_streams(jobs, streams=None, quiet=True):
     """Independent solves on ONE GPU at the same time: each job runs in a host thread of its own, on a HIP stream of its
-    own, so that solves too small to fill the device - a 256 x 256 deblurring problem is three launches of 128 workgroups
+    own, so that solves too small to fill the device - a 256 x 256 deblurring problem is two or three launches of 128 workgroups
     per iteration on a 256-CU chip - overlap instead of queueing behind each other.  The pattern of the reference's
     notebook (``examples/cameraman.ipynb`` cell 11: ``joblib.Parallel`` over 15 momentum settings of one problem) without
     processes: the problem's device arrays are shared, nothing is pickled.
