@@ -103,6 +103,7 @@ CASES = [
 def test_passes_ahead_through_the_communicator_equal_sequential_passes(case, world, monkeypatch):
     n, opts, bounds = CASES[case]
     x0 = np.zeros(n) if case % 2 == 0 else np.random.default_rng(case).standard_normal(n)
+    monkeypatch.setenv("ZF_RUNAHEAD_SHARDED", "0")   # (these grids fit the device: by default they take sharded run-ahead passes, below)
     monkeypatch.setenv("ZF_AHEAD", "0")
     ref = _sharded(world, n, 2 + case, opts, 64, bounds, x0)
     assert all(r["report"]["ahead"] == 0 for r in ref)
@@ -157,6 +158,38 @@ def test_passes_ahead_on_an_unsharded_grid_of_several_rounds(monkeypatch):
             got = _solve(DiagQuadL1(d, c, lam), np.zeros(n), opts, chunk=chunk)
             _same(got, ref)
             assert got["report"]["ahead"] >= 2 and got["report"]["runahead"] == 0
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_sharded_run_ahead_passes_equal_sequential_passes(case, world, monkeypatch):
+    """One-round grids behind a communicator (round 5, second half): the run-ahead kernels with packs instead of a decision,
+    all-gather + decide of pass p on a third stream beside the workgroups of pass p + 1.  The results of one pass at a time,
+    bit for bit, whatever the chunking; every rank launches the same passes.  World 1 = the 1-rank RCCL communicator; thread
+    ranks (several ranks of ONE device - by default they keep to passes ahead) only with grids of a few workgroups, all
+    of which the device holds at once."""
+    n, opts, bounds = CASES[case]
+    if world > 1 and n > 100_000:
+        pytest.skip("thread ranks share one device: their run-ahead passes would wait for workgroups that have no slot")
+    x0 = np.zeros(n) if case % 2 == 0 else np.random.default_rng(case).standard_normal(n)
+    monkeypatch.setenv("ZF_RUNAHEAD_SHARDED", "0")
+    monkeypatch.setenv("ZF_AHEAD", "0")
+    ref = _sharded(world, n, 2 + case, opts, 64, bounds, x0)
+    assert all(r["report"]["ahead"] == 0 and r["report"]["runahead"] == 0 for r in ref)
+    monkeypatch.delenv("ZF_AHEAD")
+    monkeypatch.setenv("ZF_RUNAHEAD_SHARDED", "1")
+    for chunk in (64, 5, 2, 1):
+        got = _sharded(world, n, 2 + case, opts, chunk, bounds, x0)
+        for r in range(world):
+            _same(got[r], ref[r])
+            rep = got[r]["report"]
+            assert rep == got[0]["report"], "every rank launches the same passes"
+            if chunk >= 2:
+                assert rep["runahead"] >= 2 and rep["runahead_overlapped"] >= 1, rep
+            assert rep["timeouts"] == 0 and not rep["runahead_off"]
+        if case in (3, 4, 5) and chunk == 64:
+            rep = got[0]["report"]
+            assert rep["ahead_void"] + rep["void"] >= 1, "a chain broke inside a chunk: the passes behind it are void and counted"
 
 
 def test_waits_that_give_up_are_counted_and_switch_run_ahead_off(monkeypatch):

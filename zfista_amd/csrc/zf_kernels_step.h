@@ -634,6 +634,16 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
         pk[ZF_PK_FX] = pk[ZF_PK_FY] + pk[7];
     }
     pk[6] = A.decide ? 0.0 : zf_pack_stamp(A.ctl_rw);   // sharded x: zf_decide_kernel checks whose packs it was given
+    if constexpr (RA) {
+        // A SHARDED run-ahead pass (round 5): the packs go to the all-gather and zf_decide_ahead_kernel on a third stream.  They
+        // carry the stamp of the block the HOST expected in front of this pass (the real block may be a decision behind) - or
+        // none, when a workgroup of this pass gave up waiting for its predecessor (rows of zeros): the decide step then
+        // finds packs that are not those of the block and voids the pass.
+        if (!A.decide) {
+            const bool poisoned = __hip_atomic_load(A.ra_flags + G + (A.pass_seq & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.pass_seq;
+            pk[6] = poisoned ? 0.0 : A.head_stamp;
+        }
+    }
     if (t % LSTR == 0) {
 #pragma unroll
         for (int k = 0; k < ZF_PACK_LEN; ++k) {
@@ -642,6 +652,10 @@ __device__ __forceinline__ void zf_pass_tail(const zf_step_args& A, const double
         }
     }
     if constexpr (RA) {
+        if (!A.decide) {   // (the shape of the pass: zf_decide_ahead overwrites it if the pass turns out void)
+            if (t == 0 && A.pass_log) A.pass_log[A.pass_slot] = A.pass_tag | zf_log_shape(0, LEN, 0);
+            return;
+        }
         constexpr int CW = (int)(sizeof(zf_control) / 8);
         static_assert(sizeof(zf_control) % 8 == 0 && CW <= 64, "one lane per word of the control block");
         unsigned long long* gw = reinterpret_cast<unsigned long long*>(const_cast<zf_control*>(A.ctl));
@@ -1329,6 +1343,17 @@ __global__ __launch_bounds__(ZF_BLOCK) void zf_trial_kernel(zf_step_args A) {
         if (A.ra_need != 0) {
             const unsigned long long W = __hip_atomic_load(A.ra_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((int)(unsigned)W < A.ra_need) return;   // (decided long ago: the launch came behind an event of that decide step)
+        } else if (A.ra_wait == 0) {
+            // The FIRST pass of a run: nothing is in flight (the host joined its streams), so the block may be read - and must
+            // be: the host's head is a prediction, and a run that starts in the middle of a chunk (behind passes of the other
+            // scheme, behind a chain that broke unseen) would otherwise write its iterates over what may be the real x_k.
+            // On a head that did not come true the pass leaves; its decide step finds the mismatch and voids it.
+            const zf_control* c = A.ctl;
+            constexpr int LEN0 = PART == 3 ? L : S;
+            const zf_pass_head& q = A.ra_head;
+            if (!(c->status == ZF_RUNNING && c->pend_status == 0 && c->lag == 0 && c->nit == q.nit && c->lr == q.lr && c->cur == q.cur &&
+                  c->prev == q.prev && zf_fresh_len(c) == LEN0))
+                return;
         }
         zf_pass_head HA = A.ra_head;
         HA.beta_next = NESTEROV ? A.beta_ring[HA.nit % ZF_RING] : 0.0;   // (zf_resolve_beta with nothing lagging)

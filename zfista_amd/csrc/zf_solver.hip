@@ -243,6 +243,11 @@ struct zf_solver {
     int ra_cap_mid[ZF_MAX_SUB_ITERS] = {};   // ... of the run-ahead mid chain of that length (0: no such kernel; asked at the first use: -1)
     unsigned ra_spin = 1u << 13;          // polls before a wait gives up (ZF_RUNAHEAD_SPIN_LIMIT): ~15 ms, some tens of passes' worth; 0: every pass behind a pass in flight gives up at once (tests)
     hipStream_t stream2 = nullptr;
+    hipStream_t stream3 = nullptr;        // sharded run-ahead passes: all-gather + decide of the pass before, beside the two trial streams
+    hipEvent_t ra_join3 = nullptr;        // stream3 -> stream at the end of such a run
+    bool ra_c_pending = false;            // stream3 holds work `stream` has not been made to wait for
+    bool ra_sharded = true;               // ZF_RUNAHEAD_SHARDED: one-round grids behind a library communicator take run-ahead passes (else passes ahead)
+    int64_t ras_passes = 0;               // sharded run-ahead passes launched
     hipEvent_t ra_join = nullptr;         // stream2 -> stream at the end of a run of run-ahead passes
     hipEvent_t ra_fork = nullptr;         // stream -> stream2 in front of a run
     bool ra_b_pending = false;            // stream2 holds work `stream` has not been made to wait for
@@ -294,6 +299,8 @@ constexpr bool ZF_AHEAD_UNSHARDED_DEFAULT = false;
 
 static int zf_solver_free_all(zf_solver* s) {
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
+    if (s->stream3) (void)hipStreamDestroy(s->stream3);
+    if (s->ra_join3) (void)hipEventDestroy(s->ra_join3);
     for (int k = 0; k < 4; ++k) {
         if (s->ah_evT[k]) (void)hipEventDestroy(s->ah_evT[k]);
         if (s->ah_evD[k]) (void)hipEventDestroy(s->ah_evD[k]);
@@ -404,6 +411,8 @@ static hipError_t zf_second_stream(zf_solver* s) {
     int lo = 0, hi = 0;
     ZF_E(hipDeviceGetStreamPriorityRange(&lo, &hi));
     ZF_E(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, hi));
+    ZF_E(hipStreamCreateWithPriority(&s->stream3, hipStreamNonBlocking, hi));
+    ZF_E(hipEventCreateWithFlags(&s->ra_join3, hipEventDisableTiming));
     ZF_E(hipEventCreateWithFlags(&s->ra_join, hipEventDisableTiming));
     ZF_E(hipEventCreateWithFlags(&s->ra_fork, hipEventDisableTiming));
     for (int k = 0; k < 4; ++k) {
@@ -524,7 +533,9 @@ extern "C" int zf_solver_create(zf_solver** out, const zf_problem_desc* desc, co
         const int64_t grid = (s->ntiles + t - 1) / t;
         if (const char* l = getenv("ZF_RUNAHEAD_SPIN_LIMIT")) s->ra_spin = (unsigned)strtoul(l, nullptr, 10);
         const bool chains16 = desc->kind == ZF_PROBLEM_DIAG_QUAD_L1 && s->sub >= 16 && !zf_fin_kernel_mode();
-        s->ra = on && chains16 && desc->world == 1;
+        // (world > 1, or one rank behind a communicator: the SHARDED run-ahead passes - same kernels, packs instead of a decision)
+        s->ra = on && chains16;
+        if (const char* se = getenv("ZF_RUNAHEAD_SHARDED")) s->ra_sharded = atoi(se) != 0;
         if (s->ra) {
             const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt, s->res};
             s->ra_cap = zf_runahead_capacity(v, s->sub);
@@ -875,6 +886,11 @@ static int zf_ra_join(zf_solver* s) {
         ZF_HIP(hipStreamWaitEvent(s->stream, s->ra_join, 0));
         s->ra_b_pending = false;
     }
+    if (s->ra_c_pending) {
+        ZF_HIP(hipEventRecord(s->ra_join3, s->stream3));
+        ZF_HIP(hipStreamWaitEvent(s->stream, s->ra_join3, 0));
+        s->ra_c_pending = false;
+    }
     s->ra_last = s->ra_last2 = 0;
     s->run_mode = 0;
     return ZF_OK;
@@ -883,8 +899,21 @@ static int zf_ra_join(zf_solver* s) {
 // A full chain the shadow predicts exactly, as a run-ahead pass (zf_runahead_kernel): behind another one of the same
 // run it goes to the other stream and starts while that one is still finalising.  `before`: the shadow control block
 // in front of this pass.
+static int zf_gather_packs(zf_solver* s, int64_t packs, hipStream_t st, const double* src = nullptr);
+
+// SHARDED (s->comm; round 5): the same kernels, the same flags between workgroups of consecutive passes - but the pass ends
+// with its packs (zf_pass_tail: decide == 0), and the all-gather + zf_decide_ahead_kernel of pass p run on a THIRD stream behind
+// an event, beside the workgroups of pass p + 1:
+//   stream  : T(0)            | [wait decided(0)] T(2) ...
+//   stream2 :    T(1) (workgroup j behind workgroup j of T(0))  | [wait decided(1)] T(3) ...
+//   stream3 : [wait T(0)] gather, decide(0) | [wait T(1)] gather, decide(1) | ...
+// The decide step checks the block against the head the pass ran on (a pass on a head that did not come true is void) and
+// publishes the done / good word the kernels read.  What a sharded one-round grid gets out of it is what the unsharded one
+// gets: the finalisation, the exchange and the decision of a pass no longer lie between two passes.
 static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& before, int nf, hipEvent_t e0, hipEvent_t e1) {
     const zf_trial_sel v = {s->opt.nesterov != 0, s->box, s->nt, s->res};
+    const bool sharded = s->comm != nullptr;
+    const int mode = sharded ? 3 : 1;
     zf_pass_head h;
     h.cur = before.cur;
     h.prev = before.prev;
@@ -892,7 +921,7 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
     h.lr = before.lr;
     h.beta_next = 0.0;
     h.nit = before.nit;
-    bool chain = s->run_mode == 1 && s->ra_last != 0 && a.pass_seq > s->ra_last;
+    bool chain = s->run_mode == mode && s->ra_last != 0 && a.pass_seq > s->ra_last;
     if (chain) {   // what this pass writes, the pass in flight must not be reading (six buffers in ring order: it never is)
         int f0, f1;
         zf_free_bufs(h.cur, h.prev, h.ring, &f0, &f1);
@@ -909,6 +938,7 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
         // out by construction).  Recorded before the launch, so the two passes still start together.
         ZF_HIP(hipEventRecord(s->ra_fork, s->stream));
         s->ra_fork_due = true;   // (waited for when - if - a pass of this run goes to the second stream)
+        s->ah_run = 0;
     } else {
         idx = 1 - s->ra_last_idx;
         if (idx == 1 && s->ra_fork_due) {
@@ -916,6 +946,7 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
             s->ra_fork_due = false;
         }
     }
+    const int k = s->ah_run;   // (number of the pass within its run: the events of a sharded run go by k % 4)
     a.ra_word = s->ra_word;
     a.ra_flags = s->ra_flags;
     a.ra_stats = s->ra_stats;
@@ -930,10 +961,38 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
         a.pack = s->pack2;
     }
     hipStream_t st = idx == 1 ? s->stream2 : s->stream;
+    if (sharded) {
+        a.decide = 0;
+        a.head_nf = nf;
+        a.head_stamp = zf_pack_stamp(&before);
+        // pass k writes what pass k - 2 (same stream) read, and reuses its rows and packs: that pass must have been DECIDED
+        // (third stream) - and as expected, which the kernel checks (ra_need)
+        if (k >= 2) ZF_HIP(hipStreamWaitEvent(st, s->ah_evD[(k - 2) & 3], 0));
+    }
     if (e0) ZF_HIP(hipEventRecord(e0, st));
     if (!zf_launch_s16_runahead(v, nf, s->grid, st, a)) return zf_fail(ZF_ERR_STATE, "zf_launch_runahead: no run-ahead kernel of that length%s");
     if (e1) ZF_HIP(hipEventRecord(e1, st));
-    s->run_mode = 1;
+    if (sharded) {
+        if (e1) {
+            ZF_HIP(hipStreamWaitEvent(s->stream3, e1, 0));
+        } else {
+            ZF_HIP(hipEventRecord(s->ah_evT[k & 3], st));
+            ZF_HIP(hipStreamWaitEvent(s->stream3, s->ah_evT[k & 3], 0));
+        }
+        int rc = zf_gather_packs(s, s->sub, s->stream3, a.pack);
+        if (rc) return rc;
+        zf_ahead_check H;
+        H.head = h;
+        H.nf = nf;
+        H.seq = a.pass_seq;
+        hipLaunchKernelGGL(zf_decide_ahead_kernel, dim3(1), dim3(64), 0, s->stream3, s->ctl, s->pack_all, s->trace, s->beta_ring, s->sub, H,
+                           s->ra_word, s->ra_stats, a.pass_log, a.pass_slot, a.pass_tag);
+        ZF_HIP(hipEventRecord(s->ah_evD[k & 3], s->stream3));
+        s->ra_c_pending = true;
+        s->ras_passes += 1;
+    }
+    s->run_mode = mode;
+    s->ah_run = k + 1;
     s->ah_last_nf = nf;
     s->ra_last2 = chain ? s->ra_last : 0;
     s->ra_last = a.pass_seq;
@@ -945,7 +1004,6 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
     return ZF_OK;
 }
 
-static int zf_gather_packs(zf_solver* s, int64_t packs, hipStream_t st);
 
 // A full or mid chain the shadow predicts exactly, as a pass AHEAD of its predecessor's decision at kernel granularity:
 //   stream  : ... T(p) | T(p+1) | [wait decided(p)] T(p+2) ...        trial kernels back to back, each on the head the
@@ -982,6 +1040,7 @@ static int zf_launch_ahead(zf_solver* s, zf_step_args a, const zf_control& befor
     a.ra_word = s->ra_word;
     a.ra_stats = s->ra_stats;
     a.ra_need = chain ? s->ra_last2 : 0;
+    a.ra_wait = chain ? s->ra_last : 0;   // (0: the first pass of a run - its kernel checks the block against the head)
     a.ra_head = h;
     a.head_nf = nf;
     a.head_stamp = zf_pack_stamp(&before);
@@ -1074,7 +1133,8 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         // passes that run ahead of their predecessor's decision: at workgroup granularity (unsharded one-round grids), or
         // at kernel granularity (through the library's communicator; ZF_AHEAD_UNSHARDED: other unsharded grids)
         const bool two_streams = s->stream2 != nullptr && !dry && !fin_kernel && !s->hist && s->shadow_valid;
-        const bool ra_can = two_streams && s->ra && !s->ra_off && decide_in_launch && !s->comm;
+        const bool ra_can = two_streams && s->ra && !s->ra_off &&
+                            (s->comm ? (!decide_in_launch && s->ra_sharded && s->stream3 != nullptr) : decide_in_launch);
         // (unsharded: what the run-ahead kernel does not take - grids of several rounds, clipped problems, and on its own
         //  grids the mid chains of a shared tail)
         const bool ah_can = two_streams && s->ah && s->ring >= 6 &&
@@ -1093,7 +1153,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         // n = 4e6 .. 1e7 +2-3 %, with bench.py's events +4-7 %): below, two launches on one stream cost less than the fork and
         // join of two; above, the chain of <= 10 trials is HBM-bound and its per-pass kernel loads through registers, 4 % faster
         // than the DMA pipeline the coherent loads need.
-        const bool mid_run = s->run_mode == 1 && s->ra_last != 0;
+        const bool mid_run = (s->run_mode == 1 || s->run_mode == 3) && s->ra_last != 0;
         if (ra_can && exact && !ra_ok && s->part_mask == ZF_K_MID && nf_before == s->mid_len && nf_before < ZF_MAX_SUB_ITERS &&
             (mid_run || (s->tiles >= ZF_RA_MID_START_MIN_TILES && s->tiles <= ZF_RA_MID_START_MAX_TILES))) {
             int& cap = s->ra_cap_mid[nf_before];
@@ -1120,6 +1180,7 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         if (ra_ok) {
             int rc = zf_launch_runahead(s, a, before, nf_before, e0, e1);
             if (rc) return rc;
+            if (s->comm && done_ahead) *done_ahead = true;   // (exchange and decide step are enqueued: third stream)
         } else if (ah_ok) {
             int rc = zf_launch_ahead(s, a, before, s->part_mask == ZF_K_FULL ? 0 : 3, nf_before, e0, e1);
             if (rc) return rc;
@@ -1693,6 +1754,13 @@ extern "C" int zf_solver_set_comm(zf_solver* s, zf_comm* comm) {
     if (rc) return rc;
     ZF_REQUIRE(rank == s->desc.rank && world == s->desc.world, "zf_solver_set_comm: rank / world differ from the problem descriptor");
     s->comm = comm;
+    {   // Thread ranks (the in-process group: several ranks of ONE device) do not hold two passes of every rank at once - sharded
+        // run-ahead passes would wait for workgroups that have no slot (correct, counted, switched off at the first poll, but
+        // 15 ms per wait): those groups keep to passes ahead, which never wait inside a kernel.  ZF_RUNAHEAD_SHARDED=1 insists.
+        zf_comm_desc cd;
+        if (world > 1 && !getenv("ZF_RUNAHEAD_SHARDED") && zf_comm_describe(comm, &cd, (int64_t)sizeof(cd)) == ZF_OK && cd.kind == 1)
+            s->ra_sharded = false;
+    }
     // passes ahead of their predecessor's decision (zf_launch_ahead) need six iterate buffers and the second stream: a
     // one-rank solver was created without knowing that a communicator would follow (before the initialisation only)
     if (s->ah && !s->initialised && (s->ring < 6 || !s->stream2)) {
@@ -1717,9 +1785,10 @@ extern "C" int zf_solver_set_comm(zf_solver* s, zf_comm* comm) {
     return ZF_OK;
 }
 
-static int zf_gather_packs(zf_solver* s, int64_t packs, hipStream_t st) {
+static int zf_gather_packs(zf_solver* s, int64_t packs, hipStream_t st, const double* src) {
     if (!st) st = s->stream;
-    if (!s->timing) return zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, st);
+    if (!src) src = s->pack_local;
+    if (!s->timing) return zf_comm_all_gather(s->comm, src, s->pack_all, packs * ZF_PACK_LEN, st);
     // timed: from "this rank's packs are ready" to "the gathered packs are here" on this rank's stream - the
     // collective itself plus the wait for the slowest rank (zf_solver_exchange_stats)
     if (s->xev_used == s->xev_pool.size()) {
@@ -1730,7 +1799,7 @@ static int zf_gather_packs(zf_solver* s, int64_t packs, hipStream_t st) {
     }
     const auto& ev = s->xev_pool[s->xev_used++];
     ZF_HIP(hipEventRecord(ev.first, st));
-    const int rc = zf_comm_all_gather(s->comm, s->pack_local, s->pack_all, packs * ZF_PACK_LEN, st);
+    const int rc = zf_comm_all_gather(s->comm, src, s->pack_all, packs * ZF_PACK_LEN, st);
     ZF_HIP(hipEventRecord(ev.second, st));
     return rc;
 }
