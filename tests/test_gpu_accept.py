@@ -210,7 +210,7 @@ def test_a_long_solve_ends_at_max_iter_not_in_backtracking_failed():
 ])
 def test_every_way_of_running_a_pass_agrees_in_the_resolved_mode(n, opts, monkeypatch):
     """Chains of 16 with run-ahead passes (the default on these grids), one launch per pass, single trials, and the solve
-    through a 1-rank RCCL communicator with passes ahead: one result, bit for bit."""
+    through a 1-rank RCCL communicator with sharded run-ahead passes and with passes ahead: one result, bit for bit."""
     import torch
 
     from zfista_amd.comm import LibComm
@@ -226,12 +226,15 @@ def test_every_way_of_running_a_pass_agrees_in_the_resolved_mode(n, opts, monkey
     _same(ra, plain)
     monkeypatch.delenv("ZF_RUNAHEAD")
     _same(_run(prob, x0, opts, sub=1), plain)
-    comm = LibComm(0, 1, LibComm.new_unique_id())
-    sharded = _run(DiagQuadL1(d, c, lam, group=comm), x0, opts, chunk=8)
-    torch.cuda.synchronize()
-    comm.close()
-    assert sharded["report"]["ahead"] >= 2
-    _same(sharded, plain)
+    for scheme in ("run-ahead", "ahead"):   # (behind a communicator a one-round grid takes sharded run-ahead passes; else passes ahead)
+        if scheme == "ahead":
+            monkeypatch.setenv("ZF_RUNAHEAD_SHARDED", "0")
+        comm = LibComm(0, 1, LibComm.new_unique_id())
+        sharded = _run(DiagQuadL1(d, c, lam, group=comm), x0, opts, chunk=8)
+        torch.cuda.synchronize()
+        comm.close()
+        assert sharded["report"]["ahead" if scheme == "ahead" else "runahead"] >= 2, (scheme, sharded["report"])
+        _same(sharded, plain)
 
 
 def test_the_mode_is_refused_where_it_does_not_exist():
