@@ -1133,12 +1133,14 @@ static int zf_launch_trial(zf_solver* s, bool decide_in_launch, bool dry = false
         // passes that run ahead of their predecessor's decision: at workgroup granularity (unsharded one-round grids), or
         // at kernel granularity (through the library's communicator; ZF_AHEAD_UNSHARDED: other unsharded grids)
         const bool two_streams = s->stream2 != nullptr && !dry && !fin_kernel && !s->hist && s->shadow_valid;
+        // (behind a communicator only from zf_solver_enqueue_steps, which hands over done_ahead: a caller that drives trial /
+        //  exchange / decide itself - zf_solver_enqueue_trial - gets one pass at a time, whatever is attached)
         const bool ra_can = two_streams && s->ra && !s->ra_off &&
-                            (s->comm ? (!decide_in_launch && s->ra_sharded && s->stream3 != nullptr) : decide_in_launch);
+                            (s->comm ? (!decide_in_launch && done_ahead != nullptr && s->ra_sharded && s->stream3 != nullptr) : decide_in_launch);
         // (unsharded: what the run-ahead kernel does not take - grids of several rounds, clipped problems, and on its own
         //  grids the mid chains of a shared tail)
         const bool ah_can = two_streams && s->ah && s->ring >= 6 &&
-                            (s->comm ? !decide_in_launch : (decide_in_launch && s->ah_unsharded && d.world == 1));
+                            (s->comm ? (!decide_in_launch && done_ahead != nullptr) : (decide_in_launch && s->ah_unsharded && d.world == 1));
         const bool have_before = ra_can || ah_can;
         if (have_before) before = s->shadow;
         s->part_mask = (dry || !(decide_in_launch || s->comm)) ? ZF_K_ALL : zf_predict_parts(s);
