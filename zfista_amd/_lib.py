@@ -267,7 +267,7 @@ ENV_SWITCHES = ("ZF_FIN_KERNEL", "ZF_SPECULATE", "ZF_NT", "ZF_LS_SMALL", "ZF_GEM
                 "ZF_COMM", "ZF_MO_COMM", "ZF_MO_LAUNCH_AHEAD", "ZF_MO_SPIN_LIMIT", "ZF_RCCL_LIB", "ZF_DUAL_SOLVER",
                 "ZF_FORCE_SPLIT", "ZF_LIB_PATH", "ZF_MID_CHAINS", "ZF_BENCH_BACKEND",
                 "ZF_RUNAHEAD", "ZF_RUNAHEAD_SPIN_LIMIT", "ZF_SHORT_VIA_GENERAL", "ZF_PASS_SEQ_START", "ZF_AHEAD",
-                "ZF_AHEAD_UNSHARDED", "ZF_ACCEPT", "ZF_OP_SEPARABLE", "ZF_OP_TY", "ZF_OP_XCD_BANDS", "ZF_OP_FUSE_PROX", "ZF_OP_PERSIST", "ZF_RUNAHEAD_SHARDED")
+                "ZF_AHEAD_UNSHARDED", "ZF_ACCEPT", "ZF_OP_SEPARABLE", "ZF_OP_TY", "ZF_OP_XCD_BANDS", "ZF_OP_FUSE_PROX", "ZF_OP_PERSIST", "ZF_RUNAHEAD_SHARDED", "ZF_RAS_LAST_INLINE")
 
 
 def env_overrides() -> dict:

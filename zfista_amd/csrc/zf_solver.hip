@@ -246,6 +246,7 @@ struct zf_solver {
     hipStream_t stream3 = nullptr;        // sharded run-ahead passes: all-gather + decide of the pass before, beside the two trial streams
     hipEvent_t ra_join3 = nullptr;        // stream3 -> stream at the end of such a run
     bool ra_c_pending = false;            // stream3 holds work `stream` has not been made to wait for
+    bool chunk_last = false;              // the step being enqueued is the last of its zf_solver_enqueue_steps call
     bool ra_sharded = true;               // ZF_RUNAHEAD_SHARDED: one-round grids behind a library communicator take run-ahead passes (else passes ahead)
     int64_t ras_passes = 0;               // sharded run-ahead passes launched
     hipEvent_t ra_join = nullptr;         // stream2 -> stream at the end of a run of run-ahead passes
@@ -973,22 +974,30 @@ static int zf_launch_runahead(zf_solver* s, zf_step_args a, const zf_control& be
     if (!zf_launch_s16_runahead(v, nf, s->grid, st, a)) return zf_fail(ZF_ERR_STATE, "zf_launch_runahead: no run-ahead kernel of that length%s");
     if (e1) ZF_HIP(hipEventRecord(e1, st));
     if (sharded) {
-        if (e1) {
-            ZF_HIP(hipStreamWaitEvent(s->stream3, e1, 0));
+        // exchange and decide step: on the third stream behind an event - but for the LAST pass of a chunk, which nothing
+        // runs beside: on the pass's own stream (one hop between queues, ~20 us, less in front of the poll; the decide steps stay
+        // in order through the event of the one before, long signalled by then)
+        static const bool last_inline = [] { const char* e = getenv("ZF_RAS_LAST_INLINE"); return e ? atoi(e) != 0 : true; }();
+        hipStream_t ds = s->stream3;
+        if (s->chunk_last && last_inline) {
+            ds = st;
+            if (k >= 1) ZF_HIP(hipStreamWaitEvent(ds, s->ah_evD[(k - 1) & 3], 0));
+        } else if (e1) {
+            ZF_HIP(hipStreamWaitEvent(ds, e1, 0));
         } else {
             ZF_HIP(hipEventRecord(s->ah_evT[k & 3], st));
-            ZF_HIP(hipStreamWaitEvent(s->stream3, s->ah_evT[k & 3], 0));
+            ZF_HIP(hipStreamWaitEvent(ds, s->ah_evT[k & 3], 0));
         }
-        int rc = zf_gather_packs(s, s->sub, s->stream3, a.pack);
+        int rc = zf_gather_packs(s, s->sub, ds, a.pack);
         if (rc) return rc;
         zf_ahead_check H;
         H.head = h;
         H.nf = nf;
         H.seq = a.pass_seq;
-        hipLaunchKernelGGL(zf_decide_ahead_kernel, dim3(1), dim3(64), 0, s->stream3, s->ctl, s->pack_all, s->trace, s->beta_ring, s->sub, H,
+        hipLaunchKernelGGL(zf_decide_ahead_kernel, dim3(1), dim3(64), 0, ds, s->ctl, s->pack_all, s->trace, s->beta_ring, s->sub, H,
                            s->ra_word, s->ra_stats, a.pass_log, a.pass_slot, a.pass_tag);
-        ZF_HIP(hipEventRecord(s->ah_evD[k & 3], s->stream3));
-        s->ra_c_pending = true;
+        ZF_HIP(hipEventRecord(s->ah_evD[k & 3], ds));
+        if (ds == s->stream3) s->ra_c_pending = true;
         s->ras_passes += 1;
     }
     s->run_mode = mode;
@@ -1846,7 +1855,10 @@ extern "C" int zf_solver_enqueue_steps(zf_solver* s, int64_t steps) {
         // same gathered packs, so nothing else is exchanged.  A pass AHEAD (zf_launch_ahead) has enqueued all of it
         // already: finalisation, exchange and decide on the second stream, beside the next pass's trial kernel.
         bool ahead = false;
-        if ((rc = zf_launch_trial(s, false, false, &ahead))) return rc;
+        s->chunk_last = k + 1 == steps;
+        rc = zf_launch_trial(s, false, false, &ahead);
+        s->chunk_last = false;
+        if (rc) return rc;
         if (ahead) continue;
         if ((rc = zf_gather_svec(s))) return rc;
         if ((rc = zf_solver_enqueue_trial_finish(s))) return rc;
