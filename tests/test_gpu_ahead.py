@@ -192,6 +192,46 @@ def test_sharded_run_ahead_passes_equal_sequential_passes(case, world, monkeypat
             assert rep["ahead_void"] + rep["void"] >= 1, "a chain broke inside a chunk: the passes behind it are void and counted"
 
 
+@pytest.mark.parametrize("bounds", [None, (-0.3, 0.4)])
+def test_the_two_schemes_mixed_in_one_chunk_start_their_runs_on_the_real_block(bounds, monkeypatch):
+    """A run that starts in the middle of a chunk starts on a PREDICTED head.  With both schemes on (unsharded: run-ahead
+    passes for full chains, passes ahead - ZF_AHEAD_UNSHARDED=1 - for what those do not take: the tail, and every mid chain
+    of a clipped problem) and a step size the line search cuts several times inside the first chunk, the first kernel of every
+    run has to find out from the block that its head did not come true - or it writes its iterates over the real x_k
+    (found with the sharded run-ahead passes; the same hole, closed the same way)."""
+    n = 300_001
+    d, c, lam = _data(n, 77)
+    from zfista_amd.problems import DiagQuadL1
+
+    for opts in (dict(lr=16.0, nesterov=True, tol=0.0, max_iter=150), dict(lr=0.45, nesterov=True, tol=0.0, max_iter=16 * 5 + 26)):
+        monkeypatch.setenv("ZF_RUNAHEAD", "0")
+        monkeypatch.setenv("ZF_AHEAD_UNSHARDED", "0")
+        ref = _solve(DiagQuadL1(d, c, lam, bounds=bounds), np.zeros(n), opts)
+        monkeypatch.delenv("ZF_RUNAHEAD")
+        monkeypatch.setenv("ZF_AHEAD_UNSHARDED", "1")
+        for chunk in (64, 7, 2):
+            got = _solve(DiagQuadL1(d, c, lam, bounds=bounds), np.zeros(n), opts, chunk=chunk)
+            _same(got, ref)
+        got = _solve(DiagQuadL1(d, c, lam, bounds=bounds), np.zeros(n), opts, chunk=64)
+        assert got["report"]["runahead"] >= 1, got["report"]
+
+
+def test_sharded_run_ahead_passes_at_the_size_of_cfg2(monkeypatch):
+    """n = 10^7 behind the 1-rank RCCL communicator: one round of 489 workgroups of ten tiles, both sharded schemes, against
+    the unsharded solve - bit for bit (150 iterations: across the noise floor of this size, chains break)."""
+    n = 10_000_000
+    opts = dict(lr=0.45, nesterov=True, tol=0.0, max_iter=150)
+    d, c, lam = _data(n, 5)
+    from zfista_amd.problems import DiagQuadL1
+
+    one = _solve(DiagQuadL1(d, c, lam), np.zeros(n), opts)
+    for scheme in ("1", "0"):
+        monkeypatch.setenv("ZF_RUNAHEAD_SHARDED", scheme)
+        got = _sharded(1, n, 5, opts, 64, None, np.zeros(n))[0]
+        _same(got, one)
+        assert got["report"]["runahead" if scheme == "1" else "ahead"] >= 2, got["report"]
+
+
 def test_waits_that_give_up_are_counted_and_switch_run_ahead_off(monkeypatch):
     """The advisor's finding of round 4: a run-ahead wait that times out cost its whole limit, voided the pass - and was
     invisible.  ZF_RUNAHEAD_SPIN_LIMIT=0 makes every workgroup of a pass launched behind a pass in flight give up at once (without looking: what it would find depends on the box).
